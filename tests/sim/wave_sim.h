@@ -1,0 +1,174 @@
+// TEST INFRASTRUCTURE -- a 64-lane CPU simulator of the "wave policy" that
+// webrtc_aecm_amd/csrc/aecm_wave.h is written against.  It lets the CPU-only test suite run the very
+// same block-DSP source that the HIP kernel instantiates and compare it with the oracle.  It is never
+// built into, linked with or called by the product library.
+#ifndef AECM_TESTS_WAVE_SIM_H_
+#define AECM_TESTS_WAVE_SIM_H_
+
+#include <stdint.h>
+
+#include <cmath>
+
+#include "aecm_ops.h"
+#include "aecm_tables.h"
+
+namespace aecm {
+
+struct VecB {
+    bool v[64];
+};
+struct VecI {
+    int v[64];
+    VecI() { for (int i = 0; i < 64; ++i) v[i] = 0; }
+    VecI(int s) { for (int i = 0; i < 64; ++i) v[i] = s; }   // NOLINT: implicit broadcast on purpose
+};
+
+#define SIM_BIN(NAME, EXPR)                                                   \
+    inline VecI NAME(const VecI &a, const VecI &b) {                          \
+        VecI r;                                                               \
+        for (int i = 0; i < 64; ++i) { int x = a.v[i], y = b.v[i]; r.v[i] = (EXPR); } \
+        return r;                                                             \
+    }
+SIM_BIN(operator+, add(x, y))
+SIM_BIN(operator-, sub(x, y))
+SIM_BIN(operator*, mul(x, y))
+SIM_BIN(operator&, x & y)
+SIM_BIN(operator|, x | y)
+SIM_BIN(operator^, x ^ y)
+SIM_BIN(operator<<, shl(x, y))
+SIM_BIN(operator>>, sar(x, y))
+SIM_BIN(shl, shl(x, y))
+SIM_BIN(sar, sar(x, y))
+SIM_BIN(lsr, lsr(x, y))
+SIM_BIN(mul, mul(x, y))
+SIM_BIN(add, add(x, y))
+SIM_BIN(sub, sub(x, y))
+SIM_BIN(imin, imin(x, y))
+SIM_BIN(imax, imax(x, y))
+SIM_BIN(divi, divi(x, y))
+SIM_BIN(divu, divu(x, y))
+#undef SIM_BIN
+
+#define SIM_UN(NAME, EXPR)                                                    \
+    inline VecI NAME(const VecI &a) {                                         \
+        VecI r;                                                               \
+        for (int i = 0; i < 64; ++i) { int x = a.v[i]; r.v[i] = (EXPR); }     \
+        return r;                                                             \
+    }
+SIM_UN(operator~, ~x)
+SIM_UN(neg, neg(x))
+SIM_UN(sext16, sext16(x))
+SIM_UN(zext16, zext16(x))
+SIM_UN(iabs, iabs(x))
+SIM_UN(clz32, clz32(x))
+SIM_UN(popc, popc(x))
+#undef SIM_UN
+
+#define SIM_CMP(NAME, EXPR)                                                   \
+    inline VecB NAME(const VecI &a, const VecI &b) {                          \
+        VecB r;                                                               \
+        for (int i = 0; i < 64; ++i) { int x = a.v[i], y = b.v[i]; r.v[i] = (EXPR); } \
+        return r;                                                             \
+    }
+SIM_CMP(operator==, x == y)
+SIM_CMP(operator!=, x != y)
+SIM_CMP(operator<, x < y)
+SIM_CMP(operator<=, x <= y)
+SIM_CMP(operator>, x > y)
+SIM_CMP(operator>=, x >= y)
+SIM_CMP(ltu, ltu(x, y))
+SIM_CMP(gtu, gtu(x, y))
+#undef SIM_CMP
+
+#define SIM_MASK(NAME, EXPR)                                                  \
+    inline VecB NAME(const VecB &a, const VecB &b) {                          \
+        VecB r;                                                               \
+        for (int i = 0; i < 64; ++i) { bool x = a.v[i], y = b.v[i]; r.v[i] = (EXPR); } \
+        return r;                                                             \
+    }
+SIM_MASK(operator&, x && y)
+SIM_MASK(operator|, x || y)
+SIM_MASK(operator==, x == y)
+SIM_MASK(operator!=, x != y)
+#undef SIM_MASK
+inline VecB operator!(const VecB &a) { VecB r; for (int i = 0; i < 64; ++i) r.v[i] = !a.v[i]; return r; }
+inline VecB operator&(const VecB &a, bool b) { VecB r; for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] && b; return r; }
+inline VecB operator&(bool b, const VecB &a) { return a & b; }
+
+inline VecI sel(const VecB &c, const VecI &a, const VecI &b) {
+    VecI r;
+    for (int i = 0; i < 64; ++i) r.v[i] = c.v[i] ? a.v[i] : b.v[i];
+    return r;
+}
+inline VecI sel(bool c, const VecI &a, const VecI &b) { return c ? a : b; }
+
+struct SimTables {
+    static int hann(int i) { return kAecmSqrtHanningQ14[i]; }
+};
+
+// The policy itself.  Cross-lane primitives are written from their mathematical definition, not
+// from any GPU instruction, so the simulator is an independent statement of what each one means.
+struct SimWave {
+    using vi = VecI;
+    using vb = VecB;
+
+    static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
+    static bool is_first_lane() { return true; }
+
+    static vi lut(const int16_t *t, int n, const vi &idx) {
+        vi r;
+        for (int i = 0; i < 64; ++i) r.v[i] = t[((idx.v[i] % n) + n) % n];
+        return r;
+    }
+    static vi hann(const vi &i) { return lut(kAecmSqrtHanningQ14, 65, i); }
+    static vi twiddle_cos(const vi &i) { return lut(kAecmTwiddleCosQ15, 64, i); }
+    static vi twiddle_sin(const vi &i) { return lut(kAecmTwiddleSinQ15, 64, i); }
+    static vi cos360(const vi &i) { return lut(kAecmCosQ13, 360, i); }
+    static vi sin360(const vi &i) { return lut(kAecmSinQ13, 360, i); }
+    static int cos360(int i) { return kAecmCosQ13[i]; }
+    static int sin360(int i) { return kAecmSinQ13[i]; }
+
+    // Re-pair FFT operands across lane bit Q: lanes with bit Q clear keep a and receive the
+    // partner's a into b; lanes with bit Q set keep b and receive the partner's b into a.
+    template <int Q>
+    static void exchange(vi &a, vi &b) {
+        vi na = a, nb = b;
+        for (int i = 0; i < 64; ++i) {
+            int p = i ^ (1 << Q);
+            if ((i >> Q) & 1) na.v[i] = b.v[p];
+            else nb.v[i] = a.v[p];
+        }
+        a = na;
+        b = nb;
+    }
+    static int reduce_max(const vi &v) { int m = v.v[0]; for (int i = 1; i < 64; ++i) m = v.v[i] > m ? v.v[i] : m; return m; }
+    static int reduce_min(const vi &v) { int m = v.v[0]; for (int i = 1; i < 64; ++i) m = v.v[i] < m ? v.v[i] : m; return m; }
+    static int reduce_add(const vi &v) { int s = 0; for (int i = 0; i < 64; ++i) s = add(s, v.v[i]); return s; }
+    static uint64_t ballot(const vb &m) { uint64_t r = 0; for (int i = 0; i < 64; ++i) r |= (uint64_t)(m.v[i] ? 1 : 0) << i; return r; }
+    static int readlane(const vi &v, int lane) { return v.v[lane & 63]; }
+    static vi writelane(const vi &v, int value, int lane) { vi r = v; r.v[lane & 63] = value; return r; }
+    static vi bpermute(const vi &v, const vi &src) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = v.v[src.v[i] & 63]; return r; }
+    static vi shift_up1(const vi &v, int fill) { vi r; r.v[0] = fill; for (int i = 1; i < 64; ++i) r.v[i] = v.v[i - 1]; return r; }
+    static vi isqrt31(const vi &v) {
+        vi r;
+        for (int i = 0; i < 64; ++i) {
+            uint32_t x = (uint32_t)v.v[i];
+            uint32_t s = (uint32_t)std::sqrt((double)x);
+            while ((uint64_t)s * s > x) --s;
+            while ((uint64_t)(s + 1) * (s + 1) <= x) ++s;
+            r.v[i] = (int)s;
+        }
+        return r;
+    }
+    static int isqrt31(int v) { return isqrt31(vi(v)).v[0]; }
+
+    static vi load_u32(const uint32_t *p, const vi &idx) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = (int)p[idx.v[i]]; return r; }
+    static void store_u32(uint32_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) p[idx.v[i]] = (uint32_t)val.v[i]; }
+    static vi load_i16(const int16_t *p, const vi &idx) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = p[idx.v[i]]; return r; }
+    static vi load_u16(const uint16_t *p, const vi &idx) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = p[idx.v[i]]; return r; }
+    static void store_i16(int16_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) p[idx.v[i]] = (int16_t)val.v[i]; }
+    static void store_u16(uint16_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) p[idx.v[i]] = (uint16_t)val.v[i]; }
+};
+
+}  // namespace aecm
+#endif  // AECM_TESTS_WAVE_SIM_H_

@@ -1,0 +1,85 @@
+"""TEST INFRASTRUCTURE: build + bind tests/_build/libaecm_sim.so -- the product's wave-generic block
+DSP (webrtc_aecm_amd/csrc/aecm_wave.h) instantiated on a 64-lane CPU simulator (tests/sim/)."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "webrtc_aecm_amd" / "csrc"
+SIM_SO = ROOT / "tests" / "_build" / "libaecm_sim.so"
+_SOURCES = [ROOT / "tests" / "sim" / "sim_lib.cpp", CSRC / "aecm_host_state.cpp"]
+_DEPS = _SOURCES + [ROOT / "tests" / "sim" / "wave_sim.h", CSRC / "aecm_wave.h", CSRC / "aecm_ops.h",
+                    CSRC / "aecm_state.h", CSRC / "aecm_host_state.h", CSRC / "aecm_tables.h"]
+_i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def build():
+    if SIM_SO.exists() and all(SIM_SO.stat().st_mtime >= d.stat().st_mtime for d in _DEPS):
+        return
+    SIM_SO.parent.mkdir(parents=True, exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fwrapv", "-fPIC", "-shared", f"-I{CSRC}",
+                           f"-I{ROOT / 'tests' / 'sim'}", *map(str, _SOURCES), "-o", str(SIM_SO)])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(str(SIM_SO))
+        l.sim_create.restype = C.c_void_p
+        l.sim_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        l.sim_free.argtypes = [C.c_void_p]
+        l.sim_control.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.sim_set_echo_path.argtypes = [C.c_void_p, _i16p]
+        l.sim_get_echo_path.argtypes = [C.c_void_p, _i16p]
+        l.sim_process.argtypes = [C.c_void_p, _i16p, _i16p, C.c_void_p, _i16p, C.c_int]
+        l.sim_digest.argtypes = [C.c_void_p, _u32p]
+        _lib = l
+    return _lib
+
+
+class SimStream:
+    def __init__(self, fs=16000, cng_mode=1, echo_mode=3):
+        self.lib = lib()
+        self.h = self.lib.sim_create(fs, cng_mode, echo_mode)
+        if not self.h:
+            raise ValueError("bad parameters")
+
+    def control(self, fixed_delay, nlp_flag):
+        self.lib.sim_control(self.h, fixed_delay, nlp_flag)
+
+    def process(self, far, near, clean=None):
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        out = np.empty_like(near)
+        cptr = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            cptr = clean.ctypes.data_as(C.c_void_p)
+        self.lib.sim_process(self.h, far, near, cptr, out, far.size // 64)
+        return out
+
+    def digest(self):
+        d = np.zeros(24, dtype=np.uint32)
+        self.lib.sim_digest(self.h, d)
+        return d
+
+    def init_echo_path(self, path):
+        self.lib.sim_set_echo_path(self.h, np.ascontiguousarray(path, dtype=np.int16))
+
+    def echo_path(self):
+        p = np.zeros(65, dtype=np.int16)
+        self.lib.sim_get_echo_path(self.h, p)
+        return p
+
+    def __del__(self):
+        try:
+            self.lib.sim_free(self.h)
+        except Exception:
+            pass

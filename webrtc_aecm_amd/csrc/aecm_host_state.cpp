@@ -1,0 +1,175 @@
+#include "aecm_host_state.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+#include "aecm_tables.h"
+
+namespace aecm {
+namespace {
+
+inline uint32_t Pack16(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | (((uint32_t)(uint16_t)hi) << 16); }
+inline int Lo16(uint32_t w) { return (int16_t)(w & 0xffff); }
+inline int Hi16(uint32_t w) { return (int16_t)(w >> 16); }
+inline uint32_t FnvStep(uint32_t h, uint32_t w) { return (h ^ w) * 16777619u; }
+constexpr uint32_t kFnvInit = 2166136261u;
+inline int BitRev6(int t) {
+    int r = 0;
+    for (int b = 0; b < 6; ++b) r |= ((t >> b) & 1) << (5 - b);
+    return r;
+}
+
+}  // namespace
+
+bool ApplyConfig(int32_t *scal, int cng_mode, int echo_mode) {
+    if (cng_mode != 0 && cng_mode != 1) return false;
+    if (echo_mode < 0 || echo_mode > 4) return false;
+    // SUPGAIN_DEFAULT / ERROR_PARAM_A / _B / _D (reference aecm/aecm_defines.h:62-68), scaled per echoMode
+    int g = 256, a = 3072, b = 1536, d = 256;
+    if (echo_mode < 3) {
+        const int s = 3 - echo_mode;
+        g >>= s; a >>= s; b >>= s; d >>= s;
+    } else if (echo_mode == 4) {
+        g <<= 1; a <<= 1; b <<= 1; d <<= 1;
+    }
+    scal[S_CNG] = cng_mode;
+    scal[S_SUPGAIN] = g;
+    scal[S_SUPGAIN_OLD] = g;
+    scal[S_SG_A] = a;
+    scal[S_SG_D] = d;
+    scal[S_SG_DAB] = a - b;
+    scal[S_SG_DBD] = b - d;
+    return true;
+}
+
+void ApplyControl(int32_t *scal, int fixed_delay, int nlp_flag) {
+    scal[S_NLP] = (int16_t)nlp_flag;
+    scal[S_FIXED_DELAY] = (int16_t)fixed_delay;
+}
+
+void SetEchoPath(uint32_t *vec, int32_t *scal, const int16_t path[kBins]) {
+    for (int t = 0; t < kLanes; ++t) {
+        vec[V_CH16 * kLanes + t] = Pack16(path[t], path[t]);
+        vec[V_CH32 * kLanes + t] = (uint32_t)(int32_t)path[t] << 16;
+    }
+    scal[S_B64_CHSTORED] = path[64];
+    scal[S_B64_CHADAPT16] = path[64];
+    scal[S_B64_CHADAPT32] = (int32_t)((uint32_t)(int32_t)path[64] << 16);
+    scal[S_MSE_ADAPT_OLD] = 1000;
+    scal[S_MSE_STORED_OLD] = 1000;
+    scal[S_MSE_THRESH] = 0x7fffffff;
+    scal[S_MSECNT] = 0;
+}
+
+void GetEchoPath(const uint32_t *vec, const int32_t *scal, int16_t path[kBins]) {
+    for (int t = 0; t < kLanes; ++t) path[t] = (int16_t)Lo16(vec[V_CH16 * kLanes + t]);
+    path[64] = (int16_t)scal[S_B64_CHSTORED];
+}
+
+bool BuildInitImage(int fs, StreamImage *img) {
+    if (fs != 8000 && fs != 16000) return false;
+    std::fill(img->vec.begin(), img->vec.end(), 0u);
+    std::fill(img->scal.begin(), img->scal.end(), 0);
+    uint32_t *vec = img->vec.data();
+    int32_t *scal = img->scal.data();
+    scal[S_MULT] = fs / 8000;                               // aecm_core.cc:368
+    scal[S_SEED] = 666;                                     // :385
+    scal[S_HISTPOS] = kHistory;                             // :397
+    scal[S_NLP] = 1;                                        // :399
+    scal[S_FIXED_DELAY] = -1;                               // :400
+    for (int t = 0; t < kLanes; ++t) {                      // delay_estimator.cc:490-493
+        vec[V_M0 * kLanes + t] = 20 << 9;
+        vec[V_M1 * kLanes + t] = t < kHistory - 64 ? (20 << 9) : 0;
+    }
+    scal[S_MIN_PROB] = 32 << 9;                             // delay_estimator.cc:494-498
+    scal[S_LAST_PROB] = 32 << 9;
+    scal[S_LAST_DELAY] = -2;
+    SetEchoPath(vec, scal, fs == 8000 ? kAecmChannelStored8k : kAecmChannelStored16k);   // :413-417
+    {                                                       // :427-435 pink-ish initial noise floor
+        int32_t t32 = kBins * kBins;
+        int16_t t16 = kBins;
+        int32_t noise[kBins];
+        int i = 0;
+        for (; i < (kBins >> 1) - 1; ++i) {
+            noise[i] = t32 << 8;
+            t16--;
+            t32 -= (int32_t)((t16 << 1) + 1);
+        }
+        for (; i < kBins; ++i) noise[i] = t32 << 8;
+        for (int t = 0; t < kLanes; ++t) vec[V_NOISE * kLanes + t] = (uint32_t)noise[t];
+        scal[S_B64_NOISE] = noise[64];
+    }
+    scal[S_FE_MIN] = 32767;                                 // :437-445
+    scal[S_FE_MAX] = -32768;
+    scal[S_FE_VAD] = 1025;
+    scal[S_FIRSTVAD] = 1;
+    scal[S_CNG] = 1;                                        // :423
+    return ApplyConfig(scal, 1, 3);
+}
+
+void ComputeDigest(const uint32_t *vec, const int32_t *scal, const uint16_t *hist, uint32_t d[kDigestWords]) {
+    auto V = [&](int f, int t) { return vec[f * kLanes + t]; };
+    uint32_t h;
+    d[0] = (uint32_t)scal[S_TOTCOUNT];
+    d[1] = (uint32_t)scal[S_SEED];
+    d[2] = Pack16(scal[S_STARTUP], scal[S_HISTPOS]);
+    d[3] = Pack16(scal[S_DFANOISYQ], scal[S_DFANOISYQ_OLD]);
+    d[4] = Pack16(scal[S_FARLOG], scal[S_FE_MIN]);
+    d[5] = Pack16(scal[S_FE_MAX], scal[S_FE_MAXMIN]);
+    d[6] = Pack16(scal[S_FE_VAD], scal[S_FE_MSE]);
+    d[7] = Pack16(scal[S_CURVAD], scal[S_VADCNT]);
+    d[8] = Pack16(scal[S_FIRSTVAD], scal[S_MSECNT]);
+    d[9] = (uint32_t)scal[S_MSE_ADAPT_OLD];
+    d[10] = (uint32_t)scal[S_MSE_STORED_OLD];
+    d[11] = (uint32_t)scal[S_MSE_THRESH];
+    d[12] = Pack16(scal[S_SUPGAIN], scal[S_SUPGAIN_OLD]);
+    d[13] = (uint32_t)scal[S_LAST_DELAY];
+    d[14] = (uint32_t)scal[S_MIN_PROB];
+    d[15] = (uint32_t)scal[S_LAST_PROB];
+    h = kFnvInit;
+    for (int i = 0; i < kLanes; ++i) h = FnvStep(h, V(V_CH16, i));
+    d[16] = FnvStep(h, Pack16(scal[S_B64_CHSTORED], scal[S_B64_CHADAPT16]));
+    h = kFnvInit;
+    for (int i = 0; i < kLanes; ++i) h = FnvStep(h, V(V_CH32, i));
+    d[17] = FnvStep(h, (uint32_t)scal[S_B64_CHADAPT32]);
+    h = kFnvInit;
+    for (int i = 0; i < kLanes; ++i) h = FnvStep(h, V(V_ECHOFILT, i));
+    d[18] = FnvStep(h, (uint32_t)scal[S_B64_ECHOFILT]);
+    h = kFnvInit;
+    for (int i = 0; i < kLanes; ++i) h = FnvStep(h, V(V_NEARFILT, i) & 0xffffu);
+    d[19] = FnvStep(h, (uint32_t)(uint16_t)scal[S_B64_NEARFILT]);
+    h = kFnvInit;
+    for (int i = 0; i < kLanes; ++i) {
+        h = FnvStep(h, V(V_NOISE, i));
+        const uint32_t w = V(V_NEARFILT, i);
+        h = FnvStep(h, Pack16((w >> 16) & 255, w >> 24));
+    }
+    h = FnvStep(h, (uint32_t)scal[S_B64_NOISE]);
+    h = FnvStep(h, Pack16(scal[S_B64_LOWCTR], scal[S_B64_HIGHCTR]));
+    d[20] = FnvStep(h, (uint32_t)(uint16_t)scal[S_NOISECTR]);
+    h = kFnvInit;
+    for (int i = 12; i <= 43; ++i) { h = FnvStep(h, V(V_MEANFAR, i)); h = FnvStep(h, V(V_MEANNEAR, i)); }
+    for (int i = 0; i < kHistory; ++i) {
+        h = FnvStep(h, i < 64 ? V(V_BH0, i) : V(V_BH1, i - 64));
+        h = FnvStep(h, i < 64 ? V(V_M0, i) : V(V_M1, i - 64));
+    }
+    d[21] = FnvStep(h, Pack16(scal[S_FAR_INIT], scal[S_NEAR_INIT]));
+    h = kFnvInit;
+    for (int i = 0; i < kLanes; ++i) { h = FnvStep(h, V(V_LOG_NA, i)); h = FnvStep(h, V(V_LOG_S, i) & 0xffffu); }
+    d[22] = h;
+    h = kFnvInit;
+    for (int i = 0; i < kLanes; ++i) {
+        h = FnvStep(h, V(V_XD_OLD, i));
+        h = FnvStep(h, V(V_OUTBUF, BitRev6(i)) & 0xffffu);
+    }
+    for (int p = 0; p < kHistory; ++p) {
+        const uint32_t side = p < 64 ? V(V_HQ0, p) : V(V_HQ1, p - 64);
+        h = FnvStep(h, (uint32_t)Hi16(side));
+        for (int i = 0; i < kLanes; ++i) h = FnvStep(h, (uint32_t)hist[p * kLanes + i]);
+        h = FnvStep(h, side & 0xffffu);
+    }
+    d[23] = h;
+}
+
+}  // namespace aecm

@@ -1,0 +1,71 @@
+// Scalar fixed-point primitives with fully defined semantics (two's complement wrap, 5-bit shift
+// counts, arithmetic >> on signed) used by the wave-generic block DSP (aecm_wave.h).
+//
+// On the GPU a "lane vector" is simply an int held in a VGPR, so these scalar overloads ARE the
+// vector operations; the CPU lane simulator used by the tests adds 64-wide overloads with the same
+// names (tests/sim/wave_sim.h).  They restate the reference's SPL helpers:
+//   norm_w32 / norm_u32 / norm_w16  -> aecm/spl_inl.h:97-111
+//   add_sat32 / sat16               -> aecm/spl_inl.h:59-85
+//   shift_i / shift_u               -> WEBRTC_SPL_SHIFT_W32, aecm/signal_processing_library.h:128
+//   divi / divu                     -> WebRtcSpl_DivW32W16 / DivU32U16, aecm/signal_processing_library.cc:107-123
+#ifndef AECM_AMD_OPS_H_
+#define AECM_AMD_OPS_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define AECM_HD __host__ __device__ __forceinline__
+#else
+#define AECM_HD inline
+#endif
+
+namespace aecm {
+
+AECM_HD int shl(int a, int n) { return (int)((unsigned)a << (n & 31)); }
+AECM_HD int sar(int a, int n) { return a >> (n & 31); }
+AECM_HD int lsr(int a, int n) { return (int)((unsigned)a >> (n & 31)); }
+AECM_HD int mul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+AECM_HD int add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+AECM_HD int sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+AECM_HD int neg(int a) { return (int)(0u - (unsigned)a); }
+AECM_HD int sext16(int a) { return (int)(int16_t)a; }
+AECM_HD int zext16(int a) { return a & 0xffff; }
+AECM_HD int sel(bool c, int a, int b) { return c ? a : b; }
+AECM_HD int imin(int a, int b) { return a < b ? a : b; }
+AECM_HD int imax(int a, int b) { return a > b ? a : b; }
+AECM_HD int iabs(int a) { return a < 0 ? neg(a) : a; }
+AECM_HD bool ltu(int a, int b) { return (unsigned)a < (unsigned)b; }
+AECM_HD bool gtu(int a, int b) { return (unsigned)a > (unsigned)b; }
+AECM_HD int clz32(int a) { return a == 0 ? 32 : __builtin_clz((unsigned)a); }
+AECM_HD int popc(int a) { return __builtin_popcount((unsigned)a); }
+// Truncating signed / unsigned division with the reference's divide-by-zero results.
+AECM_HD int divi(int a, int b) {
+    if (b == 0) return 0x7fffffff;
+    if (b == -1) return neg(a);
+    return a / b;
+}
+AECM_HD int divu(int a, int b) { return b == 0 ? -1 : (int)((unsigned)a / (unsigned)b); }
+
+// ---- generic (scalar or lane-vector) helpers built on the overload set above --------------------
+template <class I> AECM_HD I norm_u32(I a) { return sel(a == 0, I(0), clz32(a)); }
+template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 1); }
+template <class I> AECM_HD I norm_w16(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 17); }
+template <class I> AECM_HD I add_sat32(I a, I b) {
+    I s = add(a, b);
+    auto ovf = ((a < 0) == (b < 0)) & ((a < 0) != (s < 0));
+    return sel(ovf, sel(s < 0, I(0x7fffffff), I((int)0x80000000)), s);
+}
+template <class I> AECM_HD I sat16(I v) { return imax(imin(v, I(32767)), I(-32768)); }
+// c >= 0: x * 2^c (wrapping); c < 0: arithmetic / logical right shift by -c.
+template <class I, class C> AECM_HD I shift_i(I x, C c) { return sel(c >= 0, shl(x, c), sar(x, neg(c))); }
+template <class I, class C> AECM_HD I shift_u(I x, C c) { return sel(c >= 0, shl(x, c), lsr(x, neg(c))); }
+// new = mean + ((new - mean) >> factor) with the shift applied to the magnitude
+// (WebRtc_MeanEstimatorFix, aecm/delay_estimator.cc:690-702).
+template <class I, class C> AECM_HD I mean_step(I value, C factor, I mean) {
+    I diff = sub(value, mean);
+    return add(mean, sel(diff < 0, neg(sar(neg(diff), factor)), sar(diff, factor)));
+}
+
+}  // namespace aecm
+#endif  // AECM_AMD_OPS_H_

@@ -1,0 +1,94 @@
+// Device-resident per-stream state layout of the MI355X AECM engine (shared by host and device).
+//
+// One wavefront (64 lanes) owns one stream.  A stream's state is three HBM regions:
+//
+//   vec  : uint32_t [S][kNumVec][64]   "lane vectors": word v, lane t  -> one 256-byte line per
+//                                       field per wave, loaded/stored once per launch
+//   scal : int32_t  [S][64]            wave-uniform scalars (+ everything that belongs to bin 64)
+//   hist : uint16_t [S][100][64]       far-spectrum history, bins 0..63 (reference far_history,
+//                                       aecm/aecm_core.h:64); one 128-byte row written and (when
+//                                       the estimated delay is not 0) one row read per block
+//
+// Lane t owns frequency bin t (0..63), time samples t and t+64, delay-estimator history slots t and
+// t+64 (<100) and log-energy history entry t.  Bin 64 (the real-only Nyquist bin) is wave-uniform and
+// lives in scal[].  The field list mirrors the live subset of the reference's AecmCore
+// (aecm/aecm_core.h:41-141) and delay estimator (aecm/delay_estimator.h:22-63,
+// aecm/delay_estimator_wrapper.cc:25-47); see DESIGN.md section 3 for the mapping table.
+#ifndef AECM_AMD_STATE_H_
+#define AECM_AMD_STATE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace aecm {
+
+constexpr int kBlock = 64;      // PART_LEN   (reference aecm/aecm_defines.h:19)
+constexpr int kBins = 65;       // PART_LEN1  (aecm_defines.h:22)
+constexpr int kHistory = 100;   // MAX_DELAY  (aecm_defines.h:26)
+constexpr int kLanes = 64;
+
+// ---- lane-vector words ------------------------------------------------------------------------
+enum VecField : int {
+    V_XD_OLD = 0,   // lo16: xBuf[t] (previous far block), hi16: dBufNoisy[t] (previous near block)
+    V_OUTBUF,       // lo16: outBuf[bitrev6(t)] (overlap-add tail, kept in IFFT output lane order)
+                    // hi16: dBufClean[t] (previous clean-near block; only used with a clean input)
+    V_CH16,         // lo16: channelStored[t], hi16: channelAdapt16[t]
+    V_CH32,         // channelAdapt32[t]
+    V_ECHOFILT,     // echoFilt[t]
+    V_NEARFILT,     // lo16: nearFilt[t], bits 16..23: noiseEstTooLowCtr[t], bits 24..31: ...TooHighCtr[t]
+    V_NOISE,        // noiseEst[t]
+    V_MEANFAR,      // mean_far_spectrum[t]  (only bins 12..43 are ever touched)
+    V_MEANNEAR,     // mean_near_spectrum[t]
+    V_BH0,          // binary_far_history[t]        (slot 0 = newest)
+    V_BH1,          // binary_far_history[t + 64]   (t < 36)
+    V_M0,           // mean_bit_counts[t]
+    V_M1,           // mean_bit_counts[t + 64]      (t < 36)
+    V_HQ0,          // far history side band, slot t      : lo16 = far_history[slot][64], hi16 = far_q
+    V_HQ1,          // far history side band, slot t + 64
+    V_LOG_NA,       // lo16: nearLogEnergy[t], hi16: echoAdaptLogEnergy[t]
+    V_LOG_S,        // lo16: echoStoredLogEnergy[t]
+    kNumVec
+};
+
+// ---- wave-uniform scalars ---------------------------------------------------------------------
+enum ScalField : int {
+    S_TOTCOUNT = 0, S_SEED, S_STARTUP, S_HISTPOS,
+    S_DFANOISYQ, S_DFANOISYQ_OLD, S_DFACLEANQ, S_DFACLEANQ_OLD,
+    S_FARLOG, S_FE_MIN, S_FE_MAX, S_FE_MAXMIN, S_FE_VAD, S_FE_MSE,
+    S_CURVAD, S_VADCNT, S_FIRSTVAD, S_MSECNT,
+    S_MSE_ADAPT_OLD, S_MSE_STORED_OLD, S_MSE_THRESH,
+    S_SUPGAIN, S_SUPGAIN_OLD, S_NOISECTR,
+    S_FAR_INIT, S_NEAR_INIT, S_MIN_PROB, S_LAST_PROB, S_LAST_DELAY,
+    // configuration (written by init / set_config / control)
+    S_MULT, S_CNG, S_NLP, S_FIXED_DELAY, S_SG_A, S_SG_D, S_SG_DAB, S_SG_DBD,
+    // bin 64
+    S_B64_CHSTORED, S_B64_CHADAPT16, S_B64_CHADAPT32, S_B64_ECHOFILT, S_B64_NEARFILT,
+    S_B64_NOISE, S_B64_LOWCTR, S_B64_HIGHCTR,
+    kNumScalUsed,
+    kNumScal = 64
+};
+static_assert(kNumScalUsed <= kNumScal, "scalar block overflow");
+
+constexpr size_t kVecWordsPerStream = size_t(kNumVec) * kLanes;
+constexpr size_t kHistWordsPerStream = size_t(kHistory) * kLanes;   // uint16 units
+
+struct StatePtrs {
+    uint32_t *vec;
+    int32_t *scal;
+    uint16_t *hist;
+};
+
+// Strided view of the audio I/O of one launch: sample (stream s, block b, i) lives at
+// base[s * stream_stride + b * block_stride + i].  Stream-major files are (T*64, 64); a tick-major
+// server layout [T][S][64] is (64, S*64).
+struct IoView {
+    const int16_t *far;
+    const int16_t *near;
+    const int16_t *near_clean;   // optional (nullptr): the reference's nearendClean input
+    int16_t *out;
+    int64_t stream_stride;
+    int64_t block_stride;
+};
+
+}  // namespace aecm
+#endif  // AECM_AMD_STATE_H_

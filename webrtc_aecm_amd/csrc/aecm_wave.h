@@ -1,0 +1,746 @@
+// Wave-generic AECM block DSP: one 64-lane wavefront processes one stream, block after block.
+//
+// This header is the single source of the hot path.  It is written against a small "wave policy"
+// W (lane-vector type, cross-lane exchange, reductions, ballots, LDS-table lookups, coalesced
+// loads/stores) and is instantiated twice:
+//   * webrtc_aecm_amd/csrc/aecm_kernels.hip  with the gfx950 policy (vi = int in a VGPR, DPP /
+//     permlane / ds_bpermute cross-lane ops, tables in LDS)  -> the product;
+//   * tests/sim/  with a 64-lane CPU simulator policy               -> test infrastructure that
+//     lets `pytest -m "not gpu"` check this very code against the oracle without a GPU.
+//
+// Behavioural spec: WebRtcAecm_ProcessBlock and everything below it (reference
+// aecm/aecm_core_c.cc:368-711; each section cites the lines it restates).  All arithmetic is
+// Q-format integer and bit-exact; SURVEY.md Appendix A lists the C-semantics traps reproduced here.
+//
+// Data placement (lane t of 64):
+//   time domain   : samples t (old half) and t+64 (new half) of a 128-sample analysis window
+//   FFT           : radix-2 DIT on bit-reversed input == lane t starts with points n=t and n=t+64
+//                   (positions bitrev7(n) = 2*bitrev6(t) and +1), one butterfly per lane per stage;
+//                   between stages the two operands are re-paired by a lane exchange on lane bit
+//                   5,4,3,2,1,0 (xor 32,16,8,4,2,1).  After the 7th stage lane t holds points
+//                   bitrev6(t) and bitrev6(t)+64.
+//   frequency dom.: bin t in lane t (one ds_bpermute after the forward FFT); bin 64 wave-uniform
+//   delay estim.  : history slots t and t+64 (<100); mean_far/near thresholds for bins 12..43
+//   synthesis     : IFFT output stays in bit-reversed lane order; the overlap buffer is kept in that
+//                   order, so no permutation is needed before the coalesced 128-byte store.
+#ifndef AECM_AMD_WAVE_H_
+#define AECM_AMD_WAVE_H_
+
+#include "aecm_ops.h"
+#include "aecm_state.h"
+
+namespace aecm {
+
+// ---- algorithm constants (reference aecm/aecm_defines.h:17-85, delay_estimator.cc:23-28) --------
+constexpr int kConvLen = 512, kConvLen2 = 1024;
+constexpr int kFarEnergyMin = 1025, kFarEnergyDiff = 929, kEnergyDevTol = 400, kFarEnergyVadRegion = 230;
+constexpr int kMuMin = 10, kMuMax = 1, kMuDiff = 9;
+constexpr int kMinMseCount = 20, kMinMseDiff = 29, kMseResolution = 5;
+constexpr int kResChannel16 = 12, kResChannel32 = 28, kChannelVad = 16, kResSupgain = 8;
+constexpr int kSupgainEpcDt = 200, kOneQ14 = 1 << 14, kNlpCompLow = 3277, kNlpCompHigh = kOneQ14;
+constexpr int kBandFirst = 12, kBandLast = 43;
+constexpr int kMaxBitCountsQ9 = 32 << 9, kProbOffset = 1024, kProbLowerLimit = 8704, kProbMinSpread = 2816;
+
+// Per-bin persistent state; I = lane vector for bins 0..63, int for bin 64.
+template <class I>
+struct BinState {
+    I ch_stored, ch_adapt16, ch_adapt32, echo_filt, near_filt, noise_est, low_ctr, high_ctr;
+};
+
+// Wave-uniform persistent state (mirrors the scalar members of the reference's AecmCore).
+struct Uniform {
+    int tot_count, seed, startup, hist_pos;
+    int dfa_noisy_q, dfa_noisy_q_old, dfa_clean_q, dfa_clean_q_old;
+    int far_log, fe_min, fe_max, fe_maxmin, fe_vad, fe_mse;
+    int cur_vad, vad_cnt, first_vad, mse_cnt;
+    int mse_adapt_old, mse_stored_old, mse_thresh;
+    int sup_gain, sup_gain_old, noise_ctr;
+    int far_init, near_init, min_prob, last_prob, last_delay;
+    int mult, cng, nlp, fixed_delay, sg_a, sg_d, sg_dab, sg_dbd;
+};
+
+template <class W, bool kHasClean>
+struct BlockEngine {
+    using vi = typename W::vi;
+    using vb = typename W::vb;
+
+    // Everything a wave keeps in registers across the blocks of one launch.
+    struct Regs {
+        Uniform u;
+        BinState<vi> b;       // bins 0..63
+        BinState<int> b64;    // bin 64
+        vi x_old, d_old, c_old, out_ovl;
+        vi mean_far, mean_near, bh0, bh1, m0, m1, hq0, hq1;
+        vi near_log, adapt_log, stored_log;
+        // lane constants
+        vi lane, brev, hann_lo, hann_hi, hann_syn_lo, hann_syn_hi, lcg_mul, lcg_add;
+        int lcg_mul64, lcg_add64;
+    };
+
+    struct Spectrum {
+        vi re, im, mag;       // bins 0..63
+        int re64, mag64;      // bin 64 (imaginary part is 0 by construction)
+        int sum;              // sum of |X| over the 65 bins (uint32 wrap)
+        int q;                // dynamic Q of the block
+    };
+
+    // ------------------------------------------------------------------------------------------
+    // lane constants
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD vi bitrev6(vi t) {
+        vi r = ((t & 1) << 5) | ((t & 2) << 3) | ((t & 4) << 1) | (lsr(t, 1) & 4) | (lsr(t, 3) & 2) | (lsr(t, 5) & 1);
+        return r;
+    }
+
+    static AECM_HD void init_lane_constants(Regs &r) {
+        r.lane = W::lane_id();
+        r.brev = bitrev6(r.lane);
+        r.hann_lo = W::hann(r.lane);                    // analysis window, first half : hann[t]
+        r.hann_hi = W::hann(vi(64) - r.lane);           //                  second half: hann[64-t]
+        r.hann_syn_lo = W::hann(r.brev);                // synthesis window in IFFT output lane order
+        r.hann_syn_hi = W::hann(vi(64) - r.brev);
+        // LCG jump-ahead: after j steps seed_j = A^j * seed + C_j (mod 2^31); draw j-1 feeds bin j
+        // (reference spl.cc:129-147, aecm_core_c.cc:143-150), so lane t needs j = t, bin 64 and the
+        // carried-over seed need j = 64.
+        vi a = vi(1), c = vi(0);
+        int a64 = 1, c64 = 0;
+        for (int j = 1; j <= 64; ++j) {
+            a64 = mul(a64, 69069);
+            c64 = add(mul(c64, 69069), 1);
+            auto here = (r.lane == vi(j));
+            a = sel(here, vi(a64), a);
+            c = sel(here, vi(c64), c);
+        }
+        r.lcg_mul = a;
+        r.lcg_add = c;
+        r.lcg_mul64 = a64;
+        r.lcg_add64 = c64;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // 128-point radix-2 transforms (reference aecm/complex_fft.c:241-491 "mode 1", with the
+    // bit reversal of :181-209 folded into the lane placement)
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD vi pack(vi re, vi im) { return zext16(re) | shl(im, 16); }
+    static AECM_HD vi lo16(vi p) { return sext16(p); }
+    static AECM_HD vi hi16(vi p) { return sar(p, 16); }
+
+    // a = packed (re,im) of the butterfly's upper operand (position i), b = lower (position i+l).
+    // Returns the sum of the per-stage shifts (inverse only; the reference's return value "scale").
+    template <bool kInverse>
+    static AECM_HD int fft128(const Regs &r, vi &a, vi &b) {
+        int scale = 0;
+        // stage s pairs positions differing in bit s; the operands of stage s>0 are brought
+        // together by exchanging on lane bit (6 - s).
+#define AECM_FFT_STAGE(S)                                                                          \
+        {                                                                                          \
+            if (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);                            \
+            vi ar = lo16(a), ai = hi16(a), br = lo16(b), bi = hi16(b);                             \
+            int shift = 0, round2 = 8192;                                                          \
+            if (kInverse) { /* complex_fft.c:382-396: data-dependent scaling per stage */          \
+                vi m = imax(imax(iabs(ar), iabs(ai)), imax(iabs(br), iabs(bi)));                   \
+                int mx = imin(W::reduce_max(m), 32767);                                            \
+                if (mx > 13573) { shift++; scale++; round2 <<= 1; }                                \
+                if (mx > 27146) { shift++; scale++; round2 <<= 1; }                                \
+            }                                                                                      \
+            /* twiddle index m << k with m = position & (2^S - 1), k = 9 - S, in units of 8 */     \
+            vi tw = shl(r.brev & vi((1 << S) - 1), 6 - S);                                         \
+            vi wr = W::twiddle_cos(tw);                                                            \
+            vi wi = kInverse ? W::twiddle_sin(tw) : neg(W::twiddle_sin(tw));                       \
+            vi tr = sar(sub(mul(wr, br), mul(wi, bi)) + 1, 1);       /* :332-338 / :465-469 */     \
+            vi ti = sar(add(mul(wr, bi), mul(wi, br)) + 1, 1);                                     \
+            vi qr = shl(ar, 14), qi = shl(ai, 14);                                                 \
+            int rnd = kInverse ? round2 : 16384;                                                   \
+            int sh = kInverse ? shift + 14 : 15;                                                   \
+            vi nbr = sar(sub(qr, tr) + rnd, sh), nbi = sar(sub(qi, ti) + rnd, sh);                 \
+            vi nar = sar(add(qr, tr) + rnd, sh), nai = sar(add(qi, ti) + rnd, sh);                 \
+            a = pack(nar, nai);                                                                    \
+            b = pack(nbr, nbi);                                                                    \
+        }
+        AECM_FFT_STAGE(0) AECM_FFT_STAGE(1) AECM_FFT_STAGE(2) AECM_FFT_STAGE(3)
+        AECM_FFT_STAGE(4) AECM_FFT_STAGE(5) AECM_FFT_STAGE(6)
+#undef AECM_FFT_STAGE
+        return scale;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // TimeToFrequencyDomain + WindowAndFFT (reference aecm/aecm_core_c.cc:166-191, 261-365)
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD void time_to_frequency(const Regs &r, vi old_s, vi new_s, Spectrum &sp) {
+        // dynamic Q: norm of max |x| over the 128 samples, |-32768| clamped to 32767 (:288-289)
+        int mx = imin(W::reduce_max(imax(iabs(old_s), iabs(new_s))), 32767);
+        int q = norm_w16(mx);
+        // window (:174-182): scale, truncate to int16, multiply by sqrt-Hanning Q14, truncate
+        vi wo = sext16(sar(mul(sext16(shl(old_s, q)), r.hann_lo), 14));
+        vi wn = sext16(sar(mul(sext16(shl(new_s, q)), r.hann_hi), 14));
+        vi a = pack(wo, vi(0)), b = pack(wn, vi(0));        // imaginary input is zero (real_fft.c:59-65)
+        fft128<false>(r, a, b);
+        // lane t now holds X[bitrev6(t)] in a and X[bitrev6(t)+64] in b
+        int x64 = W::readlane(b, 0);
+        vi x = W::bpermute(a, r.brev);                      // bin t -> lane t
+        vi re = lo16(x);
+        vi im = sext16(neg(hi16(x)));                       // conjugate (:188-190), int16 wrap
+        im = sel(r.lane == 0, vi(0), im);                   // :296
+        sp.re = re;
+        sp.im = im;
+        sp.re64 = sext16(x64);                              // bin 64: imag forced to 0 (:297)
+        // magnitudes (:298-362, AECM_WITH_ABS_APPROX off)
+        vi ar = iabs(re), ai = iabs(im);                    // 32768 for -32768
+        vi sq = add(mul(ar, ar), mul(ai, ai));              // <= 2^31 as unsigned
+        sq = sel(gtu(sq, vi(0x7fffffff)), vi(0x7fffffff), sq);   // AddSatW32 (:354)
+        vi mag = sel(re == 0, ai, sel(im == 0, ar, W::isqrt31(sq)));
+        sp.mag = zext16(mag);
+        sp.mag64 = zext16(iabs(sp.re64));
+        sp.sum = add(W::reduce_add(sp.mag), sp.mag64);
+        sp.q = q;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Delay estimator (reference aecm/delay_estimator_wrapper.cc:92-125, delay_estimator.cc:369-382,
+    // 521-664; the float "robust validation" half is disabled and output-dead)
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD int binary_spectrum(const Regs &r, vi mag, int q, vi &threshold, int &initialized) {
+        vb in_band = (r.lane >= kBandFirst) & (r.lane <= kBandLast);
+        vi v = shl(mag, 15 - q);                                        // Q15
+        if (!initialized) {
+            vb seed = in_band & (mag > 0);
+            threshold = sel(seed, sar(v, 1), threshold);
+            if (W::ballot(seed) != 0) initialized = 1;
+        }
+        threshold = sel(in_band, mean_step(v, 6, threshold), threshold);
+        uint64_t bits = W::ballot(in_band & (v > threshold));
+        return (int)(uint32_t)(bits >> kBandFirst);
+    }
+
+    static AECM_HD int process_binary(Regs &r, int near_word) {
+        Uniform &u = r.u;
+        vb valid1 = r.lane < (kHistory - 64);
+        vi fb0 = popc(r.bh0), fb1 = popc(r.bh1);
+        vi bc0 = shl(popc(r.bh0 ^ vi(near_word)), 9), bc1 = shl(popc(r.bh1 ^ vi(near_word)), 9);
+        vb upd0 = fb0 > 0, upd1 = valid1 & (fb1 > 0);
+        r.m0 = sel(upd0, mean_step(bc0, vi(13) - sar(fb0 * 3, 4), r.m0), r.m0);     // :550-564
+        r.m1 = sel(upd1, mean_step(bc1, vi(13) - sar(fb1 * 3, 4), r.m1), r.m1);
+        bool any_far = W::ballot(upd0 | upd1) != 0;                                  // :623-626
+        // first minimum / maximum over the 100 means (:568-576): (mean << 7 | slot) is a total order
+        vi key0 = shl(r.m0, 7) | r.lane;
+        vi key1 = sel(valid1, shl(r.m1, 7) | (r.lane + 64), vi(0x7fffffff));
+        int kmin = W::reduce_min(imin(key0, key1));
+        int best = kmin >> 7, candidate = kmin & 127;
+        if (best >= kMaxBitCountsQ9) { best = kMaxBitCountsQ9; candidate = -1; }
+        int worst = imax(0, W::reduce_max(imax(r.m0, sel(valid1, r.m1, vi(0)))));
+        int valley = worst - best;
+        if (u.min_prob > kProbLowerLimit && valley > kProbMinSpread) {               // :593-606
+            int thr = imax(best + kProbOffset, kProbLowerLimit);
+            if (u.min_prob > thr) u.min_prob = thr;
+        }
+        u.last_prob = add(u.last_prob, 1);                                           // :609
+        bool valid = (valley > kProbOffset) && ((best < u.min_prob) || (best < u.last_prob));
+        if (any_far && valid) {                                                      // :643-661
+            u.last_delay = candidate;
+            if (best < u.last_prob) u.last_prob = best;
+        }
+        return u.last_delay;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Energies / VAD / step size (reference aecm/aecm_core.cc:588-794)
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD int asym_filt(int old, int in, int step_pos, int step_neg) {      // :588-605
+        if ((old == 32767) | (old == -32768)) return in;
+        if (old > in) return sext16(old - sar(old - in, step_neg));
+        return sext16(old + sar(in - old, step_pos));
+    }
+
+    static AECM_HD int log_energy_q8(int energy, int q) {                             // :612-628
+        int v = 7 << 7;
+        if (energy != 0) {
+            int zeros = clz32(energy);
+            int frac = sext16(lsr(shl(energy, zeros) & 0x7fffffff, 23));
+            v = sext16(v + ((31 - zeros) << 8) + frac - (q << 8));
+        }
+        return v;
+    }
+
+    // CalcLinearEnergies + CalcEnergies (:267-284, :644-755).  echo_est = channelStored * far.
+    static AECM_HD void calc_energies(Regs &r, vi far, int far64, int far_q, int near_energy, vi &echo_est,
+                                      int &echo_est64) {
+        Uniform &u = r.u;
+        r.near_log = W::shift_up1(r.near_log, log_energy_q8(near_energy, u.dfa_noisy_q));   // :665-669
+        echo_est = mul(r.b.ch_stored, far);
+        echo_est64 = mul(r.b64.ch_stored, far64);
+        int e_far = add(W::reduce_add(far), far64);
+        int e_adapt = add(W::reduce_add(mul(r.b.ch_adapt16, far)), mul(r.b64.ch_adapt16, far64));
+        int e_stored = add(W::reduce_add(echo_est), echo_est64);
+        u.far_log = log_energy_q8(e_far, far_q);
+        r.adapt_log = W::shift_up1(r.adapt_log, log_energy_q8(e_adapt, kResChannel16 + far_q));
+        r.stored_log = W::shift_up1(r.stored_log, log_energy_q8(e_stored, kResChannel16 + far_q));
+
+        if (u.far_log > kFarEnergyMin) {                                              // :692-730
+            int inc_max = 4, dec_max = 11, inc_min = 11, dec_min = 3;
+            if (u.startup == 0) { inc_max = 2; dec_min = 2; inc_min = 8; }
+            u.fe_min = asym_filt(u.fe_min, u.far_log, inc_min, dec_min);
+            u.fe_max = asym_filt(u.fe_max, u.far_log, inc_max, dec_max);
+            u.fe_maxmin = sext16(u.fe_max - u.fe_min);
+            int t16 = sext16(2560 - u.fe_min);
+            t16 = t16 > 0 ? sext16(sar(t16 * kFarEnergyVadRegion, 9)) : 0;
+            t16 = sext16(t16 + kFarEnergyVadRegion);
+            if ((u.startup == 0) | (u.vad_cnt > 1024)) {
+                u.fe_vad = sext16(u.fe_min + t16);
+            } else if (u.fe_vad > u.far_log) {
+                u.fe_vad = sext16(u.fe_vad + sar(u.far_log + t16 - u.fe_vad, 6));
+                u.vad_cnt = 0;
+            } else {
+                u.vad_cnt = sext16(u.vad_cnt + 1);
+            }
+            u.fe_mse = sext16(u.fe_vad + (1 << 8));
+        }
+        if (u.far_log > u.fe_vad) {                                                   // :733-740
+            if ((u.startup == 0) | (u.fe_maxmin > kFarEnergyDiff)) u.cur_vad = 1;
+        } else {
+            u.cur_vad = 0;
+        }
+        if (u.cur_vad && u.first_vad) {                                               // :741-754
+            u.first_vad = 0;
+            int adapt0 = W::readlane(r.adapt_log, 0), near0 = W::readlane(r.near_log, 0);
+            if (adapt0 > near0) {
+                r.b.ch_adapt16 = sar(r.b.ch_adapt16, 3);
+                r.b64.ch_adapt16 = sar(r.b64.ch_adapt16, 3);
+                r.adapt_log = W::writelane(r.adapt_log, sext16(adapt0 - (3 << 8)), 0);
+                u.first_vad = 1;
+            }
+        }
+    }
+
+    static AECM_HD int calc_step_size(const Uniform &u) {                             // :767-794
+        int mu = kMuMax;
+        if (!u.cur_vad) {
+            mu = 0;
+        } else if (u.startup > 0) {
+            if (u.fe_min >= u.fe_max) {
+                mu = kMuMin;
+            } else {
+                int t16 = sext16(u.far_log - u.fe_min);
+                int t32 = divi(t16 * kMuDiff, u.fe_maxmin);
+                mu = sext16(kMuMin - 1 - sext16(t32));
+            }
+            if (mu < kMuMax) mu = kMuMax;
+        }
+        return mu;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Channel update (reference aecm/aecm_core.cc:810-986)
+    // ------------------------------------------------------------------------------------------
+    // NLMS step of one bin (:831-921).  kp1 = bin index + 1.
+    template <class I>
+    static AECM_HD void nlms_bin(BinState<I> &s, I far, I dfa, I kp1, int dfa_noisy_q, int far_q, int mu) {
+        I zeros_ch = norm_u32(s.ch_adapt32);
+        I zeros_far = norm_u32(far);
+        auto safe = (zeros_ch + zeros_far) > 31;
+        I shift_ch_far = sel(safe, I(0), I(32) - zeros_ch - zeros_far);                       // :836-850
+        I u1 = mul(sel(shift_ch_far >= 32, I(0), sar(s.ch_adapt32, shift_ch_far)), far);
+        I zeros_num = norm_u32(u1);                                                           // :852-867
+        I zeros_dfa = sel(dfa != 0, norm_u32(dfa), I(32));
+        I t16 = sext16(zeros_dfa - 2 + dfa_noisy_q - kResChannel32 - far_q + shift_ch_far);
+        auto c1 = zeros_num > (t16 + 1);
+        I xfa_q = sel(c1, t16, sext16(zeros_num - 2));
+        I dfa_q = sel(c1, sext16(zeros_dfa - 2),
+                      sext16(I(kResChannel32 + far_q - dfa_noisy_q) - shift_ch_far + xfa_q));
+        u1 = shift_u(u1, xfa_q);                                                              // :869-872
+        I u2 = shift_u(dfa, dfa_q);
+        I t1 = sub(u2, u1);
+        zeros_num = norm_w32(t1);
+        auto update = (t1 != 0) & (far > shl(I(kChannelVad), far_q));                         // :873
+        auto safe2 = (zeros_num + zeros_far) > 31;                                            // :886-902
+        I shift_num = sel(safe2, I(0), I(32) - (zeros_num + zeros_far));
+        auto pos = t1 > 0;
+        I t2 = mul(sar(sel(pos, t1, neg(t1)), shift_num), far);
+        t2 = sel(pos, t2, neg(t2));
+        t2 = divi(t2, kp1);                                                                   // :904
+        I shift2res = sext16(shift_num + shift_ch_far - xfa_q - mu - shl(I(30) - zeros_far, 1));
+        t2 = sel(norm_w32(t2) < shift2res, I(0x7fffffff), shift_i(t2, shift2res));            // :906-912
+        I n32 = add_sat32(s.ch_adapt32, t2);                                                  // :913-919
+        n32 = sel(n32 < 0, I(0), n32);
+        s.ch_adapt32 = sel(update, n32, s.ch_adapt32);
+        s.ch_adapt16 = sel(update, sar(n32, 16), s.ch_adapt16);
+    }
+
+    static AECM_HD void store_adaptive_channel(Regs &r, vi far, int far64, vi &echo_est, int &echo_est64) {
+        r.b.ch_stored = r.b.ch_adapt16;                                                       // :286-306
+        r.b64.ch_stored = r.b64.ch_adapt16;
+        echo_est = mul(r.b.ch_stored, far);
+        echo_est64 = mul(r.b64.ch_stored, far64);
+    }
+
+    static AECM_HD void update_channel(Regs &r, vi far, int far64, int far_q, vi dfa, int dfa64, int mu,
+                                       vi &echo_est, int &echo_est64) {
+        Uniform &u = r.u;
+        if (mu) {
+            nlms_bin<vi>(r.b, far, dfa, r.lane + 1, u.dfa_noisy_q, far_q, mu);
+            nlms_bin<int>(r.b64, far64, dfa64, 65, u.dfa_noisy_q, far_q, mu);
+        }
+        if ((u.startup == 0) & (u.cur_vad != 0)) {                                            // :926-929
+            store_adaptive_channel(r, far, far64, echo_est, echo_est64);
+        } else {
+            if (u.far_log < u.fe_mse) u.mse_cnt = 0;                                          // :931-935
+            else u.mse_cnt = sext16(u.mse_cnt + 1);
+            if (u.mse_cnt >= (kMinMseCount + 10)) {                                           // :937-983
+                vb first20 = r.lane < kMinMseCount;
+                int mse_stored = W::reduce_add(sel(first20, iabs(r.stored_log - r.near_log), vi(0)));
+                int mse_adapt = W::reduce_add(sel(first20, iabs(r.adapt_log - r.near_log), vi(0)));
+                if (((shl(mse_stored, kMseResolution)) < (kMinMseDiff * mse_adapt)) &
+                    ((shl(u.mse_stored_old, kMseResolution)) < mul(kMinMseDiff, u.mse_adapt_old))) {
+                    r.b.ch_adapt16 = r.b.ch_stored;                                           // :308-323
+                    r.b.ch_adapt32 = shl(r.b.ch_stored, 16);
+                    r.b64.ch_adapt16 = r.b64.ch_stored;
+                    r.b64.ch_adapt32 = shl(r.b64.ch_stored, 16);
+                } else if (((kMinMseDiff * mse_stored) > shl(mse_adapt, kMseResolution)) &
+                           (mse_adapt < u.mse_thresh) & (u.mse_adapt_old < u.mse_thresh)) {
+                    store_adaptive_channel(r, far, far64, echo_est, echo_est64);
+                    if (u.mse_thresh == 0x7fffffff) {
+                        u.mse_thresh = add(mse_adapt, u.mse_adapt_old);
+                    } else {
+                        int scaled = divi(mul(u.mse_thresh, 5), 8);
+                        u.mse_thresh = add(u.mse_thresh, sar(mul(sub(mse_adapt, scaled), 205), 8));
+                    }
+                }
+                u.mse_cnt = 0;
+                u.mse_stored_old = mse_stored;
+                u.mse_adapt_old = mse_adapt;
+            }
+        }
+    }
+
+    static AECM_HD int calc_suppression_gain(Regs &r) {                               // :1000-1052
+        Uniform &u = r.u;
+        int sup;
+        if (!u.cur_vad) {
+            sup = 0;
+        } else {
+            int near0 = W::readlane(r.near_log, 0), stored0 = W::readlane(r.stored_log, 0);
+            int dE = sext16(iabs(sext16(near0 - stored0)));
+            if (dE < kEnergyDevTol) {
+                if (dE < kSupgainEpcDt) {
+                    int t32 = u.sg_dab * dE + (kSupgainEpcDt >> 1);
+                    sup = sext16(u.sg_a - sext16(divi(t32, kSupgainEpcDt)));
+                } else {
+                    int t32 = u.sg_dbd * (kEnergyDevTol - dE) + ((kEnergyDevTol - kSupgainEpcDt) >> 1);
+                    sup = sext16(u.sg_d + sext16(divi(t32, kEnergyDevTol - kSupgainEpcDt)));
+                }
+            } else {
+                sup = u.sg_d;
+            }
+        }
+        int t16 = sup > u.sup_gain_old ? sup : u.sup_gain_old;
+        u.sup_gain_old = sup;
+        u.sup_gain = sext16(u.sup_gain + sext16(sar(t16 - u.sup_gain, 4)));
+        return u.sup_gain;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Wiener gain of one bin (reference aecm/aecm_core_c.cc:517-615)
+    // ------------------------------------------------------------------------------------------
+    template <class I>
+    static AECM_HD I wiener_bin(BinState<I> &s, I echo_est, I dfa_clean, int sup_gain, int clean_q, int clean_q_old,
+                                int zeros_xbuf) {
+        // echoFilt += ((int64)(echoEst - echoFilt) * 50) >> 8 without 64-bit math:
+        // d = 256a + b  =>  (50 d) >> 8 = 50 a + ((50 b) >> 8)                                    :523-525
+        I d = sub(echo_est, s.echo_filt);
+        s.echo_filt = add(s.echo_filt, add(mul(sar(d, 8), I(50)), sar(mul(d & 255, I(50)), 8)));
+
+        I zeros32 = norm_w32(s.echo_filt) + 1;                                                // :527-550
+        int zeros16 = norm_w16(sup_gain) + 1;
+        auto safe = (zeros32 + zeros16) > 16;
+        I t16 = I(17) - zeros32 - zeros16;
+        int dq = clean_q - zeros_xbuf;
+        I res_diff = sel(safe, I(14 - kResChannel16 - kResSupgain + dq),
+                         sext16(t16 + (14 - kResChannel16 - kResSupgain + dq)));
+        I g_safe = mul(s.echo_filt, I(zext16(sup_gain)));
+        I g_b = mul(s.echo_filt, zext16(sar(I(sup_gain), t16)));
+        I g_c = mul(sar(s.echo_filt, t16), I(sup_gain));
+        I gained = sel(safe, g_safe, sel(zeros32 > t16, g_b, g_c));
+
+        I zn = norm_w16(s.near_filt);                                                         // :552-579
+        int dqq = sext16(clean_q - clean_q_old);
+        auto c = (zn < dqq) & (s.near_filt != 0);
+        I a_else = dqq < 0 ? sext16(sar(s.near_filt, -dqq)) : sext16(shl(s.near_filt, dqq));
+        I q_diff = sel(c, zn - dqq, I(0));
+        I t_a = sel(c, sext16(shl(s.near_filt, zn)), a_else);
+        I t_b = sel(c, sext16(lsr(dfa_clean, neg(q_diff))), sext16(dfa_clean));
+        t_b = sext16(sext16(sar(sub(t_b, t_a), 4)) + t_a);
+        I z2 = norm_w16(t_b);
+        auto weird = (t_b & sel(neg(q_diff) > z2, I(1), I(0))) != 0;                           // :572 literally
+        s.near_filt = sel(weird, I(32767), sel(q_diff < 0, sext16(shl(t_b, neg(q_diff))), t_b));
+
+        I g2 = add(gained, sar(s.near_filt, 1));                                              // :582-611
+        I t32 = shift_u(divu(g2, zext16(s.near_filt)), res_diff);
+        I h = sel(t32 > kOneQ14, I(0), sel(t32 < 0, I(kOneQ14), imax(I(kOneQ14) - sext16(t32), I(0))));
+        return sel(gained == 0, I(kOneQ14), sel(s.near_filt == 0, I(0), h));
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Comfort noise of one bin (reference aecm/aecm_core_c.cc:52-164); returns (uReal, uImag)
+    // ------------------------------------------------------------------------------------------
+    template <class I>
+    static AECM_HD void noise_bin(BinState<I> &s, I dfa, I hnl, I rnd, int shift_n, int min_track, I &u_re, I &u_im) {
+        I in = shl(dfa, shift_n);                                                             // :81-127
+        auto lt = in < s.noise_est;
+        auto small = s.noise_est < (1 << min_track);
+        I high_inc = s.high_ctr + 1;
+        auto dec = high_inc >= 5;
+        I ne_lt = sel(small, sel(dec, s.noise_est - 1, s.noise_est), sub(s.noise_est, sar(sub(s.noise_est, in), min_track)));
+        I high_lt = sel(small, sel(dec, I(0), high_inc), s.high_ctr);
+        auto c19 = sar(s.noise_est, 19) > 0;
+        auto c11 = sar(s.noise_est, 11) > 0;
+        I low_inc = s.low_ctr + 1;
+        auto inc = low_inc >= 5;
+        I ne_ge = sel(c19, mul(sar(s.noise_est, 11), I(2049)),
+                      sel(c11, sar(mul(s.noise_est, I(2049)), 11),
+                          sel(inc, s.noise_est + sar(s.noise_est, 9) + 1, s.noise_est)));
+        I low_ge = sel(c19 | c11, s.low_ctr, sel(inc, I(0), low_inc));
+        I ne = sel(lt, ne_lt, ne_ge);
+        s.low_ctr = sel(lt, I(0), low_ge);
+        s.high_ctr = sel(lt, high_lt, I(0));
+        I t32 = sar(ne, shift_n);                                                             // :129-140
+        auto clamp = t32 > 32767;
+        t32 = sel(clamp, I(32767), t32);
+        s.noise_est = sel(clamp, shl(I(32767), shift_n), ne);
+        I n16 = sext16(sar(mul(sext16(I(kOneQ14) - hnl), sext16(t32)), 14));
+        I idx = sext16(sar(mul(I(359), rnd), 15));                                            // :150
+        u_re = sext16(sar(mul(n16, W::cos360(idx)), 13));                                     // :153-156
+        u_im = sext16(sar(mul(neg(n16), W::sin360(idx)), 13));
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // state load / store
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD void load_state(Regs &r, const uint32_t *vec, const int32_t *scal) {
+        auto V = [&](int f) { return W::load_u32(vec + f * kLanes, r.lane); };
+        vi w = V(V_XD_OLD);
+        r.x_old = lo16(w); r.d_old = hi16(w);
+        w = V(V_OUTBUF);
+        r.out_ovl = lo16(w); r.c_old = hi16(w);
+        w = V(V_CH16);
+        r.b.ch_stored = lo16(w); r.b.ch_adapt16 = hi16(w);
+        r.b.ch_adapt32 = V(V_CH32);
+        r.b.echo_filt = V(V_ECHOFILT);
+        w = V(V_NEARFILT);
+        r.b.near_filt = lo16(w); r.b.low_ctr = lsr(w, 16) & 255; r.b.high_ctr = lsr(w, 24);
+        r.b.noise_est = V(V_NOISE);
+        r.mean_far = V(V_MEANFAR); r.mean_near = V(V_MEANNEAR);
+        r.bh0 = V(V_BH0); r.bh1 = V(V_BH1); r.m0 = V(V_M0); r.m1 = V(V_M1);
+        r.hq0 = V(V_HQ0); r.hq1 = V(V_HQ1);
+        w = V(V_LOG_NA);
+        r.near_log = lo16(w); r.adapt_log = hi16(w);
+        r.stored_log = lo16(V(V_LOG_S));
+        Uniform &u = r.u;
+        u.tot_count = scal[S_TOTCOUNT]; u.seed = scal[S_SEED]; u.startup = scal[S_STARTUP]; u.hist_pos = scal[S_HISTPOS];
+        u.dfa_noisy_q = scal[S_DFANOISYQ]; u.dfa_noisy_q_old = scal[S_DFANOISYQ_OLD];
+        u.dfa_clean_q = scal[S_DFACLEANQ]; u.dfa_clean_q_old = scal[S_DFACLEANQ_OLD];
+        u.far_log = scal[S_FARLOG]; u.fe_min = scal[S_FE_MIN]; u.fe_max = scal[S_FE_MAX]; u.fe_maxmin = scal[S_FE_MAXMIN];
+        u.fe_vad = scal[S_FE_VAD]; u.fe_mse = scal[S_FE_MSE]; u.cur_vad = scal[S_CURVAD]; u.vad_cnt = scal[S_VADCNT];
+        u.first_vad = scal[S_FIRSTVAD]; u.mse_cnt = scal[S_MSECNT]; u.mse_adapt_old = scal[S_MSE_ADAPT_OLD];
+        u.mse_stored_old = scal[S_MSE_STORED_OLD]; u.mse_thresh = scal[S_MSE_THRESH];
+        u.sup_gain = scal[S_SUPGAIN]; u.sup_gain_old = scal[S_SUPGAIN_OLD]; u.noise_ctr = scal[S_NOISECTR];
+        u.far_init = scal[S_FAR_INIT]; u.near_init = scal[S_NEAR_INIT]; u.min_prob = scal[S_MIN_PROB];
+        u.last_prob = scal[S_LAST_PROB]; u.last_delay = scal[S_LAST_DELAY];
+        u.mult = scal[S_MULT]; u.cng = scal[S_CNG]; u.nlp = scal[S_NLP]; u.fixed_delay = scal[S_FIXED_DELAY];
+        u.sg_a = scal[S_SG_A]; u.sg_d = scal[S_SG_D]; u.sg_dab = scal[S_SG_DAB]; u.sg_dbd = scal[S_SG_DBD];
+        BinState<int> &e = r.b64;
+        e.ch_stored = scal[S_B64_CHSTORED]; e.ch_adapt16 = scal[S_B64_CHADAPT16]; e.ch_adapt32 = scal[S_B64_CHADAPT32];
+        e.echo_filt = scal[S_B64_ECHOFILT]; e.near_filt = scal[S_B64_NEARFILT]; e.noise_est = scal[S_B64_NOISE];
+        e.low_ctr = scal[S_B64_LOWCTR]; e.high_ctr = scal[S_B64_HIGHCTR];
+    }
+
+    static AECM_HD void store_state(const Regs &r, uint32_t *vec, int32_t *scal) {
+        auto V = [&](int f, vi w) { W::store_u32(vec + f * kLanes, r.lane, w); };
+        V(V_XD_OLD, pack(r.x_old, r.d_old));
+        V(V_OUTBUF, pack(r.out_ovl, r.c_old));
+        V(V_CH16, pack(r.b.ch_stored, r.b.ch_adapt16));
+        V(V_CH32, r.b.ch_adapt32);
+        V(V_ECHOFILT, r.b.echo_filt);
+        V(V_NEARFILT, zext16(r.b.near_filt) | shl(r.b.low_ctr & 255, 16) | shl(r.b.high_ctr, 24));
+        V(V_NOISE, r.b.noise_est);
+        V(V_MEANFAR, r.mean_far); V(V_MEANNEAR, r.mean_near);
+        V(V_BH0, r.bh0); V(V_BH1, r.bh1); V(V_M0, r.m0); V(V_M1, r.m1);
+        V(V_HQ0, r.hq0); V(V_HQ1, r.hq1);
+        V(V_LOG_NA, pack(r.near_log, r.adapt_log));
+        V(V_LOG_S, zext16(r.stored_log));
+        if (W::is_first_lane()) {
+            const Uniform &u = r.u;
+            scal[S_TOTCOUNT] = u.tot_count; scal[S_SEED] = u.seed; scal[S_STARTUP] = u.startup; scal[S_HISTPOS] = u.hist_pos;
+            scal[S_DFANOISYQ] = u.dfa_noisy_q; scal[S_DFANOISYQ_OLD] = u.dfa_noisy_q_old;
+            scal[S_DFACLEANQ] = u.dfa_clean_q; scal[S_DFACLEANQ_OLD] = u.dfa_clean_q_old;
+            scal[S_FARLOG] = u.far_log; scal[S_FE_MIN] = u.fe_min; scal[S_FE_MAX] = u.fe_max; scal[S_FE_MAXMIN] = u.fe_maxmin;
+            scal[S_FE_VAD] = u.fe_vad; scal[S_FE_MSE] = u.fe_mse; scal[S_CURVAD] = u.cur_vad; scal[S_VADCNT] = u.vad_cnt;
+            scal[S_FIRSTVAD] = u.first_vad; scal[S_MSECNT] = u.mse_cnt; scal[S_MSE_ADAPT_OLD] = u.mse_adapt_old;
+            scal[S_MSE_STORED_OLD] = u.mse_stored_old; scal[S_MSE_THRESH] = u.mse_thresh;
+            scal[S_SUPGAIN] = u.sup_gain; scal[S_SUPGAIN_OLD] = u.sup_gain_old; scal[S_NOISECTR] = u.noise_ctr;
+            scal[S_FAR_INIT] = u.far_init; scal[S_NEAR_INIT] = u.near_init; scal[S_MIN_PROB] = u.min_prob;
+            scal[S_LAST_PROB] = u.last_prob; scal[S_LAST_DELAY] = u.last_delay;
+            const BinState<int> &e = r.b64;
+            scal[S_B64_CHSTORED] = e.ch_stored; scal[S_B64_CHADAPT16] = e.ch_adapt16; scal[S_B64_CHADAPT32] = e.ch_adapt32;
+            scal[S_B64_ECHOFILT] = e.echo_filt; scal[S_B64_NEARFILT] = e.near_filt; scal[S_B64_NOISE] = e.noise_est;
+            scal[S_B64_LOWCTR] = e.low_ctr; scal[S_B64_HIGHCTR] = e.high_ctr;
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // One block (reference aecm/aecm_core_c.cc:368-711).  far_new/near_new/clean_new: lane t holds
+    // sample t of the new 64-sample block (sign-extended).  Returns the output block in IFFT lane
+    // order: lane t holds out[bitrev6(t)].
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD vi process_block(Regs &r, uint16_t *hist, vi far_new, vi near_new, vi clean_new) {
+        Uniform &u = r.u;
+        if (u.startup < 2) u.startup = (gtu(u.tot_count, kConvLen - 1) ? 1 : 0) + (gtu(u.tot_count, kConvLen2 - 1) ? 1 : 0);  // :420-424
+
+        Spectrum xf, df, cf;
+        time_to_frequency(r, r.x_old, far_new, xf);                                   // :439
+        time_to_frequency(r, r.d_old, near_new, df);                                  // :442
+        u.dfa_noisy_q_old = u.dfa_noisy_q;
+        u.dfa_noisy_q = df.q;
+        if (kHasClean) {                                                              // :449-464
+            time_to_frequency(r, r.c_old, clean_new, cf);
+            u.dfa_clean_q_old = u.dfa_clean_q;
+            u.dfa_clean_q = cf.q;
+        } else {
+            u.dfa_clean_q_old = u.dfa_noisy_q_old;
+            u.dfa_clean_q = u.dfa_noisy_q;
+        }
+        const Spectrum &clean = kHasClean ? cf : df;   // "dfw"/"ptrDfaClean" of the reference (T30)
+
+        // UpdateFarHistory (aecm_core.cc:125-138)
+        u.hist_pos = u.hist_pos + 1;
+        if (u.hist_pos >= kHistory) u.hist_pos = 0;
+        W::store_u16(hist + u.hist_pos * kLanes, r.lane, xf.mag);
+        {
+            int side = zext16(xf.mag64) | shl(xf.q, 16);
+            if (u.hist_pos < 64) r.hq0 = W::writelane(r.hq0, side, u.hist_pos);
+            else r.hq1 = W::writelane(r.hq1, side, u.hist_pos - 64);
+        }
+
+        // far binary spectrum -> history (delay_estimator_wrapper.cc:233-263, delay_estimator.cc:369-382)
+        {
+            int word = binary_spectrum(r, xf.mag, xf.q, r.mean_far, u.far_init);
+            int carry = W::readlane(r.bh0, 63);
+            r.bh0 = W::shift_up1(r.bh0, word);
+            r.bh1 = W::shift_up1(r.bh1, carry);
+        }
+        // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
+        int delay = process_binary(r, binary_spectrum(r, df.mag, df.q, r.mean_near, u.near_init));
+        if (delay == -2) delay = 0;                                                   // :479-483
+        if (u.fixed_delay >= 0) delay = u.fixed_delay;                                // :485-488
+
+        // AlignedFarend (aecm_core.cc:157-172)
+        int pos = u.hist_pos - delay;
+        if (pos < 0) pos += kHistory;
+        int side = pos < 64 ? W::readlane(r.hq0, pos) : W::readlane(r.hq1, pos - 64);
+        const int far_q = sar(side, 16);
+        const int far64 = zext16(side);
+        vi far = xf.mag;
+        if (delay != 0) far = W::load_u16(hist + pos * kLanes, r.lane);
+
+        vi echo_est;
+        int echo_est64;
+        calc_energies(r, far, far64, far_q, df.sum, echo_est, echo_est64);            // :498
+        const int mu = calc_step_size(u);                                             // :503
+        u.tot_count = add(u.tot_count, 1);                                            // :506
+        update_channel(r, far, far64, far_q, df.mag, df.mag64, mu, echo_est, echo_est64);   // :511
+        const int sup_gain = calc_suppression_gain(r);                                // :514
+
+        vi hnl = wiener_bin<vi>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+        int hnl64 = wiener_bin<int>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+        const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
+
+        if (u.mult == 2) {                                                            // :618-648
+            hnl = sext16(sar(mul(hnl, hnl), 14));
+            hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
+            int avg = W::reduce_add(sel((r.lane >= 4) & (r.lane <= 24), hnl, vi(0)));
+            avg = sext16(divi(avg, 21));
+            hnl = sel((r.lane >= 24) & (hnl > avg), vi(avg), hnl);
+            if (hnl64 > avg) hnl64 = avg;
+        }
+        if (u.nlp) {                                                                  // :651-686
+            hnl = sel(hnl > kNlpCompHigh, vi(kOneQ14), sel(hnl < kNlpCompLow, vi(0), hnl));
+            hnl64 = hnl64 > kNlpCompHigh ? kOneQ14 : (hnl64 < kNlpCompLow ? 0 : hnl64);
+            if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
+        }
+        vi e_re = sext16(sar(mul(clean.re, hnl) + 8192, 14));                         // :680-685
+        vi e_im = sext16(sar(mul(clean.im, hnl) + 8192, 14));
+        int e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
+        int e_im64 = 0;
+
+        if (u.cng == 1) {                                                             // :702-705
+            int shift_n = sext16(15 - u.dfa_clean_q);
+            int min_track = 9;
+            if (u.noise_ctr < 100) { u.noise_ctr = sext16(u.noise_ctr + 1); min_track = 6; }
+            // LCG jump-ahead: lane t gets the t-th of this block's 64 draws
+            vi st = add(mul(r.lcg_mul, vi(u.seed)), r.lcg_add) & 0x7fffffff;
+            int s64 = add(mul(r.lcg_mul64, u.seed), r.lcg_add64) & 0x7fffffff;
+            vi rnd = sext16(lsr(st, 16));
+            int rnd64 = sext16(lsr(s64, 16));
+            u.seed = s64;
+            vi u_re, u_im;
+            int u_re64, u_im64;
+            noise_bin<vi>(r.b, clean.mag, hnl, rnd, shift_n, min_track, u_re, u_im);
+            noise_bin<int>(r.b64, clean.mag64, hnl64, rnd64, shift_n, min_track, u_re64, u_im64);
+            u_re = sel(r.lane == 0, vi(0), u_re);                                     // :146-147
+            u_im = sel(r.lane == 0, vi(0), u_im);
+            u_im64 = 0;                                                               // :158
+            e_re = sat16(e_re + u_re);                                                // :160-163
+            e_im = sat16(e_im + u_im);
+            e_re64 = sat16(e_re64 + u_re64);
+            e_im64 = sat16(e_im64 + u_im64);
+        }
+
+        // InverseFFTAndWindow (:193-246) + RealInverseFFT (real_fft.c:74-102):
+        // Y[c] = (re[c], -im[c]) for c <= 64, conj-symmetric extension for c > 64 (T7).
+        vi y = pack(e_re, sext16(neg(e_im)));
+        vi mirrored = W::bpermute(pack(e_re, e_im), (vi(64) - r.lane) & 63);           // lane t <- bin 64-t
+        int y64 = zext16(e_re64) | shl(sext16(neg(e_im64)), 16);
+        vi a = y;
+        vi b = sel(r.lane == 0, vi(y64), mirrored);
+        const int out_cfft = fft128<true>(r, a, b);
+        const int sh = out_cfft - u.dfa_clean_q;
+        // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
+        vi first = sext16(sar(mul(lo16(a), r.hann_syn_lo) + 8192, 14));               // :219-221
+        vi out = sat16(add(shift_i(first, sh), r.out_ovl));                           // :222-227
+        vi second = sar(mul(lo16(b), r.hann_syn_hi), 14);                             // :229-234
+        r.out_ovl = sat16(shift_i(second, sh));
+        r.x_old = far_new;                                                            // :239-245
+        r.d_old = near_new;
+        if (kHasClean) r.c_old = clean_new;
+        return out;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // A launch: n_blocks consecutive blocks of one stream, state in registers throughout.
+    // ------------------------------------------------------------------------------------------
+    static AECM_HD void run_stream(const StatePtrs &st, const IoView &io, int64_t stream, int n_blocks) {
+        Regs r;
+        init_lane_constants(r);
+        uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
+        int32_t *scal = st.scal + stream * (int64_t)kNumScal;
+        uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
+        load_state(r, vec, scal);
+        const int64_t base = stream * io.stream_stride;
+        vi far_next = W::load_i16(io.far + base, r.lane);
+        vi near_next = W::load_i16(io.near + base, r.lane);
+        vi clean_next = kHasClean ? W::load_i16(io.near_clean + base, r.lane) : vi(0);
+        for (int blk = 0; blk < n_blocks; ++blk) {
+            vi far_cur = far_next, near_cur = near_next, clean_cur = clean_next;
+            if (blk + 1 < n_blocks) {             // prefetch the next block's 3 x 128 bytes
+                const int64_t off = base + (int64_t)(blk + 1) * io.block_stride;
+                far_next = W::load_i16(io.far + off, r.lane);
+                near_next = W::load_i16(io.near + off, r.lane);
+                if (kHasClean) clean_next = W::load_i16(io.near_clean + off, r.lane);
+            }
+            vi out = process_block(r, hist, far_cur, near_cur, clean_cur);
+            W::store_i16(io.out + base + (int64_t)blk * io.block_stride, r.brev, out);
+        }
+        store_state(r, vec, scal);
+    }
+};
+
+}  // namespace aecm
+#endif  // AECM_AMD_WAVE_H_

@@ -27,6 +27,7 @@ _LEVELS = np.array([15, 60, 500, 3000, 9000, 20000], dtype=np.int64)
 _PATH_A = ((100, 16384), (180, -9830), (333, 6553), (600, 3276))     # (delay samples, Q15 gain)
 _PATH_B = ((60, 13107), (140, 11468), (410, -8192), (520, 4915))
 PROFILES = ("mixed", "steady", "loud", "sparse")
+EXTRA_PROFILES = ("silent",)   # near is exact digital silence for the first 85 % (noise-floor floor branches)
 
 
 def _noise(rs: np.random.RandomState, n: int) -> np.ndarray:
@@ -45,7 +46,7 @@ def synth_pair(seed: int, n_blocks: int, fs: int = 16000, profile: str | None = 
     """Return (far, near) int16 arrays of n_blocks*64 samples."""
     if profile is None:
         profile = PROFILES[seed % len(PROFILES)]
-    if profile not in PROFILES:
+    if profile not in PROFILES + EXTRA_PROFILES:
         raise ValueError(profile)
     rs = np.random.RandomState((seed * 2654435761 + 12345) % (2 ** 32))
     n = n_blocks * BLOCK
@@ -101,6 +102,8 @@ def synth_pair(seed: int, n_blocks: int, fs: int = 16000, profile: str | None = 
         near[f0:f1] = np.where(sign == 1, 32767, -32768)
         r0 = f0 + (f1 - f0) // 2
         near[r0:r0 + 200] = -32768                                    # a run of -32768
+    if profile == "silent":
+        near[: int(n * 0.85)] = 0
     near = np.clip(near, -32768, 32767)
     return far.astype(np.int16), near.astype(np.int16)
 
