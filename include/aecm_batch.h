@@ -1,0 +1,91 @@
+/*
+ * Batch extension of the AECM C ABI: S independent AECM block streams resident on one MI355X,
+ * one wavefront per stream.  Not present in the reference; it is the data-parallel form of the
+ * reference's block-level core interface (aecm/aecm_core.h:149-239):
+ *
+ *   WebRtcAecmBatch_Create/Free      <->  WebRtcAecm_CreateCore / FreeCore   (aecm_core.h:149,198)
+ *   WebRtcAecmBatch_Init             <->  WebRtcAecm_InitCore                (aecm_core.h:166)
+ *                                         + default set_config (echo_control_mobile.cc:183-188)
+ *   WebRtcAecmBatch_set_config       <->  core part of WebRtcAecm_set_config (echo_control_mobile.cc:410-479)
+ *   WebRtcAecmBatch_Control          <->  WebRtcAecm_Control                 (aecm_core.h:200)
+ *   WebRtcAecmBatch_ProcessBlocks    <->  T x WebRtcAecm_ProcessBlock per stream (aecm_core.h:235)
+ *   WebRtcAecmBatch_InitEchoPath / GetEchoPath <-> WebRtcAecm_InitEchoPathCore (aecm_core.h:187) /
+ *                                         WebRtcAecm_GetEchoPath (echo_control_mobile.h:191)
+ *
+ * Return codes follow echo_control_mobile.h: 0 ok, -1 NULL handle, 12002 not initialised,
+ * 12003 NULL data pointer, 12004 bad parameter, 12000 device (HIP) failure.
+ *
+ * Audio layout: sample i of block b of stream s is at base[s*stream_stride + b*block_stride + i]
+ * (strides in int16 elements).  Stream-major "files" are (stream_stride, block_stride) = (T*64, 64);
+ * a tick-major server layout [T][S][64] is (64, S*64).  Each wavefront reads/writes whole 128-byte
+ * lines either way.
+ */
+#ifndef AECM_MI355X_BATCH_H_
+#define AECM_MI355X_BATCH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "echo_control_mobile.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct AecmBatch AecmBatch;
+
+enum { AECM_BATCH_DIGEST_WORDS = 24 };
+enum { AECM_KERNEL_SAFE = 0, AECM_KERNEL_FAST = 1 };
+
+/* Allocates device state for num_streams streams on HIP device device_id.  NULL on failure. */
+AecmBatch *WebRtcAecmBatch_Create(int32_t num_streams, int32_t device_id);
+void WebRtcAecmBatch_Free(AecmBatch *b);
+
+int32_t WebRtcAecmBatch_num_streams(const AecmBatch *b);
+
+/* (Re)initialises every stream for sampFreq in {8000, 16000}, default config cng=1, echoMode=3. */
+int32_t WebRtcAecmBatch_Init(AecmBatch *b, int32_t sampFreq);
+/* Applies config to streams [first, first+count); count < 0 means "to the end". */
+int32_t WebRtcAecmBatch_set_config(AecmBatch *b, AecmConfig config, int32_t first, int32_t count);
+int32_t WebRtcAecmBatch_Control(AecmBatch *b, int32_t fixed_delay, int32_t nlp_flag, int32_t first, int32_t count);
+
+/* Runs num_blocks consecutive 64-sample blocks of every stream.  All four pointers are DEVICE
+ * pointers (near_clean may be NULL).  Asynchronous on the engine's HIP stream. */
+int32_t WebRtcAecmBatch_ProcessBlocks(AecmBatch *b, const int16_t *far_dev, const int16_t *near_dev,
+                                      const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                      int64_t block_stride, int32_t num_blocks);
+/* Same with HOST pointers: copies in, runs, copies out, synchronises. */
+int32_t WebRtcAecmBatch_ProcessBlocksHost(AecmBatch *b, const int16_t *far_host, const int16_t *near_host,
+                                          const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                          int64_t block_stride, int32_t num_blocks);
+int32_t WebRtcAecmBatch_Synchronize(AecmBatch *b);
+
+/* Duration of the most recent ProcessBlocks kernel, from HIP events recorded around the launch on
+ * the engine's own stream (waits for it to finish). */
+int32_t WebRtcAecmBatch_GetLastLaunchMs(AecmBatch *b, float *ms);
+/* Sum of the kernel durations since the last call to WebRtcAecmBatch_ResetTimers and their count. */
+int32_t WebRtcAecmBatch_GetTimers(AecmBatch *b, double *total_ms, int64_t *launches);
+int32_t WebRtcAecmBatch_ResetTimers(AecmBatch *b);
+
+/* Per-stream stored echo channel (65 x int16 = 130 bytes), as echo_control_mobile.h:172,191. */
+int32_t WebRtcAecmBatch_InitEchoPath(AecmBatch *b, int32_t stream, const void *echo_path, size_t size_bytes);
+int32_t WebRtcAecmBatch_GetEchoPath(AecmBatch *b, int32_t stream, void *echo_path, size_t size_bytes);
+
+/* 24-word digest of one stream's complete state (canonical order: oracle/aecm_oracle.c). */
+int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]);
+
+/* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */
+int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
+
+/* Device self test of the wave primitives on device_id; failures[0..7] must all be 0 afterwards
+ * (see webrtc_aecm_amd/csrc/aecm_kernels.h).  exhaustive != 0 checks floor-sqrt on all of [0, 2^31). */
+int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]);
+
+/* Name, CU count and clock of the device the library would use (diagnostics). */
+int32_t WebRtcAecmBatch_DeviceInfo(int32_t device_id, char *name, size_t name_len, int32_t *compute_units,
+                                   int32_t *clock_khz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AECM_MI355X_BATCH_H_ */

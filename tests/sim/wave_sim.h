@@ -114,6 +114,7 @@ struct SimWave {
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
     static bool is_first_lane() { return true; }
+    static int uni(int x) { return x; }   // device: v_readfirstlane (value is wave-uniform)
 
     static vi lut(const int16_t *t, int n, const vi &idx) {
         vi r;

@@ -11,9 +11,11 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "webrtc_aecm_amd" / "csrc"
 SIM_SO = ROOT / "tests" / "_build" / "libaecm_sim.so"
-_SOURCES = [ROOT / "tests" / "sim" / "sim_lib.cpp", CSRC / "aecm_host_state.cpp"]
+_SOURCES = [ROOT / "tests" / "sim" / "sim_lib.cpp", ROOT / "tests" / "sim" / "sim_engine.cpp",
+            CSRC / "aecm_host_state.cpp", CSRC / "aecm_session.cpp"]
 _DEPS = _SOURCES + [ROOT / "tests" / "sim" / "wave_sim.h", CSRC / "aecm_wave.h", CSRC / "aecm_ops.h",
-                    CSRC / "aecm_state.h", CSRC / "aecm_host_state.h", CSRC / "aecm_tables.h"]
+                    CSRC / "aecm_state.h", CSRC / "aecm_host_state.h", CSRC / "aecm_tables.h",
+                    CSRC / "aecm_session.h", CSRC / "aecm_engine.h"]
 _i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _lib = None
@@ -23,7 +25,8 @@ def build():
     if SIM_SO.exists() and all(SIM_SO.stat().st_mtime >= d.stat().st_mtime for d in _DEPS):
         return
     SIM_SO.parent.mkdir(parents=True, exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fwrapv", "-fPIC", "-shared", f"-I{CSRC}",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fwrapv", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", f"-I{CSRC}",
                            f"-I{ROOT / 'tests' / 'sim'}", *map(str, _SOURCES), "-o", str(SIM_SO)])
 
 
@@ -40,6 +43,14 @@ def lib():
         l.sim_get_echo_path.argtypes = [C.c_void_p, _i16p]
         l.sim_process.argtypes = [C.c_void_p, _i16p, _i16p, C.c_void_p, _i16p, C.c_int]
         l.sim_digest.argtypes = [C.c_void_p, _u32p]
+        l.simsession_create.restype = C.c_void_p
+        l.simsession_free.argtypes = [C.c_void_p]
+        l.simsession_init.argtypes = [C.c_void_p, C.c_int32]
+        l.simsession_buffer_farend.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        l.simsession_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int16]
+        l.simsession_set_config.argtypes = [C.c_void_p, C.c_int16, C.c_int16]
+        l.simsession_init_echo_path.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        l.simsession_get_echo_path.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = l
     return _lib
 
@@ -81,5 +92,47 @@ class SimStream:
     def __del__(self):
         try:
             self.lib.sim_free(self.h)
+        except Exception:
+            pass
+
+
+class SimSession:
+    """The product's Session class (host logic) over the simulated engine, ABI-shaped."""
+
+    def __init__(self):
+        self.lib = lib()
+        self.h = self.lib.simsession_create()
+
+    def init(self, fs):
+        return self.lib.simsession_init(self.h, fs)
+
+    def set_config(self, cng, em):
+        return self.lib.simsession_set_config(self.h, cng, em)
+
+    def buffer_farend(self, far):
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        return self.lib.simsession_buffer_farend(self.h, far.ctypes.data, far.size)
+
+    def process(self, near, clean=None, ms=0):
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        out = np.empty_like(near)
+        cp = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            cp = clean.ctypes.data
+        rc = self.lib.simsession_process(self.h, near.ctypes.data, cp, out.ctypes.data, near.size, ms)
+        return rc, out
+
+    def init_echo_path(self, path):
+        path = np.ascontiguousarray(path, dtype=np.int16)
+        return self.lib.simsession_init_echo_path(self.h, path.ctypes.data, path.nbytes)
+
+    def get_echo_path(self):
+        out = np.zeros(65, dtype=np.int16)
+        return self.lib.simsession_get_echo_path(self.h, out.ctypes.data, out.nbytes), out
+
+    def __del__(self):
+        try:
+            self.lib.simsession_free(self.h)
         except Exception:
             pass

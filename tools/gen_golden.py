@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/libaecm_ref.so).
+
+Run in the build container (needs /root/reference to build the reference .so).  The fixtures hold
+only data: generator recipe ids (seed, n_blocks, fs, config) + expected outputs + state digests.
+Inputs are regenerated bit-identically by webrtc_aecm_amd.synth on any machine.
+"""
+import hashlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import pyoracle  # noqa: E402
+from webrtc_aecm_amd.synth import synth_pair  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+# (seed, n_blocks, fs, cng, echo_mode, profile)
+BLOCK_CASES = [
+    (0, 1200, 16000, 1, 3, None),
+    (1, 1200, 16000, 1, 1, None),
+    (2, 1200, 8000, 1, 4, None),
+    (3, 1200, 8000, 0, 0, None),
+    (100, 4200, 16000, 1, 3, "silent"),
+]
+# (seed, seconds, fs, frame, cng, echo_mode, ms)
+SESSION_CASES = [
+    (7, 10, 16000, 160, 1, 1, 40),     # the reference CLI's parameters (main.cc:102-105,163-164)
+    (8, 6, 8000, 80, 1, 3, 40),
+    (9, 4, 16000, 160, 0, 2, 700),     # ms out of range -> warning path, clamped
+]
+
+
+def main():
+    pyoracle.build()
+    assert pyoracle.have_reference(), "reference .so missing"
+    GOLD.mkdir(parents=True, exist_ok=True)
+    for seed, nb, fs, cng, em, prof in BLOCK_CASES:
+        far, near = synth_pair(seed, nb, fs, prof)
+        r = pyoracle.RefCoreStream(fs, cng, em)
+        digs = []
+        outs = []
+        for c in range(0, nb, 300):
+            outs.append(r.process(far[c * 64:(c + 300) * 64], near[c * 64:(c + 300) * 64]))
+            digs.append(r.digest())
+        out = np.concatenate(outs)
+        keep = out if prof is None else out[-600 * 64:]      # long cases: keep the tail + digests only
+        np.savez_compressed(GOLD / f"block_s{seed}_fs{fs}_c{cng}_e{em}.npz", seed=seed, n_blocks=nb, fs=fs, cng=cng,
+                            echo_mode=em, profile=prof or "", out=keep, digests=np.stack(digs),
+                            sha256=hashlib.sha256(out.tobytes()).hexdigest())
+        print("block", seed, fs, cng, em, prof, hashlib.sha256(out.tobytes()).hexdigest()[:16])
+    for seed, secs, fs, frame, cng, em, ms in SESSION_CASES:
+        nb = secs * fs // 64
+        far, near = synth_pair(seed, nb, fs, "mixed")
+        n = (far.size // frame) * frame
+        s = pyoracle.RefSession(fs, cng, em)
+        lib = s.lib
+        out = near.copy()
+        codes = set()
+        buf = np.empty(frame, dtype=np.int16)
+        for i in range(n // frame):
+            f = far[i * frame:(i + 1) * frame]
+            d = out[i * frame:(i + 1) * frame]
+            assert lib.WebRtcAecm_BufferFarend(s.h, f.ctypes.data, frame) == 0
+            codes.add(int(lib.WebRtcAecm_Process(s.h, d.ctypes.data, None, buf.ctypes.data, frame, ms)))
+            d[:] = buf
+        np.savez_compressed(GOLD / f"session_s{seed}_fs{fs}_f{frame}_c{cng}_e{em}_ms{ms}.npz", seed=seed, n_blocks=nb,
+                            fs=fs, frame=frame, cng=cng, echo_mode=em, ms=ms, out=out[:n], codes=np.array(sorted(codes)),
+                            sha256=hashlib.sha256(out[:n].tobytes()).hexdigest())
+        print("session", seed, fs, frame, cng, em, ms, sorted(codes))
+    # 60 s reference-CLI-shaped run: hash only
+    far, near = synth_pair(60, 15000, 16000, "mixed")
+    s = pyoracle.RefSession(16000, 1, 1)
+    out = s.run(far, near, 160, 40)
+    (GOLD / "session_60s_16k.sha256").write_text(hashlib.sha256(out.tobytes()).hexdigest() + "\n")
+    print("60 s hash", hashlib.sha256(out.tobytes()).hexdigest()[:16])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+"""Build the HIP shared library in-tree: webrtc_aecm_amd/_lib/libaecm_mi355x.so (gfx950 only)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB_DIR = PKG / "_lib"
+LIB = LIB_DIR / "libaecm_mi355x.so"
+SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_capi.cpp", "aecm_host_state.cpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-shared"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm)")
+
+
+def is_stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = list(CSRC.glob("*")) + list((PKG.parent / "include").glob("*.h"))
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP/C++ source of the engine into one shared library for gfx950."""
+    if not force and not is_stale():
+        return LIB
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    cmd = [_hipcc(), *HIPCC_FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=str(CSRC))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

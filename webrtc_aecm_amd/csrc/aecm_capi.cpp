@@ -1,0 +1,224 @@
+// extern "C" surface of libaecm_mi355x.so: the reference's session ABI (include/echo_control_mobile.h)
+// and the batch extension (include/aecm_batch.h).  Plain pointers and sizes only.
+#include <hip/hip_runtime_api.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/aecm_batch.h"
+#include "../../include/echo_control_mobile.h"
+#include "aecm_engine.h"
+#include "aecm_session.h"
+
+using aecm::BatchEngine;
+using aecm::Session;
+
+struct AecmBatch {
+    BatchEngine *engine;
+};
+
+extern "C" {
+
+// ---- session ABI (reference aecm/echo_control_mobile.h:46-202) -----------------------------------
+
+void *WebRtcAecm_Create(void) { return Session::Create(); }
+
+void WebRtcAecm_Free(void *inst) { delete static_cast<Session *>(inst); }
+
+int32_t WebRtcAecm_Init(void *inst, int32_t sampFreq) {
+    if (inst == nullptr) return -1;
+    return static_cast<Session *>(inst)->Init(sampFreq);
+}
+
+int32_t WebRtcAecm_GetBufferFarendError(void *inst, const int16_t *farend, size_t nrOfSamples) {
+    if (inst == nullptr) return -1;
+    return static_cast<Session *>(inst)->BufferFarendError(farend, nrOfSamples);
+}
+
+int32_t WebRtcAecm_BufferFarend(void *inst, const int16_t *farend, size_t nrOfSamples) {
+    if (inst == nullptr) return -1;
+    return static_cast<Session *>(inst)->BufferFarend(farend, nrOfSamples);
+}
+
+int32_t WebRtcAecm_Process(void *inst, const int16_t *nearendNoisy, const int16_t *nearendClean, int16_t *out,
+                           size_t nrOfSamples, int16_t msInSndCardBuf) {
+    if (inst == nullptr) return -1;
+    return static_cast<Session *>(inst)->Process(nearendNoisy, nearendClean, out, nrOfSamples, msInSndCardBuf);
+}
+
+int32_t WebRtcAecm_set_config(void *inst, AecmConfig config) {
+    if (inst == nullptr) return -1;
+    return static_cast<Session *>(inst)->SetConfig(config.cngMode, config.echoMode);
+}
+
+int32_t WebRtcAecm_InitEchoPath(void *inst, const void *echo_path, size_t size_bytes) {
+    if (inst == nullptr) return -1;
+    return static_cast<Session *>(inst)->InitEchoPath(echo_path, size_bytes);
+}
+
+int32_t WebRtcAecm_GetEchoPath(void *inst, void *echo_path, size_t size_bytes) {
+    if (inst == nullptr) return -1;
+    return static_cast<Session *>(inst)->GetEchoPath(echo_path, size_bytes);
+}
+
+size_t WebRtcAecm_echo_path_size_bytes(void) { return aecm::kBins * sizeof(int16_t); }
+
+// ---- batch extension -------------------------------------------------------------------------------
+
+AecmBatch *WebRtcAecmBatch_Create(int32_t num_streams, int32_t device_id) {
+    BatchEngine *e = BatchEngine::Create(num_streams, device_id);
+    if (!e) return nullptr;
+    AecmBatch *b = new (std::nothrow) AecmBatch{e};
+    if (!b) delete e;
+    return b;
+}
+
+void WebRtcAecmBatch_Free(AecmBatch *b) {
+    if (!b) return;
+    delete b->engine;
+    delete b;
+}
+
+int32_t WebRtcAecmBatch_num_streams(const AecmBatch *b) { return b ? b->engine->num_streams() : -1; }
+
+int32_t WebRtcAecmBatch_Init(AecmBatch *b, int32_t sampFreq) {
+    if (!b) return -1;
+    if (sampFreq != 8000 && sampFreq != 16000) return AECM_BAD_PARAMETER_ERROR;
+    return b->engine->Init(sampFreq) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+static int32_t CheckRange(const AecmBatch *b, int32_t first, int32_t *count) {
+    if (!b) return -1;
+    if (!b->engine->initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (*count < 0) *count = b->engine->num_streams() - first;
+    if (first < 0 || *count < 0 || first + *count > b->engine->num_streams()) return AECM_BAD_PARAMETER_ERROR;
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_set_config(AecmBatch *b, AecmConfig config, int32_t first, int32_t count) {
+    if (int32_t rc = CheckRange(b, first, &count)) return rc;
+    if (config.cngMode != AecmFalse && config.cngMode != AecmTrue) return AECM_BAD_PARAMETER_ERROR;
+    if (config.echoMode < 0 || config.echoMode > 4) return AECM_BAD_PARAMETER_ERROR;
+    return b->engine->SetConfig(config.cngMode, config.echoMode, first, count) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_Control(AecmBatch *b, int32_t fixed_delay, int32_t nlp_flag, int32_t first, int32_t count) {
+    if (int32_t rc = CheckRange(b, first, &count)) return rc;
+    return b->engine->Control(fixed_delay, nlp_flag, first, count) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+static int32_t CheckIo(const AecmBatch *b, const void *far_p, const void *near_p, const void *out_p, int32_t num_blocks) {
+    if (!b) return -1;
+    if (!b->engine->initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (!far_p || !near_p || !out_p) return AECM_NULL_POINTER_ERROR;
+    if (num_blocks < 0) return AECM_BAD_PARAMETER_ERROR;
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_ProcessBlocks(AecmBatch *b, const int16_t *far_dev, const int16_t *near_dev,
+                                      const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                      int64_t block_stride, int32_t num_blocks) {
+    if (int32_t rc = CheckIo(b, far_dev, near_dev, out_dev, num_blocks)) return rc;
+    if (num_blocks == 0) return 0;
+    aecm::IoView io{far_dev, near_dev, near_clean_dev, out_dev, stream_stride, block_stride};
+    return b->engine->ProcessBlocks(io, num_blocks) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_ProcessBlocksHost(AecmBatch *b, const int16_t *far_host, const int16_t *near_host,
+                                          const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                          int64_t block_stride, int32_t num_blocks) {
+    if (int32_t rc = CheckIo(b, far_host, near_host, out_host, num_blocks)) return rc;
+    if (num_blocks == 0) return 0;
+    aecm::IoView io{far_host, near_host, near_clean_host, out_host, stream_stride, block_stride};
+    return b->engine->ProcessBlocksHost(io, num_blocks) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_Synchronize(AecmBatch *b) {
+    if (!b) return -1;
+    return b->engine->Synchronize() ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_GetLastLaunchMs(AecmBatch *b, float *ms) {
+    if (!b) return -1;
+    if (!ms) return AECM_NULL_POINTER_ERROR;
+    return b->engine->LastLaunchMs(ms) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_GetTimers(AecmBatch *b, double *total_ms, int64_t *launches) {
+    if (!b) return -1;
+    if (!total_ms || !launches) return AECM_NULL_POINTER_ERROR;
+    return b->engine->Timers(total_ms, launches) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_ResetTimers(AecmBatch *b) {
+    if (!b) return -1;
+    b->engine->ResetTimers();
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_InitEchoPath(AecmBatch *b, int32_t stream, const void *echo_path, size_t size_bytes) {
+    if (!b) return -1;
+    if (!echo_path) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes != aecm::kBins * sizeof(int16_t)) return AECM_BAD_PARAMETER_ERROR;
+    if (!b->engine->initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (stream < 0 || stream >= b->engine->num_streams()) return AECM_BAD_PARAMETER_ERROR;
+    int16_t tmp[aecm::kBins];
+    memcpy(tmp, echo_path, sizeof tmp);
+    return b->engine->SetEchoPath(stream, tmp) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_GetEchoPath(AecmBatch *b, int32_t stream, void *echo_path, size_t size_bytes) {
+    if (!b) return -1;
+    if (!echo_path) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes != aecm::kBins * sizeof(int16_t)) return AECM_BAD_PARAMETER_ERROR;
+    if (!b->engine->initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (stream < 0 || stream >= b->engine->num_streams()) return AECM_BAD_PARAMETER_ERROR;
+    int16_t tmp[aecm::kBins];
+    if (!b->engine->GetEchoPath(stream, tmp)) return AECM_UNSPECIFIED_ERROR;
+    memcpy(echo_path, tmp, sizeof tmp);
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]) {
+    if (!b) return -1;
+    if (!digest) return AECM_NULL_POINTER_ERROR;
+    if (!b->engine->initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (stream < 0 || stream >= b->engine->num_streams()) return AECM_BAD_PARAMETER_ERROR;
+    return b->engine->Digest(stream, digest) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant) {
+    if (!b) return -1;
+    if (variant != AECM_KERNEL_SAFE && variant != AECM_KERNEL_FAST) return AECM_BAD_PARAMETER_ERROR;
+    b->engine->set_variant(variant);
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]) {
+    if (!failures) return AECM_NULL_POINTER_ERROR;
+    if (hipSetDevice(device_id) != hipSuccess) return AECM_UNSPECIFIED_ERROR;
+    uint64_t *dev = nullptr;
+    if (hipMalloc((void **)&dev, 8 * sizeof(uint64_t)) != hipSuccess) return AECM_UNSPECIFIED_ERROR;
+    int32_t rc = AECM_UNSPECIFIED_ERROR;
+    if (hipMemset(dev, 0, 8 * sizeof(uint64_t)) == hipSuccess && aecm::LaunchSelfTest(dev, exhaustive, nullptr) == hipSuccess &&
+        hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(failures, dev, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess)
+        rc = 0;
+    (void)hipFree(dev);
+    return rc;
+}
+
+int32_t WebRtcAecmBatch_DeviceInfo(int32_t device_id, char *name, size_t name_len, int32_t *compute_units,
+                                   int32_t *clock_khz) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return AECM_UNSPECIFIED_ERROR;
+    if (name && name_len) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+#include "aecm_engine.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace aecm {
+
+#define AECM_HIP_OK(expr) ((expr) == hipSuccess)
+
+BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
+    if (num_streams <= 0) return nullptr;
+    int n_dev = 0;
+    if (!AECM_HIP_OK(hipGetDeviceCount(&n_dev)) || device_id < 0 || device_id >= n_dev) return nullptr;
+    if (!AECM_HIP_OK(hipSetDevice(device_id))) return nullptr;
+    BatchEngine *e = new BatchEngine();
+    e->device_ = device_id;
+    e->num_streams_ = num_streams;
+    const size_t S = (size_t)num_streams;
+    bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
+              AECM_HIP_OK(hipMalloc((void **)&e->st_.vec, S * kVecWordsPerStream * sizeof(uint32_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&e->st_.scal, S * kNumScal * sizeof(int32_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&e->st_.hist, S * kHistWordsPerStream * sizeof(uint16_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&e->image_vec_dev_, kVecWordsPerStream * sizeof(uint32_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&e->image_scal_dev_, kNumScal * sizeof(int32_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&e->patch_dev_, 32 * sizeof(int32_t))) &&
+              AECM_HIP_OK(hipEventCreate(&e->ev_start_)) && AECM_HIP_OK(hipEventCreate(&e->ev_stop_));
+    if (!ok) {
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+
+BatchEngine::~BatchEngine() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (ev_start_) (void)hipEventDestroy(ev_start_);
+    if (ev_stop_) (void)hipEventDestroy(ev_stop_);
+    (void)hipFree(st_.vec);
+    (void)hipFree(st_.scal);
+    (void)hipFree(st_.hist);
+    (void)hipFree(image_vec_dev_);
+    (void)hipFree(image_scal_dev_);
+    (void)hipFree(patch_dev_);
+    (void)hipFree(stage_dev_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+bool BatchEngine::Init(int fs) {
+    StreamImage img;
+    if (!BuildInitImage(fs, &img)) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    if (!AECM_HIP_OK(hipMemcpyAsync(image_vec_dev_, img.vec.data(), img.vec.size() * sizeof(uint32_t),
+                                    hipMemcpyHostToDevice, stream_)))
+        return false;
+    if (!AECM_HIP_OK(hipMemcpyAsync(image_scal_dev_, img.scal.data(), img.scal.size() * sizeof(int32_t),
+                                    hipMemcpyHostToDevice, stream_)))
+        return false;
+    if (!AECM_HIP_OK(LaunchBroadcastImage(st_, image_vec_dev_, image_scal_dev_, 0, num_streams_, stream_))) return false;
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;   // img goes out of scope
+    initialized_ = true;
+    return true;
+}
+
+bool BatchEngine::PatchScalars(const int32_t *fields, const int32_t *values, int n, int first, int count) {
+    if (n > 16) return false;
+    if (count < 0) count = num_streams_ - first;
+    if (first < 0 || count < 0 || first + count > num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    int32_t host[32];
+    memcpy(host, fields, n * sizeof(int32_t));
+    memcpy(host + 16, values, n * sizeof(int32_t));
+    if (!AECM_HIP_OK(hipMemcpyAsync(patch_dev_, host, sizeof host, hipMemcpyHostToDevice, stream_))) return false;
+    if (!AECM_HIP_OK(LaunchPatchScalars(st_, patch_dev_, patch_dev_ + 16, n, first, count, stream_))) return false;
+    return AECM_HIP_OK(hipStreamSynchronize(stream_));               // host[] is on the stack
+}
+
+bool BatchEngine::SetConfig(int cng_mode, int echo_mode, int first, int count) {
+    int32_t scal[kNumScal] = {0};
+    if (!ApplyConfig(scal, cng_mode, echo_mode)) return false;
+    const int32_t fields[7] = {S_CNG, S_SUPGAIN, S_SUPGAIN_OLD, S_SG_A, S_SG_D, S_SG_DAB, S_SG_DBD};
+    int32_t values[7];
+    for (int i = 0; i < 7; ++i) values[i] = scal[fields[i]];
+    return PatchScalars(fields, values, 7, first, count);
+}
+
+bool BatchEngine::SetCngMode(int cng_mode, int first, int count) {
+    const int32_t fields[1] = {S_CNG};
+    const int32_t values[1] = {cng_mode};
+    return PatchScalars(fields, values, 1, first, count);
+}
+
+bool BatchEngine::Control(int fixed_delay, int nlp_flag, int first, int count) {
+    int32_t scal[kNumScal] = {0};
+    ApplyControl(scal, fixed_delay, nlp_flag);
+    const int32_t fields[2] = {S_NLP, S_FIXED_DELAY};
+    const int32_t values[2] = {scal[S_NLP], scal[S_FIXED_DELAY]};
+    return PatchScalars(fields, values, 2, first, count);
+}
+
+bool BatchEngine::FlushTimers() {
+    if (!timed_pending_) return true;
+    if (!AECM_HIP_OK(hipEventSynchronize(ev_stop_))) return false;
+    float ms = 0.f;
+    if (!AECM_HIP_OK(hipEventElapsedTime(&ms, ev_start_, ev_stop_))) return false;
+    last_ms_ = ms;
+    total_ms_ += ms;
+    launches_ += 1;
+    timed_pending_ = false;
+    return true;
+}
+
+bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks) {
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    if (!FlushTimers()) return false;            // the event pair is reused: harvest the previous launch first
+    if (!AECM_HIP_OK(hipEventRecord(ev_start_, stream_))) return false;
+    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, io, num_streams_, num_blocks, variant_, stream_))) return false;
+    if (!AECM_HIP_OK(hipEventRecord(ev_stop_, stream_))) return false;
+    timed_pending_ = true;
+    return true;
+}
+
+bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    // Dense repack on the device side: [S][T*64] for each of far / near / (clean) / out.
+    const size_t per = (size_t)num_streams_ * num_blocks * kBlock;
+    const int n_in = io.near_clean ? 3 : 2;
+    const size_t need = per * (n_in + 1);
+    if (need > stage_elems_) {
+        (void)hipFree(stage_dev_);
+        stage_dev_ = nullptr;
+        stage_elems_ = 0;
+        if (!AECM_HIP_OK(hipMalloc((void **)&stage_dev_, need * sizeof(int16_t)))) return false;
+        stage_elems_ = need;
+    }
+    const bool dense = io.block_stride == kBlock && io.stream_stride == (int64_t)num_blocks * kBlock;
+    std::vector<int16_t> tmp;
+    auto upload = [&](const int16_t *src, int16_t *dst) -> bool {
+        if (dense) return AECM_HIP_OK(hipMemcpyAsync(dst, src, per * sizeof(int16_t), hipMemcpyHostToDevice, stream_));
+        tmp.resize(per);
+        for (int s = 0; s < num_streams_; ++s)
+            for (int b = 0; b < num_blocks; ++b)
+                memcpy(&tmp[((size_t)s * num_blocks + b) * kBlock], src + s * io.stream_stride + b * io.block_stride,
+                       kBlock * sizeof(int16_t));
+        return AECM_HIP_OK(hipMemcpy(dst, tmp.data(), per * sizeof(int16_t), hipMemcpyHostToDevice));
+    };
+    IoView dev;
+    dev.far = stage_dev_;
+    dev.near = stage_dev_ + per;
+    dev.near_clean = io.near_clean ? stage_dev_ + 2 * per : nullptr;
+    dev.out = stage_dev_ + (size_t)n_in * per;
+    dev.stream_stride = (int64_t)num_blocks * kBlock;
+    dev.block_stride = kBlock;
+    if (!upload(io.far, const_cast<int16_t *>(dev.far))) return false;
+    if (!upload(io.near, const_cast<int16_t *>(dev.near))) return false;
+    if (io.near_clean && !upload(io.near_clean, const_cast<int16_t *>(dev.near_clean))) return false;
+    if (!ProcessBlocks(dev, num_blocks)) return false;
+    if (dense) {
+        if (!AECM_HIP_OK(hipMemcpyAsync(io.out, dev.out, per * sizeof(int16_t), hipMemcpyDeviceToHost, stream_))) return false;
+        return AECM_HIP_OK(hipStreamSynchronize(stream_));
+    }
+    tmp.resize(per);
+    if (!AECM_HIP_OK(hipMemcpyAsync(tmp.data(), dev.out, per * sizeof(int16_t), hipMemcpyDeviceToHost, stream_))) return false;
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    for (int s = 0; s < num_streams_; ++s)
+        for (int b = 0; b < num_blocks; ++b)
+            memcpy(io.out + s * io.stream_stride + b * io.block_stride, &tmp[((size_t)s * num_blocks + b) * kBlock],
+                   kBlock * sizeof(int16_t));
+    return true;
+}
+
+bool BatchEngine::Synchronize() {
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    return AECM_HIP_OK(hipStreamSynchronize(stream_));
+}
+
+bool BatchEngine::LastLaunchMs(float *ms) {
+    if (!FlushTimers()) return false;
+    *ms = last_ms_;
+    return true;
+}
+
+bool BatchEngine::Timers(double *total_ms, int64_t *launches) {
+    if (!FlushTimers()) return false;
+    *total_ms = total_ms_;
+    *launches = launches_;
+    return true;
+}
+
+void BatchEngine::ResetTimers() {
+    (void)FlushTimers();
+    total_ms_ = 0.0;
+    launches_ = 0;
+}
+
+bool BatchEngine::SetEchoPath(int stream, const int16_t path[kBins]) {
+    if (stream < 0 || stream >= num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    // Read-modify-write of the three touched regions of one stream (rare, host-driven).
+    std::vector<uint32_t> vec(kVecWordsPerStream);
+    std::vector<int32_t> scal(kNumScal);
+    uint32_t *dvec = st_.vec + (size_t)stream * kVecWordsPerStream;
+    int32_t *dscal = st_.scal + (size_t)stream * kNumScal;
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!AECM_HIP_OK(hipMemcpy(vec.data(), dvec, vec.size() * sizeof(uint32_t), hipMemcpyDeviceToHost))) return false;
+    if (!AECM_HIP_OK(hipMemcpy(scal.data(), dscal, scal.size() * sizeof(int32_t), hipMemcpyDeviceToHost))) return false;
+    aecm::SetEchoPath(vec.data(), scal.data(), path);
+    if (!AECM_HIP_OK(hipMemcpy(dvec, vec.data(), vec.size() * sizeof(uint32_t), hipMemcpyHostToDevice))) return false;
+    return AECM_HIP_OK(hipMemcpy(dscal, scal.data(), scal.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+}
+
+bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
+    if (stream < 0 || stream >= num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    std::vector<uint32_t> ch(kLanes);
+    std::vector<int32_t> scal(kNumScal);
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!AECM_HIP_OK(hipMemcpy(ch.data(), st_.vec + (size_t)stream * kVecWordsPerStream + V_CH16 * kLanes,
+                               kLanes * sizeof(uint32_t), hipMemcpyDeviceToHost)))
+        return false;
+    if (!AECM_HIP_OK(hipMemcpy(scal.data(), st_.scal + (size_t)stream * kNumScal, kNumScal * sizeof(int32_t),
+                               hipMemcpyDeviceToHost)))
+        return false;
+    for (int t = 0; t < kLanes; ++t) path[t] = (int16_t)(ch[t] & 0xffff);
+    path[64] = (int16_t)scal[S_B64_CHSTORED];
+    return true;
+}
+
+bool BatchEngine::Digest(int stream, uint32_t digest[kDigestWords]) {
+    if (stream < 0 || stream >= num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    std::vector<uint32_t> vec(kVecWordsPerStream);
+    std::vector<int32_t> scal(kNumScal);
+    std::vector<uint16_t> hist(kHistWordsPerStream);
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!AECM_HIP_OK(hipMemcpy(vec.data(), st_.vec + (size_t)stream * kVecWordsPerStream, vec.size() * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost)))
+        return false;
+    if (!AECM_HIP_OK(hipMemcpy(scal.data(), st_.scal + (size_t)stream * kNumScal, scal.size() * sizeof(int32_t),
+                               hipMemcpyDeviceToHost)))
+        return false;
+    if (!AECM_HIP_OK(hipMemcpy(hist.data(), st_.hist + (size_t)stream * kHistWordsPerStream,
+                               hist.size() * sizeof(uint16_t), hipMemcpyDeviceToHost)))
+        return false;
+    ComputeDigest(vec.data(), scal.data(), hist.data(), digest);
+    return true;
+}
+
+}  // namespace aecm

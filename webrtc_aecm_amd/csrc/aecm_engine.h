@@ -1,0 +1,65 @@
+// Host-side owner of the device state of S AECM streams and of the HIP stream they run on.
+#ifndef AECM_AMD_ENGINE_H_
+#define AECM_AMD_ENGINE_H_
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "aecm_host_state.h"
+#include "aecm_kernels.h"
+#include "aecm_state.h"
+
+namespace aecm {
+
+class BatchEngine {
+public:
+    // Returns nullptr if the device cannot be used or memory cannot be allocated.
+    static BatchEngine *Create(int num_streams, int device_id);
+    ~BatchEngine();
+
+    int num_streams() const { return num_streams_; }
+    bool initialized() const { return initialized_; }
+    hipStream_t stream() const { return stream_; }
+
+    // All methods return a hipError_t-free status: true on success.
+    bool Init(int fs);
+    bool SetConfig(int cng_mode, int echo_mode, int first, int count);
+    bool SetCngMode(int cng_mode, int first, int count);
+    bool Control(int fixed_delay, int nlp_flag, int first, int count);
+    bool ProcessBlocks(const IoView &io_dev, int num_blocks);          // async
+    bool ProcessBlocksHost(const IoView &io_host, int num_blocks);     // sync
+    bool Synchronize();
+    bool LastLaunchMs(float *ms);
+    bool Timers(double *total_ms, int64_t *launches);
+    void ResetTimers();
+    bool SetEchoPath(int stream, const int16_t path[kBins]);
+    bool GetEchoPath(int stream, int16_t path[kBins]);
+    bool Digest(int stream, uint32_t digest[kDigestWords]);
+    void set_variant(int v) { variant_ = v; }
+
+private:
+    BatchEngine() = default;
+    bool PatchScalars(const int32_t *fields, const int32_t *values, int n, int first, int count);
+    bool FlushTimers();
+
+    int device_ = 0;
+    int num_streams_ = 0;
+    bool initialized_ = false;
+    int variant_ = kVariantFast;
+    hipStream_t stream_ = nullptr;
+    StatePtrs st_{nullptr, nullptr, nullptr};
+    uint32_t *image_vec_dev_ = nullptr;
+    int32_t *image_scal_dev_ = nullptr;
+    int32_t *patch_dev_ = nullptr;       // 2 x 16 ints
+    hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
+    bool timed_pending_ = false;
+    float last_ms_ = 0.f;
+    double total_ms_ = 0.0;
+    int64_t launches_ = 0;
+    // staging for ProcessBlocksHost
+    int16_t *stage_dev_ = nullptr;
+    size_t stage_elems_ = 0;
+};
+
+}  // namespace aecm
+#endif  // AECM_AMD_ENGINE_H_

@@ -1,0 +1,38 @@
+// Launchers of the gfx950 kernels (aecm_kernels.hip).  Host-callable, HIP runtime types only.
+#ifndef AECM_AMD_KERNELS_H_
+#define AECM_AMD_KERNELS_H_
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "aecm_state.h"
+
+namespace aecm {
+
+constexpr int kWavesPerWorkgroup = 4;    // 256 threads: 4 streams share one copy of the LDS tables
+
+enum KernelVariant : int {
+    kVariantSafe = 0,   // ds_bpermute shuffles only
+    kVariantFast = 1    // DPP / permlane-swap cross-lane primitives (default)
+};
+
+// Process n_blocks consecutive blocks of streams [0, n_streams) -- one wavefront per stream.
+hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
+                               hipStream_t stream);
+
+// Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into
+// streams [first, first + count) and clear their far-spectrum history.
+hipError_t LaunchBroadcastImage(const StatePtrs &st, const uint32_t *image_vec, const int32_t *image_scal,
+                                int first, int count, hipStream_t stream);
+
+// Overwrite a few scalar fields (field ids from ScalField) of streams [first, first + count).
+hipError_t LaunchPatchScalars(const StatePtrs &st, const int32_t *fields_dev, const int32_t *values_dev, int n_fields,
+                              int first, int count, hipStream_t stream);
+
+// Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
+//  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,
+//  6 isqrt31 (exhaustive over [0, 2^31) when exhaustive != 0, else 2^24 samples), 7 table upload.
+hipError_t LaunchSelfTest(uint64_t *counters_dev, int exhaustive, hipStream_t stream);
+
+}  // namespace aecm
+#endif  // AECM_AMD_KERNELS_H_

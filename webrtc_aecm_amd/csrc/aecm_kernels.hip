@@ -1,0 +1,196 @@
+// gfx950 kernels of the MI355X AECM engine.
+//
+// aecm_process_kernel: one wavefront per stream, 4 streams per 256-thread workgroup.  The whole
+// persistent state of a stream (~40 lane vectors + ~50 scalars) is loaded into registers once,
+// n_blocks blocks are processed back to back (WebRtcAecm_ProcessBlock-equivalents, aecm_wave.h),
+// and the state is written back once.  Per block a wave touches 3 x 128 B of audio I/O (prefetched
+// one block ahead), writes one 128-byte far-spectrum row and reads at most one.  The constant
+// tables (FFT twiddles, comfort-noise cos/sin, sqrt-Hanning) are staged in LDS by the prologue.
+// No MFMA: nothing here is a dense contraction.
+#define AECM_TABLE_ATTR __device__
+#include "aecm_kernels.h"
+
+#include "aecm_tables.h"
+#include "aecm_wave.h"
+#include "wave_gfx950.h"
+
+namespace aecm {
+
+__device__ __forceinline__ void FillLdsTables() {
+    LdsTables &t = g_lds[0];
+    for (int i = threadIdx.x; i < 64; i += blockDim.x)
+        t.twiddle[i] = zext16(kAecmTwiddleCosQ15[i]) | shl(kAecmTwiddleSinQ15[i], 16);
+    for (int i = threadIdx.x; i < 360; i += blockDim.x)
+        t.cossin[i] = zext16(kAecmCosQ13[i]) | shl(kAecmSinQ13[i], 16);
+    for (int i = threadIdx.x; i < 65; i += blockDim.x) t.hann[i] = kAecmSqrtHanningQ14[i];
+    __syncthreads();
+}
+
+template <bool kFast, bool kHasClean>
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup) void aecm_process_kernel(StatePtrs st, IoView io, int n_streams,
+                                                                              int n_blocks) {
+    FillLdsTables();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t stream = (int64_t)blockIdx.x * kWavesPerWorkgroup + wave;
+    if (stream >= n_streams) return;
+    BlockEngine<Gfx950Wave<kFast>, kHasClean>::run_stream(st, io, stream, n_blocks);
+}
+
+hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
+                               hipStream_t stream) {
+    if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
+    const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup);
+    const dim3 block(64 * kWavesPerWorkgroup);
+    const size_t lds = sizeof(LdsTables);
+    const bool clean = io.near_clean != nullptr;
+    if (variant == kVariantFast) {
+        if (clean) hipLaunchKernelGGL((aecm_process_kernel<true, true>), grid, block, lds, stream, st, io, n_streams, n_blocks);
+        else hipLaunchKernelGGL((aecm_process_kernel<true, false>), grid, block, lds, stream, st, io, n_streams, n_blocks);
+    } else {
+        if (clean) hipLaunchKernelGGL((aecm_process_kernel<false, true>), grid, block, lds, stream, st, io, n_streams, n_blocks);
+        else hipLaunchKernelGGL((aecm_process_kernel<false, false>), grid, block, lds, stream, st, io, n_streams, n_blocks);
+    }
+    return hipGetLastError();
+}
+
+// ---- state maintenance ---------------------------------------------------------------------------
+
+__global__ void aecm_broadcast_image_kernel(StatePtrs st, const uint32_t *image_vec, const int32_t *image_scal,
+                                            int first, int count) {
+    const int64_t s = (int64_t)first + blockIdx.x;
+    if (blockIdx.x >= (unsigned)count) return;
+    uint32_t *vec = st.vec + s * (int64_t)kVecWordsPerStream;
+    for (int i = threadIdx.x; i < (int)kVecWordsPerStream; i += blockDim.x) vec[i] = image_vec[i];
+    int32_t *scal = st.scal + s * (int64_t)kNumScal;
+    for (int i = threadIdx.x; i < kNumScal; i += blockDim.x) scal[i] = image_scal[i];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(st.hist + s * (int64_t)kHistWordsPerStream);
+    for (int i = threadIdx.x; i < (int)kHistWordsPerStream / 2; i += blockDim.x) hist[i] = 0u;
+}
+
+hipError_t LaunchBroadcastImage(const StatePtrs &st, const uint32_t *image_vec, const int32_t *image_scal, int first,
+                                int count, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_broadcast_image_kernel, dim3(count), dim3(256), 0, stream, st, image_vec, image_scal, first,
+                       count);
+    return hipGetLastError();
+}
+
+__global__ void aecm_patch_scalars_kernel(StatePtrs st, const int32_t *fields, const int32_t *values, int n_fields,
+                                          int first, int count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)count * n_fields) return;
+    const int64_t s = first + i / n_fields;
+    const int f = (int)(i % n_fields);
+    st.scal[s * (int64_t)kNumScal + fields[f]] = values[f];
+}
+
+hipError_t LaunchPatchScalars(const StatePtrs &st, const int32_t *fields_dev, const int32_t *values_dev, int n_fields,
+                              int first, int count, hipStream_t stream) {
+    if (count <= 0 || n_fields <= 0) return hipSuccess;
+    const int64_t total = (int64_t)count * n_fields;
+    hipLaunchKernelGGL(aecm_patch_scalars_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, st,
+                       fields_dev, values_dev, n_fields, first, count);
+    return hipGetLastError();
+}
+
+// ---- self test of the wave primitives ------------------------------------------------------------
+
+__device__ __forceinline__ unsigned Mix(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <int Q>
+__device__ __forceinline__ void TestExchange(int va, int vb, uint64_t *fails) {
+    int a0 = va, b0 = vb, a1 = va, b1 = vb;
+    Gfx950Wave<false>::exchange<Q>(a0, b0);
+    Gfx950Wave<true>::exchange<Q>(a1, b1);
+    // definition: lanes with bit Q clear keep a, b <- partner's a; lanes with bit Q set keep b, a <- partner's b
+    const int lane = threadIdx.x & 63;
+    const int pa = __shfl(va, lane ^ (1 << Q)), pb = __shfl(vb, lane ^ (1 << Q));
+    const int ea = ((lane >> Q) & 1) ? pb : va, eb = ((lane >> Q) & 1) ? vb : pa;
+    if (a0 != ea || b0 != eb) atomicAdd((unsigned long long *)&fails[1], 1ull);
+    if (a1 != ea || b1 != eb) atomicAdd((unsigned long long *)&fails[1], 1ull);
+}
+
+__global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int exhaustive) {
+    FillLdsTables();
+    using S = Gfx950Wave<false>;
+    using F = Gfx950Wave<true>;
+    const int lane = threadIdx.x & 63;
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    auto bump = [&](int k) { atomicAdd((unsigned long long *)&fails[k], 1ull); };
+
+    if (blockIdx.x < 64) {
+        for (int round = 0; round < 16; ++round) {
+            const int v = (int)Mix(gid * 977u + round * 131071u + 1u);
+            const int w = (int)Mix(gid * 31u + round * 8191u + 7u);
+            // 0: xor shuffles against __shfl with an explicit source lane
+            if (F::shfl_xor<1>(v) != __shfl(v, lane ^ 1)) bump(0);
+            if (F::shfl_xor<2>(v) != __shfl(v, lane ^ 2)) bump(0);
+            if (F::shfl_xor<4>(v) != __shfl(v, lane ^ 4)) bump(0);
+            if (F::shfl_xor<8>(v) != __shfl(v, lane ^ 8)) bump(0);
+            if (F::shfl_xor<16>(v) != __shfl(v, lane ^ 16)) bump(0);
+            if (F::shfl_xor<32>(v) != __shfl(v, lane ^ 32)) bump(0);
+            // 1: FFT operand exchange on every lane bit
+            TestExchange<0>(v, w, fails); TestExchange<1>(v, w, fails); TestExchange<2>(v, w, fails);
+            TestExchange<3>(v, w, fails); TestExchange<4>(v, w, fails); TestExchange<5>(v, w, fails);
+            // 2: reductions against a serial readlane loop
+            int mx = (int)0x80000000, mn = 0x7fffffff, sm = 0;
+            for (int i = 0; i < 64; ++i) {
+                const int x = __shfl(v, i);
+                mx = x > mx ? x : mx; mn = x < mn ? x : mn; sm = add(sm, x);
+            }
+            if (F::reduce_max(v) != mx || S::reduce_max(v) != mx) bump(2);
+            if (F::reduce_min(v) != mn || S::reduce_min(v) != mn) bump(2);
+            if (F::reduce_add(v) != sm || S::reduce_add(v) != sm) bump(2);
+            // 3: whole-wave shift by one lane with fill
+            const int up = __shfl(v, lane == 0 ? 0 : lane - 1);
+            const int expect_up = lane == 0 ? 12345 + round : up;
+            if (F::shift_up1(v, 12345 + round) != expect_up || S::shift_up1(v, 12345 + round) != expect_up) bump(3);
+            // 4: bpermute / readlane / writelane
+            const int src = (int)(Mix(gid + round) & 63u);
+            if (F::bpermute(v, src) != __shfl(v, src)) bump(4);
+            const int sel_lane = (round * 7 + (int)blockIdx.x) & 63;
+            if (F::readlane(v, sel_lane) != __shfl(v, sel_lane)) bump(4);
+            const int wl = F::writelane(v, 424242, sel_lane);
+            if (wl != (lane == sel_lane ? 424242 : v)) bump(4);
+            // 5: ballot bit order
+            const bool p = (v >> 3) & 1;
+            const uint64_t bal = F::ballot(p);
+            if (((bal >> lane) & 1ull) != (p ? 1ull : 0ull)) bump(5);
+            if (__builtin_popcountll(bal) != F::reduce_add(p ? 1 : 0)) bump(5);
+        }
+        // 7: LDS tables
+        if (threadIdx.x < 64) {
+            if (F::twiddle_cos(lane) != kAecmTwiddleCosQ15[lane] || F::twiddle_sin(lane) != kAecmTwiddleSinQ15[lane]) bump(7);
+            if (F::hann(lane + 1) != kAecmSqrtHanningQ14[lane + 1]) bump(7);
+            for (int i = lane; i < 360; i += 64)
+                if (F::cos360(i) != kAecmCosQ13[i] || F::sin360(i) != kAecmSinQ13[i]) bump(7);
+        }
+    }
+    // 6: floor(sqrt) -- exhaustive over [0, 2^31) in grid-stride, or a 2^24-point sample
+    const uint64_t total = exhaustive ? (1ull << 31) : (1ull << 24);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = gid; i < total; i += stride) {
+        const unsigned x = exhaustive ? (unsigned)i : (Mix((unsigned)i) & 0x7fffffffu);
+        const uint64_t r = (unsigned)F::isqrt31((int)x);
+        if (r * r > x || (r + 1) * (r + 1) <= x) bump(6);
+    }
+    // edge values
+    if (gid == 0) {
+        const unsigned edges[6] = {0u, 1u, 0x7fffffffu, 0x7ffea810u /*46340^2*/, 0x7ffea80fu, 0x40000000u};
+        for (int k = 0; k < 6; ++k) {
+            const uint64_t r = (unsigned)F::isqrt31((int)edges[k]);
+            if (r * r > edges[k] || (r + 1) * (r + 1) <= edges[k]) bump(6);
+        }
+    }
+}
+
+hipError_t LaunchSelfTest(uint64_t *counters_dev, int exhaustive, hipStream_t stream) {
+    hipLaunchKernelGGL(aecm_selftest_kernel, dim3(exhaustive ? 4096 : 256), dim3(256), sizeof(LdsTables), stream,
+                       counters_dev, exhaustive);
+    return hipGetLastError();
+}
+
+}  // namespace aecm

@@ -534,22 +534,22 @@ struct BlockEngine {
         r.near_log = lo16(w); r.adapt_log = hi16(w);
         r.stored_log = lo16(V(V_LOG_S));
         Uniform &u = r.u;
-        u.tot_count = scal[S_TOTCOUNT]; u.seed = scal[S_SEED]; u.startup = scal[S_STARTUP]; u.hist_pos = scal[S_HISTPOS];
-        u.dfa_noisy_q = scal[S_DFANOISYQ]; u.dfa_noisy_q_old = scal[S_DFANOISYQ_OLD];
-        u.dfa_clean_q = scal[S_DFACLEANQ]; u.dfa_clean_q_old = scal[S_DFACLEANQ_OLD];
-        u.far_log = scal[S_FARLOG]; u.fe_min = scal[S_FE_MIN]; u.fe_max = scal[S_FE_MAX]; u.fe_maxmin = scal[S_FE_MAXMIN];
-        u.fe_vad = scal[S_FE_VAD]; u.fe_mse = scal[S_FE_MSE]; u.cur_vad = scal[S_CURVAD]; u.vad_cnt = scal[S_VADCNT];
-        u.first_vad = scal[S_FIRSTVAD]; u.mse_cnt = scal[S_MSECNT]; u.mse_adapt_old = scal[S_MSE_ADAPT_OLD];
-        u.mse_stored_old = scal[S_MSE_STORED_OLD]; u.mse_thresh = scal[S_MSE_THRESH];
-        u.sup_gain = scal[S_SUPGAIN]; u.sup_gain_old = scal[S_SUPGAIN_OLD]; u.noise_ctr = scal[S_NOISECTR];
-        u.far_init = scal[S_FAR_INIT]; u.near_init = scal[S_NEAR_INIT]; u.min_prob = scal[S_MIN_PROB];
-        u.last_prob = scal[S_LAST_PROB]; u.last_delay = scal[S_LAST_DELAY];
-        u.mult = scal[S_MULT]; u.cng = scal[S_CNG]; u.nlp = scal[S_NLP]; u.fixed_delay = scal[S_FIXED_DELAY];
-        u.sg_a = scal[S_SG_A]; u.sg_d = scal[S_SG_D]; u.sg_dab = scal[S_SG_DAB]; u.sg_dbd = scal[S_SG_DBD];
+        u.tot_count = W::uni(scal[S_TOTCOUNT]); u.seed = W::uni(scal[S_SEED]); u.startup = W::uni(scal[S_STARTUP]); u.hist_pos = W::uni(scal[S_HISTPOS]);
+        u.dfa_noisy_q = W::uni(scal[S_DFANOISYQ]); u.dfa_noisy_q_old = W::uni(scal[S_DFANOISYQ_OLD]);
+        u.dfa_clean_q = W::uni(scal[S_DFACLEANQ]); u.dfa_clean_q_old = W::uni(scal[S_DFACLEANQ_OLD]);
+        u.far_log = W::uni(scal[S_FARLOG]); u.fe_min = W::uni(scal[S_FE_MIN]); u.fe_max = W::uni(scal[S_FE_MAX]); u.fe_maxmin = W::uni(scal[S_FE_MAXMIN]);
+        u.fe_vad = W::uni(scal[S_FE_VAD]); u.fe_mse = W::uni(scal[S_FE_MSE]); u.cur_vad = W::uni(scal[S_CURVAD]); u.vad_cnt = W::uni(scal[S_VADCNT]);
+        u.first_vad = W::uni(scal[S_FIRSTVAD]); u.mse_cnt = W::uni(scal[S_MSECNT]); u.mse_adapt_old = W::uni(scal[S_MSE_ADAPT_OLD]);
+        u.mse_stored_old = W::uni(scal[S_MSE_STORED_OLD]); u.mse_thresh = W::uni(scal[S_MSE_THRESH]);
+        u.sup_gain = W::uni(scal[S_SUPGAIN]); u.sup_gain_old = W::uni(scal[S_SUPGAIN_OLD]); u.noise_ctr = W::uni(scal[S_NOISECTR]);
+        u.far_init = W::uni(scal[S_FAR_INIT]); u.near_init = W::uni(scal[S_NEAR_INIT]); u.min_prob = W::uni(scal[S_MIN_PROB]);
+        u.last_prob = W::uni(scal[S_LAST_PROB]); u.last_delay = W::uni(scal[S_LAST_DELAY]);
+        u.mult = W::uni(scal[S_MULT]); u.cng = W::uni(scal[S_CNG]); u.nlp = W::uni(scal[S_NLP]); u.fixed_delay = W::uni(scal[S_FIXED_DELAY]);
+        u.sg_a = W::uni(scal[S_SG_A]); u.sg_d = W::uni(scal[S_SG_D]); u.sg_dab = W::uni(scal[S_SG_DAB]); u.sg_dbd = W::uni(scal[S_SG_DBD]);
         BinState<int> &e = r.b64;
-        e.ch_stored = scal[S_B64_CHSTORED]; e.ch_adapt16 = scal[S_B64_CHADAPT16]; e.ch_adapt32 = scal[S_B64_CHADAPT32];
-        e.echo_filt = scal[S_B64_ECHOFILT]; e.near_filt = scal[S_B64_NEARFILT]; e.noise_est = scal[S_B64_NOISE];
-        e.low_ctr = scal[S_B64_LOWCTR]; e.high_ctr = scal[S_B64_HIGHCTR];
+        e.ch_stored = W::uni(scal[S_B64_CHSTORED]); e.ch_adapt16 = W::uni(scal[S_B64_CHADAPT16]); e.ch_adapt32 = W::uni(scal[S_B64_CHADAPT32]);
+        e.echo_filt = W::uni(scal[S_B64_ECHOFILT]); e.near_filt = W::uni(scal[S_B64_NEARFILT]); e.noise_est = W::uni(scal[S_B64_NOISE]);
+        e.low_ctr = W::uni(scal[S_B64_LOWCTR]); e.high_ctr = W::uni(scal[S_B64_HIGHCTR]);
     }
 
     static AECM_HD void store_state(const Regs &r, uint32_t *vec, int32_t *scal) {

@@ -1,0 +1,156 @@
+// gfx950 (MI355X / CDNA4) wave policy for aecm_wave.h: a lane vector is an int in a VGPR, a
+// wave-uniform value is an int the compiler keeps in an SGPR, tables live in LDS.
+//
+// Two variants of the cross-lane primitives:
+//   kFast = false : only ds_bpermute-based HIP shuffles (__shfl_xor/__shfl_up) -- semantics are the
+//                   documented ones, used as the in-kernel reference for the self test;
+//   kFast = true  : DPP row operations (quad_perm / row_ror / row_shl+row_shr with bank masks /
+//                   row_half_mirror / row_mirror / wave_shr), v_permlane16_swap / v_permlane32_swap
+//                   for the two widest FFT exchanges, v_readlane for the final cross-row combine.
+// aecm_selftest_kernel (aecm_kernels.hip) checks every kFast primitive against kFast = false and
+// isqrt31 against its definition on the device before any parity claim is made.
+#ifndef AECM_AMD_WAVE_GFX950_H_
+#define AECM_AMD_WAVE_GFX950_H_
+
+#include <hip/hip_runtime.h>
+
+#include "aecm_ops.h"
+
+namespace aecm {
+
+// LDS tables, filled by the kernel prologue (aecm_kernels.hip).
+struct LdsTables {
+    int twiddle[64];   // lo16: cos (wr), hi16: sin       entries 8r+256 / 8r of kSinTable1024
+    int cossin[360];   // lo16: cos Q13, hi16: sin Q13     comfort-noise phase table
+    int hann[65];      // sqrt-Hanning Q14
+};
+extern __shared__ LdsTables g_lds[];   // one instance (dynamic LDS)
+
+#define AECM_DPP(old, src, ctrl, row_mask, bank_mask, bound) \
+    __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), (bank_mask), (bound))
+
+enum : int {
+    kDppQuadXor1 = 0xB1,       // quad_perm:[1,0,3,2]
+    kDppQuadXor2 = 0x4E,       // quad_perm:[2,3,0,1]
+    kDppRowShl4 = 0x104,       // dst[i] = src[i+4] within a row of 16
+    kDppRowShr4 = 0x114,       // dst[i] = src[i-4]
+    kDppRowRor8 = 0x128,       // dst[i] = src[(i+8) mod 16]  == xor 8
+    kDppWaveShr1 = 0x138,      // dst[i] = src[i-1] across the whole wave
+    kDppRowMirror = 0x140,     // dst[i] = src[15-i]
+    kDppRowHalfMirror = 0x141  // dst[i] = src[7-i] within 8
+};
+
+template <bool kFast>
+struct Gfx950Wave {
+    using vi = int;
+    using vb = bool;
+
+    static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+    static __device__ __forceinline__ bool is_first_lane() { return lane_id() == 0; }
+    static __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+    // ---- tables ----
+    static __device__ __forceinline__ int hann(int i) { return g_lds[0].hann[i]; }
+    static __device__ __forceinline__ int twiddle_cos(int i) { return sext16(g_lds[0].twiddle[i]); }
+    static __device__ __forceinline__ int twiddle_sin(int i) { return g_lds[0].twiddle[i] >> 16; }
+    static __device__ __forceinline__ int cos360(int i) { return sext16(g_lds[0].cossin[i]); }
+    static __device__ __forceinline__ int sin360(int i) { return g_lds[0].cossin[i] >> 16; }
+
+    // ---- xor shuffles ----
+    template <int M>
+    static __device__ __forceinline__ int shfl_xor(int v) {
+        if constexpr (!kFast) {
+            return __shfl_xor(v, M);
+        } else if constexpr (M == 1) {
+            return AECM_DPP(v, v, kDppQuadXor1, 0xf, 0xf, false);
+        } else if constexpr (M == 2) {
+            return AECM_DPP(v, v, kDppQuadXor2, 0xf, 0xf, false);
+        } else if constexpr (M == 4) {
+            int t = AECM_DPP(v, v, kDppRowShl4, 0xf, 0x5, false);   // banks 0,2 (bit 2 clear) <- lane+4
+            return AECM_DPP(t, v, kDppRowShr4, 0xf, 0xa, false);    // banks 1,3 (bit 2 set)   <- lane-4
+        } else if constexpr (M == 8) {
+            return AECM_DPP(v, v, kDppRowRor8, 0xf, 0xf, false);
+        } else {
+            return __shfl_xor(v, M);
+        }
+    }
+
+    // Re-pair FFT operands across lane bit Q (see tests/sim/wave_sim.h for the definition).
+    template <int Q>
+    static __device__ __forceinline__ void exchange(int &a, int &b) {
+        if constexpr (kFast && Q == 5) {
+            auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+            a = (int)r[0];
+            b = (int)r[1];
+        } else if constexpr (kFast && Q == 4) {
+            auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+            a = (int)r[0];
+            b = (int)r[1];
+        } else {
+            const bool hi = (lane_id() >> Q) & 1;
+            int send = hi ? a : b;
+            int recv = shfl_xor<(1 << Q)>(send);
+            if (hi) a = recv;
+            else b = recv;
+        }
+    }
+
+    // ---- reductions: all lanes of a 16-lane row get the row result, then 4 readlanes ----
+    template <class Op>
+    static __device__ __forceinline__ int reduce(int v, Op op) {
+        if constexpr (kFast) {
+            v = op(v, AECM_DPP(v, v, kDppQuadXor1, 0xf, 0xf, false));
+            v = op(v, AECM_DPP(v, v, kDppQuadXor2, 0xf, 0xf, false));
+            v = op(v, AECM_DPP(v, v, kDppRowHalfMirror, 0xf, 0xf, false));
+            v = op(v, AECM_DPP(v, v, kDppRowMirror, 0xf, 0xf, false));
+            int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+            int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+            return op(op(r0, r1), op(r2, r3));
+        } else {
+            v = op(v, __shfl_xor(v, 1));
+            v = op(v, __shfl_xor(v, 2));
+            v = op(v, __shfl_xor(v, 4));
+            v = op(v, __shfl_xor(v, 8));
+            v = op(v, __shfl_xor(v, 16));
+            v = op(v, __shfl_xor(v, 32));
+            return __builtin_amdgcn_readfirstlane(v);
+        }
+    }
+    static __device__ __forceinline__ int reduce_max(int v) { return reduce(v, [](int a, int b) { return a > b ? a : b; }); }
+    static __device__ __forceinline__ int reduce_min(int v) { return reduce(v, [](int a, int b) { return a < b ? a : b; }); }
+    static __device__ __forceinline__ int reduce_add(int v) { return reduce(v, [](int a, int b) { return add(a, b); }); }
+
+    static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+    static __device__ __forceinline__ int readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+    static __device__ __forceinline__ int writelane(int v, int value, int lane) { return lane_id() == lane ? value : v; }
+    static __device__ __forceinline__ int bpermute(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+    static __device__ __forceinline__ int shift_up1(int v, int fill) {
+        if constexpr (kFast) {
+            return AECM_DPP(fill, v, kDppWaveShr1, 0xf, 0xf, false);   // lane 0 has no source: keeps `old` = fill
+        } else {
+            int t = __shfl_up(v, 1);
+            return lane_id() == 0 ? fill : t;
+        }
+    }
+
+    // floor(sqrt(x)) for 0 <= x <= 2^31-1: v_sqrt_f32 is within 1 ulp, float(x) within 2^-24
+    // relative, so the truncated root is off by at most one either way; two exact corrections.
+    static __device__ __forceinline__ int isqrt31(int x) {
+        unsigned ux = (unsigned)x;
+        unsigned r = (unsigned)__builtin_amdgcn_sqrtf((float)ux);
+        r = (r * r > ux) ? r - 1 : r;
+        r = ((r + 1) * (r + 1) <= ux) ? r + 1 : r;
+        return (int)r;
+    }
+
+    // ---- memory ----
+    static __device__ __forceinline__ int load_u32(const uint32_t *p, int idx) { return (int)p[idx]; }
+    static __device__ __forceinline__ void store_u32(uint32_t *p, int idx, int v) { p[idx] = (uint32_t)v; }
+    static __device__ __forceinline__ int load_i16(const int16_t *p, int idx) { return p[idx]; }
+    static __device__ __forceinline__ int load_u16(const uint16_t *p, int idx) { return p[idx]; }
+    static __device__ __forceinline__ void store_i16(int16_t *p, int idx, int v) { p[idx] = (int16_t)v; }
+    static __device__ __forceinline__ void store_u16(uint16_t *p, int idx, int v) { p[idx] = (uint16_t)v; }
+};
+
+}  // namespace aecm
+#endif  // AECM_AMD_WAVE_GFX950_H_

@@ -1,0 +1,281 @@
+"""ctypes bindings of libaecm_mi355x.so.
+
+`Aecm` mirrors the reference's session interface (aecm/echo_control_mobile.h: Create / Init /
+BufferFarend / Process / set_config / InitEchoPath / GetEchoPath / Free, same argument meaning and
+return codes); `AecmBatch` is the batch extension (include/aecm_batch.h).  There is no Python or CPU
+implementation of the DSP here: without the HIP library and a GPU these classes raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import build as _build
+
+BLOCK = 64
+BINS = 65
+DIGEST_WORDS = 24
+KERNEL_SAFE, KERNEL_FAST = 0, 1
+
+AECM_UNSPECIFIED_ERROR = 12000
+AECM_UNSUPPORTED_FUNCTION_ERROR = 12001
+AECM_UNINITIALIZED_ERROR = 12002
+AECM_NULL_POINTER_ERROR = 12003
+AECM_BAD_PARAMETER_ERROR = 12004
+AECM_BAD_PARAMETER_WARNING = 12100
+
+SESSION_SYMBOLS = [
+    "WebRtcAecm_Create", "WebRtcAecm_Free", "WebRtcAecm_Init", "WebRtcAecm_BufferFarend",
+    "WebRtcAecm_GetBufferFarendError", "WebRtcAecm_Process", "WebRtcAecm_set_config",
+    "WebRtcAecm_InitEchoPath", "WebRtcAecm_GetEchoPath", "WebRtcAecm_echo_path_size_bytes",
+]
+BATCH_SYMBOLS = [
+    "WebRtcAecmBatch_Create", "WebRtcAecmBatch_Free", "WebRtcAecmBatch_num_streams", "WebRtcAecmBatch_Init",
+    "WebRtcAecmBatch_set_config", "WebRtcAecmBatch_Control", "WebRtcAecmBatch_ProcessBlocks",
+    "WebRtcAecmBatch_ProcessBlocksHost", "WebRtcAecmBatch_Synchronize", "WebRtcAecmBatch_GetLastLaunchMs",
+    "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
+    "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
+    "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DeviceInfo",
+]
+
+
+class AecmConfig(C.Structure):
+    _fields_ = [("cngMode", C.c_int16), ("echoMode", C.c_int16)]
+
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _build.LIB
+
+
+def load():
+    """Load the HIP library (building it first if the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    lib = C.CDLL(str(path))
+    vp, i16p = C.c_void_p, C.c_void_p
+    lib.WebRtcAecm_Create.restype = vp
+    lib.WebRtcAecm_Free.argtypes = [vp]
+    lib.WebRtcAecm_Free.restype = None
+    lib.WebRtcAecm_Init.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecm_BufferFarend.argtypes = [vp, i16p, C.c_size_t]
+    lib.WebRtcAecm_GetBufferFarendError.argtypes = [vp, i16p, C.c_size_t]
+    lib.WebRtcAecm_Process.argtypes = [vp, i16p, i16p, i16p, C.c_size_t, C.c_int16]
+    lib.WebRtcAecm_set_config.argtypes = [vp, AecmConfig]
+    lib.WebRtcAecm_InitEchoPath.argtypes = [vp, vp, C.c_size_t]
+    lib.WebRtcAecm_GetEchoPath.argtypes = [vp, vp, C.c_size_t]
+    lib.WebRtcAecm_echo_path_size_bytes.restype = C.c_size_t
+    lib.WebRtcAecmBatch_Create.restype = vp
+    lib.WebRtcAecmBatch_Create.argtypes = [C.c_int32, C.c_int32]
+    lib.WebRtcAecmBatch_Free.argtypes = [vp]
+    lib.WebRtcAecmBatch_Free.restype = None
+    lib.WebRtcAecmBatch_num_streams.argtypes = [vp]
+    lib.WebRtcAecmBatch_Init.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmBatch_set_config.argtypes = [vp, AecmConfig, C.c_int32, C.c_int32]
+    lib.WebRtcAecmBatch_Control.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.WebRtcAecmBatch_ProcessBlocks.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32]
+    lib.WebRtcAecmBatch_ProcessBlocksHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32]
+    lib.WebRtcAecmBatch_Synchronize.argtypes = [vp]
+    lib.WebRtcAecmBatch_GetLastLaunchMs.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.WebRtcAecmBatch_GetTimers.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.WebRtcAecmBatch_ResetTimers.argtypes = [vp]
+    lib.WebRtcAecmBatch_InitEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmBatch_GetEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmBatch_GetDigest.argtypes = [vp, C.c_int32, vp]
+    lib.WebRtcAecmBatch_SetKernelVariant.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
+    lib.WebRtcAecmBatch_DeviceInfo.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    _lib = lib
+    return lib
+
+
+def _i16(a):
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    return a, a.ctypes.data
+
+
+class AecmError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__(f"{where} returned {code}")
+        self.code = code
+
+
+class Aecm:
+    """One AECM session: the reference's WebRtcAecm_* interface, DSP on the GPU."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = self.lib.WebRtcAecm_Create()
+        if not self.h:
+            raise RuntimeError("WebRtcAecm_Create failed: the HIP engine needs a usable MI355X (no CPU fallback exists)")
+
+    def init(self, samp_freq: int) -> int:
+        return self.lib.WebRtcAecm_Init(self.h, samp_freq)
+
+    def set_config(self, cng_mode: int, echo_mode: int) -> int:
+        return self.lib.WebRtcAecm_set_config(self.h, AecmConfig(cng_mode, echo_mode))
+
+    def buffer_farend(self, farend) -> int:
+        a, p = _i16(farend)
+        return self.lib.WebRtcAecm_BufferFarend(self.h, p, a.size)
+
+    def process(self, nearend_noisy, nearend_clean=None, ms_in_snd_card_buf: int = 0):
+        """Returns (code, out)."""
+        a, p = _i16(nearend_noisy)
+        cp = None
+        if nearend_clean is not None:
+            c, cp = _i16(nearend_clean)
+        out = np.empty_like(a)
+        rc = self.lib.WebRtcAecm_Process(self.h, p, cp, out.ctypes.data, a.size, ms_in_snd_card_buf)
+        return rc, out
+
+    def init_echo_path(self, path) -> int:
+        a, p = _i16(path)
+        return self.lib.WebRtcAecm_InitEchoPath(self.h, p, a.nbytes)
+
+    def get_echo_path(self):
+        out = np.zeros(BINS, dtype=np.int16)
+        rc = self.lib.WebRtcAecm_GetEchoPath(self.h, out.ctypes.data, out.nbytes)
+        return rc, out
+
+    def run(self, far, near, frame: int, ms: int = 40):
+        """The reference CLI's loop (main.cc:105-143): BufferFarend + Process per `frame` samples."""
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        near = np.ascontiguousarray(near, dtype=np.int16).copy()
+        for i in range(near.size // frame):
+            sl = slice(i * frame, (i + 1) * frame)
+            rc = self.buffer_farend(far[sl])
+            if rc != 0:
+                raise AecmError(rc, "WebRtcAecm_BufferFarend")
+            rc, out = self.process(near[sl], None, ms)
+            if rc != 0:
+                raise AecmError(rc, "WebRtcAecm_Process")
+            near[sl] = out
+        return near
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.WebRtcAecm_Free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AecmBatch:
+    """S independent AECM block streams on one GPU (include/aecm_batch.h)."""
+
+    def __init__(self, num_streams: int, fs: int = 16000, cng_mode: int = 1, echo_mode: int = 3, device: int = 0,
+                 variant: int = KERNEL_FAST):
+        self.lib = load()
+        self.num_streams = num_streams
+        self.h = self.lib.WebRtcAecmBatch_Create(num_streams, device)
+        if not self.h:
+            raise RuntimeError("WebRtcAecmBatch_Create failed: the HIP engine needs a usable MI355X (no CPU fallback exists)")
+        self._check(self.lib.WebRtcAecmBatch_Init(self.h, fs), "Init")
+        self._check(self.lib.WebRtcAecmBatch_set_config(self.h, AecmConfig(cng_mode, echo_mode), 0, -1), "set_config")
+        self._check(self.lib.WebRtcAecmBatch_SetKernelVariant(self.h, variant), "SetKernelVariant")
+
+    @staticmethod
+    def _check(rc, where):
+        if rc != 0:
+            raise AecmError(rc, "WebRtcAecmBatch_" + where)
+
+    def set_config(self, cng_mode, echo_mode, first=0, count=-1):
+        self._check(self.lib.WebRtcAecmBatch_set_config(self.h, AecmConfig(cng_mode, echo_mode), first, count), "set_config")
+
+    def control(self, fixed_delay, nlp_flag, first=0, count=-1):
+        self._check(self.lib.WebRtcAecmBatch_Control(self.h, fixed_delay, nlp_flag, first, count), "Control")
+
+    def set_variant(self, variant):
+        self._check(self.lib.WebRtcAecmBatch_SetKernelVariant(self.h, variant), "SetKernelVariant")
+
+    def process_host(self, far, near, clean=None):
+        """far/near: [S, T*64] int16 host arrays (stream-major).  Returns out [S, T*64]."""
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        assert far.shape == near.shape and far.shape[0] == self.num_streams and far.shape[1] % BLOCK == 0
+        out = np.empty_like(near)
+        cp = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            cp = clean.ctypes.data
+        t = far.shape[1] // BLOCK
+        self._check(self.lib.WebRtcAecmBatch_ProcessBlocksHost(self.h, far.ctypes.data, near.ctypes.data, cp,
+                                                               out.ctypes.data, far.shape[1], BLOCK, t), "ProcessBlocksHost")
+        return out
+
+    def process_device(self, far_ptr, near_ptr, out_ptr, stream_stride, block_stride, num_blocks, clean_ptr=None):
+        """Device pointers (e.g. torch .data_ptr()); asynchronous on the engine's stream."""
+        self._check(self.lib.WebRtcAecmBatch_ProcessBlocks(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride,
+                                                           block_stride, num_blocks), "ProcessBlocks")
+
+    def synchronize(self):
+        self._check(self.lib.WebRtcAecmBatch_Synchronize(self.h), "Synchronize")
+
+    def last_launch_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.WebRtcAecmBatch_GetLastLaunchMs(self.h, C.byref(ms)), "GetLastLaunchMs")
+        return ms.value
+
+    def timers(self):
+        total, n = C.c_double(), C.c_int64()
+        self._check(self.lib.WebRtcAecmBatch_GetTimers(self.h, C.byref(total), C.byref(n)), "GetTimers")
+        return total.value, n.value
+
+    def reset_timers(self):
+        self._check(self.lib.WebRtcAecmBatch_ResetTimers(self.h), "ResetTimers")
+
+    def digest(self, stream: int):
+        d = np.zeros(DIGEST_WORDS, dtype=np.uint32)
+        self._check(self.lib.WebRtcAecmBatch_GetDigest(self.h, stream, d.ctypes.data), "GetDigest")
+        return d
+
+    def init_echo_path(self, stream, path):
+        a, p = _i16(path)
+        self._check(self.lib.WebRtcAecmBatch_InitEchoPath(self.h, stream, p, a.nbytes), "InitEchoPath")
+
+    def get_echo_path(self, stream):
+        out = np.zeros(BINS, dtype=np.int16)
+        self._check(self.lib.WebRtcAecmBatch_GetEchoPath(self.h, stream, out.ctypes.data, out.nbytes), "GetEchoPath")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.WebRtcAecmBatch_Free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def self_test(device: int = 0, exhaustive: bool = False):
+    """Device self test of the wave primitives; returns the 8 failure counters (all must be 0)."""
+    lib = load()
+    f = np.zeros(8, dtype=np.uint64)
+    rc = lib.WebRtcAecmBatch_SelfTest(device, 1 if exhaustive else 0, f.ctypes.data)
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_SelfTest")
+    return f
+
+
+def device_info(device: int = 0):
+    lib = load()
+    name = C.create_string_buffer(64)
+    cu, clk = C.c_int32(), C.c_int32()
+    rc = lib.WebRtcAecmBatch_DeviceInfo(device, name, 64, C.byref(cu), C.byref(clk))
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_DeviceInfo")
+    return name.value.decode(), cu.value, clk.value
