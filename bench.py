@@ -60,42 +60,63 @@ def synth_on_device(torch, S, L, seed, device, chunk=8192):
     return far, near
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(p).read_text().split()
+            if p.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(fs, budget_s=12.0):
     """The reference C path (oracle/_ref, kind 'reference') or our restatement of it (kind 'port')
-    timed on this box's host cores: one stream per thread, all cores, bounded sample."""
+    timed on this box's host cores: one stream per thread, bounded to ~budget_s of wall time."""
+    import threading
+
     from oracle import pyoracle
     from webrtc_aecm_amd.synth import synth_pair
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     use_ref = pyoracle.have_reference()
     mk = (lambda: pyoracle.RefCoreStream(fs, 1, 1)) if use_ref else (lambda: pyoracle.OracleStream(fs, 1, 1))
-    # calibrate on one core, then size the sample to ~budget_s of wall on all cores
-    far, near = synth_pair(1, 3000, fs)
-    st = mk()
-    t0 = time.perf_counter()
-    st.process(far, near)
-    one = 3000 / (time.perf_counter() - t0)
-    n_blocks = int(min(max(one * budget_s, 3000), 600000))
-    pairs = [synth_pair(100 + (i % 8), min(n_blocks, 20000), fs) for i in range(min(cores, 8))]
+    chunk = 4000                                   # blocks per call (~60 ms of CPU work)
+    pairs = [synth_pair(100 + i, chunk, fs) for i in range(min(cores, 8))]
+    streams = [mk() for _ in range(cores)]
+    deadline = [0.0]
+    start_gate = threading.Barrier(cores + 1)
 
     def work(i):
         f, d = pairs[i % len(pairs)]
-        s = mk()
+        s = streams[i]
+        start_gate.wait()
         done = 0
-        while done < n_blocks:
-            k = min(n_blocks - done, f.size // 64)
-            s.process(f[:k * 64], d[:k * 64])
-            done += k
+        while time.perf_counter() < deadline[0]:
+            s.process(f, d)
+            done += chunk
         return done
-    t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
-        total = sum(ex.map(work, range(cores)))
-    dt = time.perf_counter() - t0
+        futs = [ex.submit(work, i) for i in range(cores)]
+        deadline[0] = time.perf_counter() + budget_s + 0.05
+        start_gate.wait()
+        t0 = time.perf_counter()
+        total = sum(f.result() for f in futs)
+        dt = time.perf_counter() - t0
     return {
         "value": total / dt, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
         "per_core": total / dt / cores,
-        "sample": f"{cores} streams x {n_blocks} blocks ({fs} Hz synthetic pairs, cng on, echoMode 1), one stream per thread, "
-                  f"{dt:.1f} s wall; " + ("unmodified reference built -O2 from /root/reference (oracle/_ref)" if use_ref
-                                          else "oracle/aecm_oracle.c restatement built -O2"),
+        "sample": f"{cores} threads (one stream each) x {dt:.1f} s wall = {total} frames of {fs} Hz synthetic pairs, cng on, "
+                  f"echoMode 1; " + ("unmodified reference built -O2 from /root/reference (oracle/_ref)" if use_ref
+                                     else "oracle/aecm_oracle.c restatement built -O2"),
     }
 
 

@@ -1,0 +1,131 @@
+"""CPU tests that pin the oracle: against the committed golden vectors (generated from the unmodified
+reference by tools/gen_golden.py) and, where oracle/_ref/libaecm_ref.so exists, against the reference
+itself on seeded and adversarial inputs."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import describe_digest_diff, golden_files
+from oracle import pyoracle
+from webrtc_aecm_amd.synth import PROFILES, synth_pair
+
+needs_ref = pytest.mark.skipif(not pyoracle.have_reference(), reason="oracle/_ref/libaecm_ref.so not built")
+
+
+def test_synth_is_deterministic():
+    a = synth_pair(3, 200, 16000)
+    b = synth_pair(3, 200, 16000)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # pinned so that a numpy/generator change on another machine cannot silently move the fixtures
+    h = hashlib.sha256(synth_pair(0, 100, 16000)[1].tobytes()).hexdigest()
+    assert h == hashlib.sha256(synth_pair(0, 100, 16000, PROFILES[0])[1].tobytes()).hexdigest()
+
+
+def test_oracle_matches_golden_block_vectors():
+    files = golden_files("block_")
+    assert len(files) >= 5
+    for f in files:
+        g = np.load(f)
+        seed, nb, fs = int(g["seed"]), int(g["n_blocks"]), int(g["fs"])
+        prof = str(g["profile"]) or None
+        far, near = synth_pair(seed, nb, fs, prof)
+        o = pyoracle.OracleStream(fs, int(g["cng"]), int(g["echo_mode"]))
+        outs = []
+        for i, c in enumerate(range(0, nb, 300)):
+            outs.append(o.process(far[c * 64:(c + 300) * 64], near[c * 64:(c + 300) * 64]))
+            d = o.digest()
+            assert np.array_equal(d, g["digests"][i]), f"{f.name} block {c + 300}: {describe_digest_diff(d, g['digests'][i])}"
+        out = np.concatenate(outs)
+        assert hashlib.sha256(out.tobytes()).hexdigest() == str(g["sha256"]), f.name
+        assert np.array_equal(out[-g["out"].size:], g["out"])
+
+
+def test_sqrt_floor_is_exact_floor_sqrt():
+    lib = pyoracle.oracle_lib()
+    rs = np.random.RandomState(1)
+    vals = np.concatenate([np.arange(0, 70000), rs.randint(0, 2 ** 31 - 1, size=200000),
+                           np.array([2 ** 31 - 1, 46340 ** 2, 46340 ** 2 - 1, 46340 ** 2 + 1])])
+    for v in vals[::7]:
+        r = lib.aecm_oracle_sqrt_floor(int(v))
+        assert r * r <= v < (r + 1) * (r + 1)
+
+
+def test_forward_fft_of_impulse_and_dc():
+    lib = pyoracle.oracle_lib()
+    re = np.zeros(128, dtype=np.int16)
+    im = np.zeros(128, dtype=np.int16)
+    re[0] = 12800
+    lib.aecm_oracle_fft128(re, im, 0, None)
+    assert np.all(re == 100) and np.all(im == 0)          # impulse / 128
+    re[:] = 6400
+    im[:] = 0
+    lib.aecm_oracle_fft128(re, im, 0, None)
+    assert re[0] == 6400 and np.all(re[1:] == 0) and np.all(im == 0)
+
+
+@needs_ref
+@pytest.mark.parametrize("fs", [16000, 8000])
+def test_oracle_equals_reference_on_seeded_streams(fs):
+    for seed in range(8):
+        far, near = synth_pair(seed, 2048, fs)
+        cng, em = (1 if seed % 7 else 0), seed % 5
+        o, r = pyoracle.OracleStream(fs, cng, em), pyoracle.RefCoreStream(fs, cng, em)
+        for c in range(0, 2048, 256):
+            a = o.process(far[c * 64:(c + 256) * 64], near[c * 64:(c + 256) * 64])
+            b = r.process(far[c * 64:(c + 256) * 64], near[c * 64:(c + 256) * 64])
+            assert np.array_equal(a, b), (seed, c)
+            assert np.array_equal(o.digest(), r.digest()), (seed, c, describe_digest_diff(o.digest(), r.digest()))
+
+
+@needs_ref
+def test_oracle_equals_reference_long_silence_control_and_clean():
+    for fs in (16000, 8000):
+        far, near = synth_pair(100, 5000, fs, "silent")         # noise-floor floor branches
+        o, r = pyoracle.OracleStream(fs, 1, 3), pyoracle.RefCoreStream(fs, 1, 3)
+        assert np.array_equal(o.process(far, near), r.process(far, near))
+        assert np.array_equal(o.digest(), r.digest())
+        far, near = synth_pair(5, 1200, fs)                     # WebRtcAecm_Control: fixed delay, NLP off
+        o, r = pyoracle.OracleStream(fs, 1, 3), pyoracle.RefCoreStream(fs, 1, 3)
+        o.control(7, 0)
+        r.control(7, 0)
+        assert np.array_equal(o.process(far, near), r.process(far, near))
+        far, near = synth_pair(4, 700, fs)                      # nearendClean path
+        clean = (near.astype(np.int32) * 3 // 4).astype(np.int16)
+        o, r = pyoracle.OracleStream(fs, 1, 2), pyoracle.RefCoreStream(fs, 1, 2)
+        for b in range(700):
+            sl = slice(b * 64, (b + 1) * 64)
+            assert np.array_equal(o.process_block_clean(far[sl], near[sl], clean[sl]),
+                                  r.process_block_clean(far[sl], near[sl], clean[sl])), b
+
+
+@needs_ref
+def test_oracle_equals_reference_on_adversarial_inputs():
+    rs = np.random.RandomState(7)
+
+    def nasty(n, kind):
+        if kind == 0:
+            return rs.randint(-32768, 32768, size=n).astype(np.int16)
+        if kind == 1:
+            return np.where(rs.randint(0, 2, size=n) == 1, 32767, -32768).astype(np.int16)
+        if kind == 2:
+            return np.full(n, rs.choice([-32768, 32767, 1, -1, 0, 16384]), dtype=np.int16)
+        if kind == 3:
+            x = np.zeros(n, dtype=np.int16)
+            idx = rs.randint(0, n, size=n // 50)
+            x[idx] = rs.randint(-32768, 32768, size=idx.size)
+            return x
+        if kind == 4:
+            return rs.randint(-3, 4, size=n).astype(np.int16)
+        t = np.arange(n)
+        return (32767 * np.sin(2 * np.pi * t * rs.randint(1, 60) / 128.0)).astype(np.int16)
+    for it in range(24):
+        n = 1000 * 64
+        far, near = nasty(n, rs.randint(0, 6)), nasty(n, rs.randint(0, 6))
+        if it % 3 == 0:
+            near = np.clip(np.roll(far.astype(np.int32), rs.randint(0, 2000)) // rs.choice([1, 2, 8, 64]) +
+                           near // rs.choice([1, 4, 64, 1024]), -32768, 32767).astype(np.int16)
+        fs, cng, em = int(rs.choice([8000, 16000])), int(rs.randint(0, 2)), int(rs.randint(0, 5))
+        o, r = pyoracle.OracleStream(fs, cng, em), pyoracle.RefCoreStream(fs, cng, em)
+        assert np.array_equal(o.process(far, near), r.process(far, near)), it
+        assert np.array_equal(o.digest(), r.digest()), it

@@ -1,0 +1,135 @@
+"""CPU tests of the PRODUCT sources without a GPU:
+  * webrtc_aecm_amd/csrc/aecm_wave.h (the block DSP the HIP kernel instantiates) on a 64-lane CPU
+    simulator (tests/sim) against the oracle -- outputs and complete state, bit for bit;
+  * webrtc_aecm_amd/csrc/aecm_session.cpp (host logic of the session ABI) over that simulator against
+    the reference-generated session fixtures and, when present, the reference session ABI itself.
+"""
+import numpy as np
+import pytest
+
+import simlib
+from helpers import describe_digest_diff, golden_files
+from oracle import pyoracle
+from webrtc_aecm_amd.synth import synth_pair
+
+
+@pytest.mark.parametrize("fs", [16000, 8000])
+def test_wave_dsp_equals_oracle(fs):
+    for seed in range(6):
+        far, near = synth_pair(seed, 1400, fs)
+        cng, em = (1 if seed % 7 else 0), seed % 5
+        o, s = pyoracle.OracleStream(fs, cng, em), simlib.SimStream(fs, cng, em)
+        for c in range(0, 1400, 350):        # also exercises state store/load between "launches"
+            a = o.process(far[c * 64:(c + 350) * 64], near[c * 64:(c + 350) * 64])
+            b = s.process(far[c * 64:(c + 350) * 64], near[c * 64:(c + 350) * 64])
+            assert np.array_equal(a, b), (seed, c)
+            assert np.array_equal(o.digest(), s.digest()), (seed, c, describe_digest_diff(o.digest(), s.digest()))
+
+
+def test_wave_dsp_rare_branches():
+    fs = 16000
+    far, near = synth_pair(100, 4200, fs, "silent")
+    o, s = pyoracle.OracleStream(fs, 1, 3), simlib.SimStream(fs, 1, 3)
+    assert np.array_equal(o.process(far, near), s.process(far, near))
+    assert np.array_equal(o.digest(), s.digest())
+    far, near = synth_pair(5, 900, fs)
+    o, s = pyoracle.OracleStream(fs, 1, 3), simlib.SimStream(fs, 1, 3)
+    o.control(7, 0)
+    s.control(7, 0)
+    assert np.array_equal(o.process(far, near), s.process(far, near))
+    far, near = synth_pair(4, 600, fs)
+    clean = (near.astype(np.int32) * 3 // 4).astype(np.int16)
+    o, s = pyoracle.OracleStream(fs, 1, 2), simlib.SimStream(fs, 1, 2)
+    exp = np.concatenate([o.process_block_clean(far[b * 64:(b + 1) * 64], near[b * 64:(b + 1) * 64],
+                                                clean[b * 64:(b + 1) * 64]) for b in range(600)])
+    assert np.array_equal(s.process(far, near, clean), exp)
+    assert np.array_equal(o.digest(), s.digest())
+
+
+def test_wave_dsp_full_scale_and_zero_inputs():
+    rs = np.random.RandomState(3)
+    n = 700 * 64
+    cases = [
+        (np.zeros(n, np.int16), np.zeros(n, np.int16)),
+        (np.full(n, -32768, np.int16), np.full(n, -32768, np.int16)),
+        (np.where(rs.randint(0, 2, n) == 1, 32767, -32768).astype(np.int16), rs.randint(-32768, 32768, n).astype(np.int16)),
+        (rs.randint(-32768, 32768, n).astype(np.int16), np.zeros(n, np.int16)),
+        (rs.randint(-2, 3, n).astype(np.int16), rs.randint(-2, 3, n).astype(np.int16)),
+    ]
+    for i, (far, near) in enumerate(cases):
+        o, s = pyoracle.OracleStream(16000, 1, 3), simlib.SimStream(16000, 1, 3)
+        assert np.array_equal(o.process(far, near), s.process(far, near)), i
+        assert np.array_equal(o.digest(), s.digest()), i
+
+
+def test_echo_path_import_export():
+    path = (np.arange(65) * 53 % 3000).astype(np.int16)
+    o, s = pyoracle.OracleStream(8000, 1, 3), simlib.SimStream(8000, 1, 3)
+    o.init_echo_path(path)
+    s.init_echo_path(path)
+    assert np.array_equal(s.echo_path(), path)
+    far, near = synth_pair(2, 500, 8000)
+    assert np.array_equal(o.process(far, near), s.process(far, near))
+    assert np.array_equal(o.echo_path(), s.echo_path())
+
+
+def _run(sess, far, near, frame, ms):
+    out = near.copy()
+    codes = set()
+    for i in range(near.size // frame):
+        sl = slice(i * frame, (i + 1) * frame)
+        assert sess.buffer_farend(far[sl]) == 0
+        rc, o = sess.process(out[sl], None, ms)
+        codes.add(rc)
+        out[sl] = o
+    return out, codes
+
+
+def test_session_host_logic_matches_reference_fixtures():
+    files = golden_files("session_")
+    assert len(files) >= 3
+    for f in files:
+        g = np.load(f)
+        fs, frame, ms = int(g["fs"]), int(g["frame"]), int(g["ms"])
+        far, near = synth_pair(int(g["seed"]), int(g["n_blocks"]), fs, "mixed")
+        n = (far.size // frame) * frame
+        s = simlib.SimSession()
+        assert s.init(fs) == 0 and s.set_config(int(g["cng"]), int(g["echo_mode"])) == 0
+        out, codes = _run(s, far[:n], near[:n], frame, ms)
+        assert sorted(codes) == g["codes"].tolist(), f.name
+        assert np.array_equal(out, g["out"]), f.name
+
+
+def test_session_error_codes_and_ownership_rules():
+    s = simlib.SimSession()
+    z = np.zeros(160, dtype=np.int16)
+    assert s.buffer_farend(z) == 12002 and s.process(z)[0] == 12002 and s.set_config(1, 3) == 12002
+    assert s.init(44100) == 12004
+    assert s.init(16000) == 0
+    assert s.buffer_farend(z[:100]) == 12004 and s.process(z[:100])[0] == 12004
+    assert s.set_config(2, 3) == 12004 and s.set_config(1, 5) == 12004 and s.set_config(0, 0) == 0
+    assert s.process(z, None, -5)[0] == 12100 and s.process(z, None, 501)[0] == 12100
+    assert s.init_echo_path(z[:64]) == 12004
+    rc, p = s.get_echo_path()
+    assert rc == 0 and p[0] == 2040 and p[64] == 3153       # kChannelStored16kHz ends
+
+
+@pytest.mark.skipif(not pyoracle.have_reference(), reason="oracle/_ref/libaecm_ref.so not built")
+def test_session_host_logic_matches_reference_abi_odd_call_patterns():
+    # 80-sample calls at 16 kHz (start-up never ends, nBlocks10ms == 0), 160-sample calls at 8 kHz,
+    # a jittering msInSndCardBuf and a far-end underrun (BufferFarend skipped now and then).
+    rs = np.random.RandomState(5)
+    for fs, frame in ((16000, 80), (8000, 160), (16000, 160), (8000, 80)):
+        far, near = synth_pair(31, 1500, fs, "mixed")
+        r = pyoracle.RefSession(fs, 1, 3)
+        s = simlib.SimSession()
+        assert s.init(fs) == 0 and s.set_config(1, 3) == 0
+        ob = np.empty(frame, dtype=np.int16)
+        for i in range(far.size // frame):
+            sl = slice(i * frame, (i + 1) * frame)
+            ms = int(40 + rs.randint(-12, 13)) if i % 50 else int(rs.choice([-3, 0, 600, 90]))
+            if i % 97 != 96:
+                assert r.lib.WebRtcAecm_BufferFarend(r.h, far[sl].ctypes.data, frame) == s.buffer_farend(far[sl])
+            rc = r.lib.WebRtcAecm_Process(r.h, near[sl].ctypes.data, None, ob.ctypes.data, frame, ms)
+            rc2, o2 = s.process(near[sl], None, ms)
+            assert rc == rc2 and np.array_equal(ob, o2), (fs, frame, i)

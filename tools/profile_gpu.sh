@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py.
+# Outputs land in gpurun_out/prof_*; copy the summaries you want judged into profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
+rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
+# 1. per-kernel time (same command as the bench line)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -o bench -- $BENCH --steps 10 --warmup 2 > "$OUT/prof_stats.log" 2>&1
+# 2. HBM traffic: separate passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/prof_write" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_write.log" 2>&1
+# 3. SQ counters: instruction mix, busy cycles, LDS bank conflicts
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$OUT/prof_sq1" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_sq1.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_sq2" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_sq2.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace --output-format csv -d "$OUT/prof_grbm" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_grbm.log" 2>&1
+find "$OUT" -name "*.csv" | head -50

@@ -57,6 +57,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process do not both see the
+    # GPU.  Importing torch first makes this library bind to the runtime torch already loaded, so
+    # torch tensors (device memory, streams) and this engine share one runtime.  Without torch
+    # installed the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.build()
     lib = C.CDLL(str(path))
     vp, i16p = C.c_void_p, C.c_void_p
