@@ -47,6 +47,8 @@ SIM_BIN(imin, imin(x, y))
 SIM_BIN(imax, imax(x, y))
 SIM_BIN(divi, divi(x, y))
 SIM_BIN(divu, divu(x, y))
+SIM_BIN(pack_hi16, pack_hi16(x, y))
+SIM_BIN(pk_max_i16, pk_max_i16(x, y))
 #undef SIM_BIN
 
 #define SIM_UN(NAME, EXPR)                                                    \
@@ -62,6 +64,8 @@ SIM_UN(zext16, zext16(x))
 SIM_UN(iabs, iabs(x))
 SIM_UN(clz32, clz32(x))
 SIM_UN(popc, popc(x))
+SIM_UN(pk_abs_sat_i16, pk_abs_sat_i16(x))
+SIM_UN(max_halves_i16, max_halves_i16(x))
 #undef SIM_UN
 
 #define SIM_CMP(NAME, EXPR)                                                   \
@@ -91,6 +95,11 @@ SIM_MASK(operator|, x || y)
 SIM_MASK(operator==, x == y)
 SIM_MASK(operator!=, x != y)
 #undef SIM_MASK
+inline VecI dot2_i16(const VecI &a, const VecI &b, const VecI &c) {
+    VecI r;
+    for (int i = 0; i < 64; ++i) r.v[i] = dot2_i16(a.v[i], b.v[i], c.v[i]);
+    return r;
+}
 inline VecB operator!(const VecB &a) { VecB r; for (int i = 0; i < 64; ++i) r.v[i] = !a.v[i]; return r; }
 inline VecB operator&(const VecB &a, bool b) { VecB r; for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] && b; return r; }
 inline VecB operator&(bool b, const VecB &a) { return a & b; }

@@ -26,8 +26,12 @@ __device__ __forceinline__ void FillLdsTables() {
     __syncthreads();
 }
 
+#ifndef AECM_WAVES_PER_EU
+#define AECM_WAVES_PER_EU 5
+#endif
 template <bool kFast, bool kHasClean>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup) void aecm_process_kernel(StatePtrs st, IoView io, int n_streams,
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
+void aecm_process_kernel(StatePtrs st, IoView io, int n_streams,
                                                                               int n_blocks) {
     FillLdsTables();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -155,6 +159,20 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
             if (F::readlane(v, sel_lane) != __shfl(v, sel_lane)) bump(4);
             const int wl = F::writelane(v, 424242, sel_lane);
             if (wl != (lane == sel_lane ? 424242 : v)) bump(4);
+            // 4 (cont.): packed-int16 primitives against their portable definitions
+            {
+                const int x = v, y = w, c = (int)Mix(gid ^ 0x9e3779b9u);
+                const int ed = add(add(mul(sext16(x), sext16(y)), mul(sar(x, 16), sar(y, 16))), c);
+                if (dot2_i16(x, y, c) != ed) bump(4);
+                if (pack_hi16(x, y) != (int)(((unsigned)x >> 16) | ((unsigned)y & 0xffff0000u))) bump(4);
+                int lo = sext16(x), hi = sar(x, 16);
+                lo = lo < 0 ? (lo == -32768 ? 32767 : -lo) : lo;
+                hi = hi < 0 ? (hi == -32768 ? 32767 : -hi) : hi;
+                if (pk_abs_sat_i16(x) != ((lo & 0xffff) | (int)((unsigned)hi << 16))) bump(4);
+                if (pk_abs_sat_i16((int)0x80008000) != 0x7fff7fff) bump(4);
+                const int ml = imax(sext16(x), sext16(y)), mh = imax(sar(x, 16), sar(y, 16));
+                if (pk_max_i16(x, y) != ((ml & 0xffff) | (int)((unsigned)mh << 16))) bump(4);
+            }
             // 5: ballot bit order
             const bool p = (v >> 3) & 1;
             const uint64_t bal = F::ballot(p);

@@ -47,6 +47,52 @@ AECM_HD int divi(int a, int b) {
 }
 AECM_HD int divu(int a, int b) { return b == 0 ? -1 : (int)((unsigned)a / (unsigned)b); }
 
+// ---- packed-int16 primitives (a 32-bit word holds lo | hi<<16) -------------------------------------
+// Each has an exact portable definition; on gfx950 the same function is a single instruction.
+// sext(a.lo)*sext(b.lo) + sext(a.hi)*sext(b.hi) + c  (wrapping)              -> v_dot2_i32_i16
+AECM_HD int dot2_i16(int a, int b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short aecm_short2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(aecm_short2, a), __builtin_bit_cast(aecm_short2, b), c, false);
+#else
+    return add(add(mul(sext16(a), sext16(b)), mul(sar(a, 16), sar(b, 16))), c);
+#endif
+}
+// (upper half of yr) | (upper half of yi) << 16                              -> v_perm_b32
+AECM_HD int pack_hi16(int yr, int yi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__builtin_amdgcn_perm((unsigned)yi, (unsigned)yr, 0x07060302u);
+#else
+    return (int)(((unsigned)yr >> 16) | ((unsigned)yi & 0xffff0000u));
+#endif
+}
+// per half: |x| with |-32768| saturated to 32767                             -> v_pk_sub_i16 clamp + v_pk_max_i16
+AECM_HD int pk_abs_sat_i16(int a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short aecm_short2 __attribute__((ext_vector_type(2)));
+    aecm_short2 v = __builtin_bit_cast(aecm_short2, a);
+    aecm_short2 n = __builtin_elementwise_sub_sat((aecm_short2){0, 0}, v);
+    return __builtin_bit_cast(int, __builtin_elementwise_max(v, n));
+#else
+    int lo = sext16(a), hi = sar(a, 16);
+    lo = lo < 0 ? (lo == -32768 ? 32767 : -lo) : lo;
+    hi = hi < 0 ? (hi == -32768 ? 32767 : -hi) : hi;
+    return (lo & 0xffff) | (int)((unsigned)hi << 16);
+#endif
+}
+// per half signed max                                                        -> v_pk_max_i16
+AECM_HD int pk_max_i16(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short aecm_short2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(aecm_short2, a), __builtin_bit_cast(aecm_short2, b)));
+#else
+    int lo = imax(sext16(a), sext16(b)), hi = imax(sar(a, 16), sar(b, 16));
+    return (lo & 0xffff) | (int)((unsigned)hi << 16);
+#endif
+}
+// max(sext(lo), sext(hi))
+AECM_HD int max_halves_i16(int a) { return imax(sext16(a), sar(a, 16)); }
+
 // ---- generic (scalar or lane-vector) helpers built on the overload set above --------------------
 template <class I> AECM_HD I norm_u32(I a) { return sel(a == 0, I(0), clz32(a)); }
 template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 1); }

@@ -127,6 +127,17 @@ struct BlockEngine {
 
     // a = packed (re,im) of the butterfly's upper operand (position i), b = lower (position i+l).
     // Returns the sum of the per-stage shifts (inverse only; the reference's return value "scale").
+    //
+    // One butterfly of the reference (complex_fft.c:332-350 forward, :465-482 inverse):
+    //     T  = wr*x_b - wi*y_b + 1          (likewise for the imaginary part)
+    //     t  = T >> 1
+    //     out = (int16)((x_a * 2^14 +- t + rnd) >> sh)    fwd: rnd = 2^14, sh = 15
+    //                                                     inv: rnd = 2^13 << shift, sh = 14 + shift
+    // i.e. out = bits [sh+15 : sh] of the 32-bit sum.  Multiplying the sum by 2^(16-sh) moves those
+    // bits into the upper half of a 32-bit word, and multiplication is exact modulo 2^32:
+    //     Y = (x_a << (30 - sh)) +- ((T >> 1) << (16 - sh)) + 2^15        out = upper half of Y
+    // so the four narrowing shifts and the re-packing of a stage collapse into two byte permutes,
+    // and T is one v_dot2_i32_i16 on the packed operand with packed twiddles (wr,-wi) / (wi,wr).
     template <bool kInverse>
     static AECM_HD int fft128(const Regs &r, vi &a, vi &b) {
         int scale = 0;
@@ -135,27 +146,27 @@ struct BlockEngine {
 #define AECM_FFT_STAGE(S)                                                                          \
         {                                                                                          \
             if (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);                            \
-            vi ar = lo16(a), ai = hi16(a), br = lo16(b), bi = hi16(b);                             \
-            int shift = 0, round2 = 8192;                                                          \
+            int shift = 0;                                                                         \
             if (kInverse) { /* complex_fft.c:382-396: data-dependent scaling per stage */          \
-                vi m = imax(imax(iabs(ar), iabs(ai)), imax(iabs(br), iabs(bi)));                   \
-                int mx = imin(W::reduce_max(m), 32767);                                            \
-                if (mx > 13573) { shift++; scale++; round2 <<= 1; }                                \
-                if (mx > 27146) { shift++; scale++; round2 <<= 1; }                                \
+                vi m = max_halves_i16(pk_max_i16(pk_abs_sat_i16(a), pk_abs_sat_i16(b)));           \
+                int mx = W::reduce_max(m);        /* |-32768| already saturated to 32767 */        \
+                if (mx > 13573) { shift++; scale++; }                                              \
+                if (mx > 27146) { shift++; scale++; }                                              \
             }                                                                                      \
             /* twiddle index m << k with m = position & (2^S - 1), k = 9 - S, in units of 8 */     \
             vi tw = shl(r.brev & vi((1 << S) - 1), 6 - S);                                         \
             vi wr = W::twiddle_cos(tw);                                                            \
             vi wi = kInverse ? W::twiddle_sin(tw) : neg(W::twiddle_sin(tw));                       \
-            vi tr = sar(sub(mul(wr, br), mul(wi, bi)) + 1, 1);       /* :332-338 / :465-469 */     \
-            vi ti = sar(add(mul(wr, bi), mul(wi, br)) + 1, 1);                                     \
-            vi qr = shl(ar, 14), qi = shl(ai, 14);                                                 \
-            int rnd = kInverse ? round2 : 16384;                                                   \
-            int sh = kInverse ? shift + 14 : 15;                                                   \
-            vi nbr = sar(sub(qr, tr) + rnd, sh), nbi = sar(sub(qi, ti) + rnd, sh);                 \
-            vi nar = sar(add(qr, tr) + rnd, sh), nai = sar(add(qi, ti) + rnd, sh);                 \
-            a = pack(nar, nai);                                                                    \
-            b = pack(nbr, nbi);                                                                    \
+            vi w_re = pack(wr, neg(wi)), w_im = pack(wi, wr);                                      \
+            vi t_re = dot2_i16(b, w_re, vi(1));              /* wr*x_b - wi*y_b + 1 */             \
+            vi t_im = dot2_i16(b, w_im, vi(1));              /* wi*x_b + wr*y_b + 1 */             \
+            const int up = kInverse ? 2 - shift : 1;         /* 16 - sh */                         \
+            t_re = shl(sar(t_re, 1), up);                                                          \
+            t_im = shl(sar(t_im, 1), up);                                                          \
+            vi base_re = shl(lo16(a), 14 + up) + 32768;                                            \
+            vi base_im = shl(hi16(a), 14 + up) + 32768;                                            \
+            a = pack_hi16(add(base_re, t_re), add(base_im, t_im));                                 \
+            b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));                                 \
         }
         AECM_FFT_STAGE(0) AECM_FFT_STAGE(1) AECM_FFT_STAGE(2) AECM_FFT_STAGE(3)
         AECM_FFT_STAGE(4) AECM_FFT_STAGE(5) AECM_FFT_STAGE(6)

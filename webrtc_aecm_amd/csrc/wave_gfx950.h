@@ -37,7 +37,9 @@ enum : int {
     kDppRowRor8 = 0x128,       // dst[i] = src[(i+8) mod 16]  == xor 8
     kDppWaveShr1 = 0x138,      // dst[i] = src[i-1] across the whole wave
     kDppRowMirror = 0x140,     // dst[i] = src[15-i]
-    kDppRowHalfMirror = 0x141  // dst[i] = src[7-i] within 8
+    kDppRowHalfMirror = 0x141, // dst[i] = src[7-i] within 8
+    kDppRowBcast15 = 0x142,    // lane 15 of each row -> every lane of the next row
+    kDppRowBcast31 = 0x143     // lane 31 -> every lane of rows 2 and 3
 };
 
 template <bool kFast>
@@ -75,7 +77,8 @@ struct Gfx950Wave {
         }
     }
 
-    // Re-pair FFT operands across lane bit Q (see tests/sim/wave_sim.h for the definition).
+    // Re-pair FFT operands across lane bit Q (see tests/sim/wave_sim.h for the definition):
+    //   lanes with bit Q clear: a stays, b <- partner's a;   lanes with bit Q set: b stays, a <- partner's b.
     template <int Q>
     static __device__ __forceinline__ void exchange(int &a, int &b) {
         if constexpr (kFast && Q == 5) {
@@ -86,26 +89,45 @@ struct Gfx950Wave {
             auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
             a = (int)r[0];
             b = (int)r[1];
+        } else if constexpr (kFast && Q == 3) {
+            // bank = lane[3:2]; bit 3 set <=> banks 2,3.  DPP writes only the enabled banks, the rest keep `old`.
+            const int na = AECM_DPP(a, b, kDppRowRor8, 0xf, 0xc, false);
+            const int nb = AECM_DPP(b, a, kDppRowRor8, 0xf, 0x3, false);
+            a = na;
+            b = nb;
+        } else if constexpr (kFast && Q == 2) {
+            const int na = AECM_DPP(a, b, kDppRowShr4, 0xf, 0xa, false);   // banks 1,3 <- b of lane-4
+            const int nb = AECM_DPP(b, a, kDppRowShl4, 0xf, 0x5, false);   // banks 0,2 <- a of lane+4
+            a = na;
+            b = nb;
+        } else if constexpr (kFast) {
+            const bool hi = (lane_id() >> Q) & 1;
+            const int pb = AECM_DPP(b, b, Q == 0 ? kDppQuadXor1 : kDppQuadXor2, 0xf, 0xf, false);
+            const int pa = AECM_DPP(a, a, Q == 0 ? kDppQuadXor1 : kDppQuadXor2, 0xf, 0xf, false);
+            a = hi ? pb : a;
+            b = hi ? b : pa;
         } else {
             const bool hi = (lane_id() >> Q) & 1;
             int send = hi ? a : b;
-            int recv = shfl_xor<(1 << Q)>(send);
+            int recv = __shfl_xor(send, 1 << Q);
             if (hi) a = recv;
             else b = recv;
         }
     }
 
-    // ---- reductions: all lanes of a 16-lane row get the row result, then 4 readlanes ----
+    // ---- reductions: every lane of a 16-lane row gets the row result (4 DPP steps), then the rows are
+    // chained with row_bcast15 / row_bcast31 into lane 63 and read back with one v_readlane.
+    // `identity` is what lanes not written by a masked DPP step see (op(v, identity) == v).
     template <class Op>
-    static __device__ __forceinline__ int reduce(int v, Op op) {
+    static __device__ __forceinline__ int reduce(int v, int identity, Op op) {
         if constexpr (kFast) {
             v = op(v, AECM_DPP(v, v, kDppQuadXor1, 0xf, 0xf, false));
             v = op(v, AECM_DPP(v, v, kDppQuadXor2, 0xf, 0xf, false));
             v = op(v, AECM_DPP(v, v, kDppRowHalfMirror, 0xf, 0xf, false));
             v = op(v, AECM_DPP(v, v, kDppRowMirror, 0xf, 0xf, false));
-            int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-            int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-            return op(op(r0, r1), op(r2, r3));
+            v = op(v, AECM_DPP(identity, v, kDppRowBcast15, 0xa, 0xf, false));   // rows 1,3 += rows 0,2
+            v = op(v, AECM_DPP(identity, v, kDppRowBcast31, 0xc, 0xf, false));   // rows 2,3 += rows 0+1
+            return __builtin_amdgcn_readlane(v, 63);
         } else {
             v = op(v, __shfl_xor(v, 1));
             v = op(v, __shfl_xor(v, 2));
@@ -116,9 +138,9 @@ struct Gfx950Wave {
             return __builtin_amdgcn_readfirstlane(v);
         }
     }
-    static __device__ __forceinline__ int reduce_max(int v) { return reduce(v, [](int a, int b) { return a > b ? a : b; }); }
-    static __device__ __forceinline__ int reduce_min(int v) { return reduce(v, [](int a, int b) { return a < b ? a : b; }); }
-    static __device__ __forceinline__ int reduce_add(int v) { return reduce(v, [](int a, int b) { return add(a, b); }); }
+    static __device__ __forceinline__ int reduce_max(int v) { return reduce(v, (int)0x80000000, [](int a, int b) { return a > b ? a : b; }); }
+    static __device__ __forceinline__ int reduce_min(int v) { return reduce(v, 0x7fffffff, [](int a, int b) { return a < b ? a : b; }); }
+    static __device__ __forceinline__ int reduce_add(int v) { return reduce(v, 0, [](int a, int b) { return add(a, b); }); }
 
     static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
     static __device__ __forceinline__ int readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

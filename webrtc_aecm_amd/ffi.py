@@ -8,6 +8,7 @@ implementation of the DSP here: without the HIP library and a GPU these classes 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -65,7 +66,8 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = _build.build()
+    # AECM_LIB_PATH: load a specific prebuilt library (kernel A/B experiments) instead of (re)building.
+    path = os.environ.get("AECM_LIB_PATH") or _build.build()
     lib = C.CDLL(str(path))
     vp, i16p = C.c_void_p, C.c_void_p
     lib.WebRtcAecm_Create.restype = vp
