@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
     }
     // edge values
     if (gid == 0) {
-        const unsigned edges[6] = {0u, 1u, 0x7fffffffu, 0x7ffea810u /*46340^2*/, 0x7ffea80fu, 0x40000000u};
-        for (int k = 0; k < 6; ++k) {
+        const unsigned edges[7] = {0u, 1u, 0x7fffffffu, 0x7ffea810u /*46340^2*/, 0x7ffea80fu, 0x40000000u, 0x80000000u};
+        for (int k = 0; k < 7; ++k) {
             const uint64_t r = (unsigned)F::isqrt31((int)edges[k]);
             if (r * r > edges[k] || (r + 1) * (r + 1) <= edges[k]) bump(6);
         }

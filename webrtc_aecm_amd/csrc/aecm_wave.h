@@ -138,35 +138,56 @@ struct BlockEngine {
     //     Y = (x_a << (30 - sh)) +- ((T >> 1) << (16 - sh)) + 2^15        out = upper half of Y
     // so the four narrowing shifts and the re-packing of a stage collapse into two byte permutes,
     // and T is one v_dot2_i32_i16 on the packed operand with packed twiddles (wr,-wi) / (wi,wr).
-    template <bool kInverse>
+    // kRealInput: the imaginary parts of a and b are known to be zero on entry (forward transform of
+    // a real signal, real_fft.c:59-65), which lets stage 0 (twiddle = (32767, 0)) skip half its work.
+    template <bool kInverse, bool kRealInput>
     static AECM_HD int fft128(const Regs &r, vi &a, vi &b) {
         int scale = 0;
         // stage s pairs positions differing in bit s; the operands of stage s>0 are brought
         // together by exchanging on lane bit (6 - s).
 #define AECM_FFT_STAGE(S)                                                                          \
-        {                                                                                          \
+        if (S == 0 && kRealInput && !kInverse) {                                                   \
+            /* T_re = 32767*x_b + 1, T_im = 1 -> (T_im >> 1) << 1 = 0: imaginary outputs are 0 */  \
+            vi acc = add(mul(vi(32767), lo16(b)), shl(lo16(a), 15) + 32769);                       \
+            vi yp = acc & ~1;                                                                      \
+            vi ym = sub(shl(a, 16) + 65536, yp);                                                   \
+            a = lsr(yp, 16);                                                                       \
+            b = lsr(ym, 16);                                                                       \
+        } else {                                                                                   \
             if (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);                            \
-            int shift = 0;                                                                         \
+            int shift = 1;                                                                         \
             if (kInverse) { /* complex_fft.c:382-396: data-dependent scaling per stage */          \
                 vi m = max_halves_i16(pk_max_i16(pk_abs_sat_i16(a), pk_abs_sat_i16(b)));           \
                 int mx = W::reduce_max(m);        /* |-32768| already saturated to 32767 */        \
-                if (mx > 13573) { shift++; scale++; }                                              \
-                if (mx > 27146) { shift++; scale++; }                                              \
+                shift = lsr(13573 - mx, 31) + lsr(27146 - mx, 31);   /* sign bits; mx <= 32767 */  \
+                scale += shift;                                                                    \
             }                                                                                      \
             /* twiddle index m << k with m = position & (2^S - 1), k = 9 - S, in units of 8 */     \
             vi tw = shl(r.brev & vi((1 << S) - 1), 6 - S);                                         \
             vi wr = W::twiddle_cos(tw);                                                            \
             vi wi = kInverse ? W::twiddle_sin(tw) : neg(W::twiddle_sin(tw));                       \
             vi w_re = pack(wr, neg(wi)), w_im = pack(wi, wr);                                      \
-            vi t_re = dot2_i16(b, w_re, vi(1));              /* wr*x_b - wi*y_b + 1 */             \
-            vi t_im = dot2_i16(b, w_im, vi(1));              /* wi*x_b + wr*y_b + 1 */             \
-            const int up = kInverse ? 2 - shift : 1;         /* 16 - sh */                         \
-            t_re = shl(sar(t_re, 1), up);                                                          \
-            t_im = shl(sar(t_im, 1), up);                                                          \
-            vi base_re = shl(lo16(a), 14 + up) + 32768;                                            \
-            vi base_im = shl(hi16(a), 14 + up) + 32768;                                            \
-            a = pack_hi16(add(base_re, t_re), add(base_im, t_im));                                 \
-            b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));                                 \
+            if (shift == 1) {                                                                      \
+                /* sh = 15: Y = base + ((T >> 1) << 1) = (base + T) & ~1 because base is even, so  \
+                   the dot product accumulates straight onto base + 1; Y- = 2*base - Y+ */         \
+                vi acc_re = dot2_i16(b, w_re, shl(lo16(a), 15) + 32769);                           \
+                vi acc_im = dot2_i16(b, w_im, shl(hi16(a), 15) + 32769);                           \
+                vi yp_re = acc_re & ~1, yp_im = acc_im & ~1;                                       \
+                vi ym_re = sub(shl(a, 16) + 65536, yp_re);                                         \
+                vi ym_im = sub((a & (int)0xffff0000) + 65536, yp_im);                              \
+                a = pack_hi16(yp_re, yp_im);                                                       \
+                b = pack_hi16(ym_re, ym_im);                                                       \
+            } else {                                                                               \
+                vi t_re = dot2_i16(b, w_re, vi(1));          /* wr*x_b - wi*y_b + 1 */             \
+                vi t_im = dot2_i16(b, w_im, vi(1));          /* wi*x_b + wr*y_b + 1 */             \
+                const int up = 2 - shift;                    /* 16 - sh */                         \
+                t_re = shl(sar(t_re, 1), up);                                                      \
+                t_im = shl(sar(t_im, 1), up);                                                      \
+                vi base_re = shl(lo16(a), 14 + up) + 32768;                                        \
+                vi base_im = shl(hi16(a), 14 + up) + 32768;                                        \
+                a = pack_hi16(add(base_re, t_re), add(base_im, t_im));                             \
+                b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));                             \
+            }                                                                                      \
         }
         AECM_FFT_STAGE(0) AECM_FFT_STAGE(1) AECM_FFT_STAGE(2) AECM_FFT_STAGE(3)
         AECM_FFT_STAGE(4) AECM_FFT_STAGE(5) AECM_FFT_STAGE(6)
@@ -184,8 +205,8 @@ struct BlockEngine {
         // window (:174-182): scale, truncate to int16, multiply by sqrt-Hanning Q14, truncate
         vi wo = sext16(sar(mul(sext16(shl(old_s, q)), r.hann_lo), 14));
         vi wn = sext16(sar(mul(sext16(shl(new_s, q)), r.hann_hi), 14));
-        vi a = pack(wo, vi(0)), b = pack(wn, vi(0));        // imaginary input is zero (real_fft.c:59-65)
-        fft128<false>(r, a, b);
+        vi a = zext16(wo), b = zext16(wn);                  // packed (re, 0): imaginary input is zero (real_fft.c:59-65)
+        fft128<false, true>(r, a, b);
         // lane t now holds X[bitrev6(t)] in a and X[bitrev6(t)+64] in b
         int x64 = W::readlane(b, 0);
         vi x = W::bpermute(a, r.brev);                      // bin t -> lane t
@@ -195,12 +216,12 @@ struct BlockEngine {
         sp.re = re;
         sp.im = im;
         sp.re64 = sext16(x64);                              // bin 64: imag forced to 0 (:297)
-        // magnitudes (:298-362, AECM_WITH_ABS_APPROX off)
-        vi ar = iabs(re), ai = iabs(im);                    // 32768 for -32768
-        vi sq = add(mul(ar, ar), mul(ai, ai));              // <= 2^31 as unsigned
-        sq = sel(gtu(sq, vi(0x7fffffff)), vi(0x7fffffff), sq);   // AddSatW32 (:354)
-        vi mag = sel(re == 0, ai, sel(im == 0, ar, W::isqrt31(sq)));
-        sp.mag = zext16(mag);
+        // magnitudes (:298-362, AECM_WITH_ABS_APPROX off).  The reference special-cases re == 0 /
+        // im == 0 (|.| of the other part) and saturates re^2+im^2 at 2^31-1; both are subsumed by an
+        // exact floor(sqrt) on the unsigned sum: floor(sqrt(x^2)) == |x|, and the only sum above
+        // 2^31-1 is 2^31 (re = im = -32768), whose floor-sqrt 46340 equals that of 2^31-1.
+        vi sq = add(mul(re, re), mul(im, im));              // <= 2^31 as unsigned
+        sp.mag = W::isqrt31(sq);                            // <= 46340 < 2^16
         sp.mag64 = zext16(iabs(sp.re64));
         sp.sum = add(W::reduce_add(sp.mag), sp.mag64);
         sp.q = q;
@@ -711,7 +732,7 @@ struct BlockEngine {
         int y64 = zext16(e_re64) | shl(sext16(neg(e_im64)), 16);
         vi a = y;
         vi b = sel(r.lane == 0, vi(y64), mirrored);
-        const int out_cfft = fft128<true>(r, a, b);
+        const int out_cfft = fft128<true, false>(r, a, b);
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
         vi first = sext16(sar(mul(lo16(a), r.hann_syn_lo) + 8192, 14));               // :219-221

@@ -64,14 +64,14 @@ struct Gfx950Wave {
         if constexpr (!kFast) {
             return __shfl_xor(v, M);
         } else if constexpr (M == 1) {
-            return AECM_DPP(v, v, kDppQuadXor1, 0xf, 0xf, false);
+            return AECM_DPP(0, v, kDppQuadXor1, 0xf, 0xf, true);
         } else if constexpr (M == 2) {
-            return AECM_DPP(v, v, kDppQuadXor2, 0xf, 0xf, false);
+            return AECM_DPP(0, v, kDppQuadXor2, 0xf, 0xf, true);
         } else if constexpr (M == 4) {
             int t = AECM_DPP(v, v, kDppRowShl4, 0xf, 0x5, false);   // banks 0,2 (bit 2 clear) <- lane+4
             return AECM_DPP(t, v, kDppRowShr4, 0xf, 0xa, false);    // banks 1,3 (bit 2 set)   <- lane-4
         } else if constexpr (M == 8) {
-            return AECM_DPP(v, v, kDppRowRor8, 0xf, 0xf, false);
+            return AECM_DPP(0, v, kDppRowRor8, 0xf, 0xf, true);
         } else {
             return __shfl_xor(v, M);
         }
@@ -102,8 +102,8 @@ struct Gfx950Wave {
             b = nb;
         } else if constexpr (kFast) {
             const bool hi = (lane_id() >> Q) & 1;
-            const int pb = AECM_DPP(b, b, Q == 0 ? kDppQuadXor1 : kDppQuadXor2, 0xf, 0xf, false);
-            const int pa = AECM_DPP(a, a, Q == 0 ? kDppQuadXor1 : kDppQuadXor2, 0xf, 0xf, false);
+            const int pb = AECM_DPP(0, b, Q == 0 ? kDppQuadXor1 : kDppQuadXor2, 0xf, 0xf, true);
+            const int pa = AECM_DPP(0, a, Q == 0 ? kDppQuadXor1 : kDppQuadXor2, 0xf, 0xf, true);
             a = hi ? pb : a;
             b = hi ? b : pa;
         } else {
@@ -121,10 +121,11 @@ struct Gfx950Wave {
     template <class Op>
     static __device__ __forceinline__ int reduce(int v, int identity, Op op) {
         if constexpr (kFast) {
-            v = op(v, AECM_DPP(v, v, kDppQuadXor1, 0xf, 0xf, false));
-            v = op(v, AECM_DPP(v, v, kDppQuadXor2, 0xf, 0xf, false));
-            v = op(v, AECM_DPP(v, v, kDppRowHalfMirror, 0xf, 0xf, false));
-            v = op(v, AECM_DPP(v, v, kDppRowMirror, 0xf, 0xf, false));
+            // full masks + valid source lanes: `old` is dead, bound_ctrl:1 lets the DPP fold into the op
+            v = op(v, AECM_DPP(identity, v, kDppQuadXor1, 0xf, 0xf, true));
+            v = op(v, AECM_DPP(identity, v, kDppQuadXor2, 0xf, 0xf, true));
+            v = op(v, AECM_DPP(identity, v, kDppRowHalfMirror, 0xf, 0xf, true));
+            v = op(v, AECM_DPP(identity, v, kDppRowMirror, 0xf, 0xf, true));
             v = op(v, AECM_DPP(identity, v, kDppRowBcast15, 0xa, 0xf, false));   // rows 1,3 += rows 0,2
             v = op(v, AECM_DPP(identity, v, kDppRowBcast31, 0xc, 0xf, false));   // rows 2,3 += rows 0+1
             return __builtin_amdgcn_readlane(v, 63);
