@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--fs", type=int, default=16000)
     ap.add_argument("--variant", choices=["fast", "safe"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixed-delay", type=int, default=-1,
+                    help="WebRtcAecm_Control fixed delay (>= 0 disables the estimator's choice; 0 = no far-history reads; "
+                         "used to calibrate the FETCH_SIZE counter on a known byte count)")
     args = ap.parse_args()
 
     import torch
@@ -162,6 +165,8 @@ def main():
     far, near = synth_on_device(torch, S, segs * T * 64, 1234 + rank, device)
     batch = aecm.AecmBatch(S, args.fs, cng_mode=1, echo_mode=1, device=local_rank,
                            variant=aecm.KERNEL_FAST if args.variant == "fast" else aecm.KERNEL_SAFE)
+    if args.fixed_delay >= 0:
+        batch.control(args.fixed_delay, 1)
     stride = far.shape[1]
 
     out_full = torch.empty_like(near)       # same [S][segs*T*64] layout as the inputs

@@ -41,6 +41,7 @@ SIM_BIN(shl, shl(x, y))
 SIM_BIN(sar, sar(x, y))
 SIM_BIN(lsr, lsr(x, y))
 SIM_BIN(mul, mul(x, y))
+SIM_BIN(mul24, mul24(x, y))
 SIM_BIN(add, add(x, y))
 SIM_BIN(sub, sub(x, y))
 SIM_BIN(imin, imin(x, y))
@@ -95,6 +96,11 @@ SIM_MASK(operator|, x || y)
 SIM_MASK(operator==, x == y)
 SIM_MASK(operator!=, x != y)
 #undef SIM_MASK
+inline VecI shl_add(const VecI &a, int n, int c) {
+    VecI r;
+    for (int i = 0; i < 64; ++i) r.v[i] = shl_add(a.v[i], n, c);
+    return r;
+}
 inline VecI dot2_i16(const VecI &a, const VecI &b, const VecI &c) {
     VecI r;
     for (int i = 0; i < 64; ++i) r.v[i] = dot2_i16(a.v[i], b.v[i], c.v[i]);
@@ -131,8 +137,21 @@ struct SimWave {
         return r;
     }
     static vi hann(const vi &i) { return lut(kAecmSqrtHanningQ14, 65, i); }
-    static vi twiddle_cos(const vi &i) { return lut(kAecmTwiddleCosQ15, 64, i); }
-    static vi twiddle_sin(const vi &i) { return lut(kAecmTwiddleSinQ15, 64, i); }
+    // Packed twiddles of stage S for this lane's butterfly: w_re = (wr, -wi), w_im = (wi, wr) with
+    // wr = cos, wi = -sin (forward) / +sin (inverse) of entry m << k, m = position & (2^S - 1),
+    // k = 9 - S of kSinTable1024 (complex_fft.c:296-303, 412-420); positions are bit-reversed lanes.
+    template <int S, bool kInverse>
+    static void twiddles(vi &w_re, vi &w_im) {
+        for (int t = 0; t < 64; ++t) {
+            int brev = 0;
+            for (int b = 0; b < 6; ++b) brev |= ((t >> b) & 1) << (5 - b);
+            const int idx = (brev & ((1 << S) - 1)) << (6 - S);
+            const int wr = kAecmTwiddleCosQ15[idx];
+            const int wi = kInverse ? kAecmTwiddleSinQ15[idx] : -kAecmTwiddleSinQ15[idx];
+            w_re.v[t] = (wr & 0xffff) | (int)((unsigned)(-wi) << 16);
+            w_im.v[t] = (wi & 0xffff) | (int)((unsigned)wr << 16);
+        }
+    }
     static vi cos360(const vi &i) { return lut(kAecmCosQ13, 360, i); }
     static vi sin360(const vi &i) { return lut(kAecmSinQ13, 360, i); }
     static int cos360(int i) { return kAecmCosQ13[i]; }

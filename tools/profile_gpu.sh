@@ -18,3 +18,6 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_sq2" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_sq2.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace --output-format csv -d "$OUT/prof_grbm" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_grbm.log" 2>&1
 find "$OUT" -name "*.csv" | head -50
+# 4. FETCH_SIZE calibration on a known byte count: fixed delay 0 => no far-history reads, so the
+#    kernel reads exactly inputs (256 B/frame) + state (4608 B/stream) per launch.
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_cal" -o bench -- $BENCH --steps 3 --warmup 1 --fixed-delay 0 > "$OUT/prof_fetch_cal.log" 2>&1

@@ -1,5 +1,7 @@
 #include "aecm_host_state.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -7,6 +9,10 @@
 #include "aecm_tables.h"
 
 namespace aecm {
+[[noreturn]] void aecm_mul24_range_violation(int a, int b) {
+    fprintf(stderr, "aecm: mul24 precondition violated (%d * %d)\n", a, b);
+    abort();
+}
 namespace {
 
 inline uint32_t Pack16(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | (((uint32_t)(uint16_t)hi) << 16); }

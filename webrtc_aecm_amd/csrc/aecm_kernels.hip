@@ -18,8 +18,15 @@ namespace aecm {
 
 __device__ __forceinline__ void FillLdsTables() {
     LdsTables &t = g_lds[0];
-    for (int i = threadIdx.x; i < 64; i += blockDim.x)
-        t.twiddle[i] = zext16(kAecmTwiddleCosQ15[i]) | shl(kAecmTwiddleSinQ15[i], 16);
+    for (int i = threadIdx.x; i < 2 * 7 * 64; i += blockDim.x) {
+        const int lane = i & 63, stage = (i >> 6) % 7, inverse = i / (7 * 64);
+        int brev = 0;
+        for (int b = 0; b < 6; ++b) brev |= ((lane >> b) & 1) << (5 - b);
+        const int idx = (brev & ((1 << stage) - 1)) << (6 - stage);   // m << k in units of 8 (complex_fft.c:296,412)
+        const int wr = kAecmTwiddleCosQ15[idx];
+        const int wi = inverse ? kAecmTwiddleSinQ15[idx] : -kAecmTwiddleSinQ15[idx];
+        t.twiddle[inverse][stage][lane] = make_int2(zext16(wr) | shl(-wi, 16), zext16(wi) | shl(wr, 16));
+    }
     for (int i = threadIdx.x; i < 360; i += blockDim.x)
         t.cossin[i] = zext16(kAecmCosQ13[i]) | shl(kAecmSinQ13[i], 16);
     for (int i = threadIdx.x; i < 65; i += blockDim.x) t.hann[i] = kAecmSqrtHanningQ14[i];
@@ -181,7 +188,17 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
         }
         // 7: LDS tables
         if (threadIdx.x < 64) {
-            if (F::twiddle_cos(lane) != kAecmTwiddleCosQ15[lane] || F::twiddle_sin(lane) != kAecmTwiddleSinQ15[lane]) bump(7);
+            {   // last stage: lane t uses entry bitrev6(t); stage 0: entry 0 for every lane
+                int wre, wim, brev = 0;
+                for (int b = 0; b < 6; ++b) brev |= ((lane >> b) & 1) << (5 - b);
+                F::template twiddles<6, false>(wre, wim);
+                if (sext16(wre) != kAecmTwiddleCosQ15[brev] || sar(wre, 16) != kAecmTwiddleSinQ15[brev]) bump(7);
+                if (sext16(wim) != -kAecmTwiddleSinQ15[brev] || sar(wim, 16) != kAecmTwiddleCosQ15[brev]) bump(7);
+                F::template twiddles<6, true>(wre, wim);
+                if (sext16(wre) != kAecmTwiddleCosQ15[brev] || sar(wre, 16) != -kAecmTwiddleSinQ15[brev]) bump(7);
+                F::template twiddles<0, true>(wre, wim);
+                if (wre != 32767 || wim != (int)(32767u << 16)) bump(7);
+            }
             if (F::hann(lane + 1) != kAecmSqrtHanningQ14[lane + 1]) bump(7);
             for (int i = lane; i < 360; i += 64)
                 if (F::cos360(i) != kAecmCosQ13[i] || F::sin360(i) != kAecmSinQ13[i]) bump(7);

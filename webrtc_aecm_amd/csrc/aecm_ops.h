@@ -29,7 +29,15 @@ AECM_HD int mul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 AECM_HD int add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 AECM_HD int sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 AECM_HD int neg(int a) { return (int)(0u - (unsigned)a); }
-AECM_HD int sext16(int a) { return (int)(int16_t)a; }
+AECM_HD int sext16(int a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sbfe(a, 0, 16);       // keep it one v_bfe_i32 (do not let shifts be re-associated around it)
+#else
+    return (int)(int16_t)a;
+#endif
+}
+// (a << n) + c, wrapping                                                     -> v_lshl_add_u32
+AECM_HD int shl_add(int a, int n, int c) { return add(shl(a, n), c); }
 AECM_HD int zext16(int a) { return a & 0xffff; }
 AECM_HD int sel(bool c, int a, int b) { return c ? a : b; }
 AECM_HD int imin(int a, int b) { return a < b ? a : b; }
@@ -46,6 +54,21 @@ AECM_HD int divi(int a, int b) {
     return a / b;
 }
 AECM_HD int divu(int a, int b) { return b == 0 ? -1 : (int)((unsigned)a / (unsigned)b); }
+
+// Low 32 bits of a * b where BOTH operands are known to fit in 24 signed bits (-2^23 <= x < 2^23):
+// full-rate v_mul_i32_i24 instead of the quarter-rate 32-bit multiply.  The host build checks the
+// precondition (the CPU lane simulator runs every test input through it).
+#if !defined(__HIP_DEVICE_COMPILE__)
+[[noreturn]] void aecm_mul24_range_violation(int a, int b);
+#endif
+AECM_HD int mul24(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) aecm_mul24_range_violation(a, b);
+    return mul(a, b);
+#endif
+}
 
 // ---- packed-int16 primitives (a 32-bit word holds lo | hi<<16) -------------------------------------
 // Each has an exact portable definition; on gfx950 the same function is a single instruction.

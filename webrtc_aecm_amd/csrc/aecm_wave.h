@@ -29,6 +29,14 @@
 #include "aecm_ops.h"
 #include "aecm_state.h"
 
+// Profiling builds (-DAECM_MARKERS, device only) drop a comment marker into the ISA at each phase
+// boundary, pinned by two live values, so tools can count instructions per phase.  No-op otherwise.
+#if defined(AECM_MARKERS) && defined(__HIP_DEVICE_COMPILE__)
+#define AECM_PHASE_MARK(id, x, y) asm volatile("; AECM_MARK " #id : "+v"(x), "+v"(y))
+#else
+#define AECM_PHASE_MARK(id, x, y) ((void)0)
+#endif
+
 namespace aecm {
 
 // ---- algorithm constants (reference aecm/aecm_defines.h:17-85, delay_estimator.cc:23-28) --------
@@ -95,10 +103,10 @@ struct BlockEngine {
     static AECM_HD void init_lane_constants(Regs &r) {
         r.lane = W::lane_id();
         r.brev = bitrev6(r.lane);
-        r.hann_lo = W::hann(r.lane);                    // analysis window, first half : hann[t]
-        r.hann_hi = W::hann(vi(64) - r.lane);           //                  second half: hann[64-t]
-        r.hann_syn_lo = W::hann(r.brev);                // synthesis window in IFFT output lane order
-        r.hann_syn_hi = W::hann(vi(64) - r.brev);
+        r.hann_lo = sext16(W::hann(r.lane));                    // analysis window, first half : hann[t]
+        r.hann_hi = sext16(W::hann(vi(64) - r.lane));           //                  second half: hann[64-t]
+        r.hann_syn_lo = sext16(W::hann(r.brev));                // synthesis window in IFFT output lane order
+        r.hann_syn_hi = sext16(W::hann(vi(64) - r.brev));
         // LCG jump-ahead: after j steps seed_j = A^j * seed + C_j (mod 2^31); draw j-1 feeds bin j
         // (reference spl.cc:129-147, aecm_core_c.cc:143-150), so lane t needs j = t, bin 64 and the
         // carried-over seed need j = 64.
@@ -141,45 +149,45 @@ struct BlockEngine {
     // kRealInput: the imaginary parts of a and b are known to be zero on entry (forward transform of
     // a real signal, real_fft.c:59-65), which lets stage 0 (twiddle = (32767, 0)) skip half its work.
     template <bool kInverse, bool kRealInput>
-    static AECM_HD int fft128(const Regs &r, vi &a, vi &b) {
+    static AECM_HD int fft128(vi &a, vi &b) {
         int scale = 0;
         // stage s pairs positions differing in bit s; the operands of stage s>0 are brought
         // together by exchanging on lane bit (6 - s).
+        //
+        // sh = 15 (every forward stage; inverse stages with shift 1): base = (x_a << 15) + 2^15 is
+        // even, so Y+ = base + ((T >> 1) << 1) = (base + T) & ~1, and only the upper half of Y is
+        // kept: the dot product accumulates straight onto base + 1 and bit 0 never matters for Y+.
+        // For Y- = 2*base - Y+ the upper half equals that of Z = 2*base + 1 - acc (acc = base + T):
+        // Y- = Z - [acc even], and Z can only be a multiple of 2^16 when acc is odd.
 #define AECM_FFT_STAGE(S)                                                                          \
         if (S == 0 && kRealInput && !kInverse) {                                                   \
-            /* T_re = 32767*x_b + 1, T_im = 1 -> (T_im >> 1) << 1 = 0: imaginary outputs are 0 */  \
-            vi acc = add(mul(vi(32767), lo16(b)), shl(lo16(a), 15) + 32769);                       \
-            vi yp = acc & ~1;                                                                      \
-            vi ym = sub(shl(a, 16) + 65536, yp);                                                   \
-            a = lsr(yp, 16);                                                                       \
-            b = lsr(ym, 16);                                                                       \
+            /* twiddle (32767, 0), imaginary inputs 0: T_im = 1 -> imaginary outputs are 0 */      \
+            vi acc = add(mul24(vi(32767), lo16(b)), shl_add(lo16(a), 15, 32769));                  \
+            b = lsr(sub(shl_add(a, 16, 65537), acc), 16);                                          \
+            a = lsr(acc, 16);                                                                      \
         } else {                                                                                   \
             if (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);                            \
             int shift = 1;                                                                         \
             if (kInverse) { /* complex_fft.c:382-396: data-dependent scaling per stage */          \
+                /* only "max|x| > 13573" and "> 27146" matter: two ballots instead of a wave      \
+                   max-reduction (|-32768| saturates to 32767, the reference clamps it the same) */ \
                 vi m = max_halves_i16(pk_max_i16(pk_abs_sat_i16(a), pk_abs_sat_i16(b)));           \
-                int mx = W::reduce_max(m);        /* |-32768| already saturated to 32767 */        \
-                shift = lsr(13573 - mx, 31) + lsr(27146 - mx, 31);   /* sign bits; mx <= 32767 */  \
+                shift = (W::ballot(m > 13573) != 0 ? 1 : 0) + (W::ballot(m > 27146) != 0 ? 1 : 0); \
                 scale += shift;                                                                    \
             }                                                                                      \
-            /* twiddle index m << k with m = position & (2^S - 1), k = 9 - S, in units of 8 */     \
-            vi tw = shl(r.brev & vi((1 << S) - 1), 6 - S);                                         \
-            vi wr = W::twiddle_cos(tw);                                                            \
-            vi wi = kInverse ? W::twiddle_sin(tw) : neg(W::twiddle_sin(tw));                       \
-            vi w_re = pack(wr, neg(wi)), w_im = pack(wi, wr);                                      \
+            vi w_re, w_im;                                                                         \
+            W::template twiddles<S, kInverse>(w_re, w_im);   /* (wr,-wi) and (wi,wr), packed */    \
             if (shift == 1) {                                                                      \
-                /* sh = 15: Y = base + ((T >> 1) << 1) = (base + T) & ~1 because base is even, so  \
-                   the dot product accumulates straight onto base + 1; Y- = 2*base - Y+ */         \
-                vi acc_re = dot2_i16(b, w_re, shl(lo16(a), 15) + 32769);                           \
-                vi acc_im = dot2_i16(b, w_im, shl(hi16(a), 15) + 32769);                           \
-                vi yp_re = acc_re & ~1, yp_im = acc_im & ~1;                                       \
-                vi ym_re = sub(shl(a, 16) + 65536, yp_re);                                         \
-                vi ym_im = sub((a & (int)0xffff0000) + 65536, yp_im);                              \
-                a = pack_hi16(yp_re, yp_im);                                                       \
-                b = pack_hi16(ym_re, ym_im);                                                       \
+                vi acc_re = dot2_i16(b, w_re, shl_add(lo16(a), 15, 32769));  /* base + T_re */     \
+                vi acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));  /* base + T_im */     \
+                /* Z = 2*base + 1 - acc with 2*base = x_a << 16 */                                 \
+                vi z_re = sub(shl_add(a, 16, 65537), acc_re);                                      \
+                vi z_im = sub((a & (int)0xffff0000) + 65537, acc_im);                              \
+                a = pack_hi16(acc_re, acc_im);                                                     \
+                b = pack_hi16(z_re, z_im);                                                         \
             } else {                                                                               \
-                vi t_re = dot2_i16(b, w_re, vi(1));          /* wr*x_b - wi*y_b + 1 */             \
-                vi t_im = dot2_i16(b, w_im, vi(1));          /* wi*x_b + wr*y_b + 1 */             \
+                vi t_re = dot2_i16(b, w_re, vi(1));                                                \
+                vi t_im = dot2_i16(b, w_im, vi(1));                                                \
                 const int up = 2 - shift;                    /* 16 - sh */                         \
                 t_re = shl(sar(t_re, 1), up);                                                      \
                 t_im = shl(sar(t_im, 1), up);                                                      \
@@ -203,10 +211,10 @@ struct BlockEngine {
         int mx = imin(W::reduce_max(imax(iabs(old_s), iabs(new_s))), 32767);
         int q = norm_w16(mx);
         // window (:174-182): scale, truncate to int16, multiply by sqrt-Hanning Q14, truncate
-        vi wo = sext16(sar(mul(sext16(shl(old_s, q)), r.hann_lo), 14));
-        vi wn = sext16(sar(mul(sext16(shl(new_s, q)), r.hann_hi), 14));
+        vi wo = sext16(sar(mul24(sext16(shl(old_s, q)), r.hann_lo), 14));
+        vi wn = sext16(sar(mul24(sext16(shl(new_s, q)), r.hann_hi), 14));
         vi a = zext16(wo), b = zext16(wn);                  // packed (re, 0): imaginary input is zero (real_fft.c:59-65)
-        fft128<false, true>(r, a, b);
+        fft128<false, true>(a, b);
         // lane t now holds X[bitrev6(t)] in a and X[bitrev6(t)+64] in b
         int x64 = W::readlane(b, 0);
         vi x = W::bpermute(a, r.brev);                      // bin t -> lane t
@@ -220,7 +228,7 @@ struct BlockEngine {
         // im == 0 (|.| of the other part) and saturates re^2+im^2 at 2^31-1; both are subsumed by an
         // exact floor(sqrt) on the unsigned sum: floor(sqrt(x^2)) == |x|, and the only sum above
         // 2^31-1 is 2^31 (re = im = -32768), whose floor-sqrt 46340 equals that of 2^31-1.
-        vi sq = add(mul(re, re), mul(im, im));              // <= 2^31 as unsigned
+        vi sq = add(mul24(re, re), mul24(im, im));          // <= 2^31 as unsigned
         sp.mag = W::isqrt31(sq);                            // <= 46340 < 2^16
         sp.mag64 = zext16(iabs(sp.re64));
         sp.sum = add(W::reduce_add(sp.mag), sp.mag64);
@@ -298,10 +306,10 @@ struct BlockEngine {
                                       int &echo_est64) {
         Uniform &u = r.u;
         r.near_log = W::shift_up1(r.near_log, log_energy_q8(near_energy, u.dfa_noisy_q));   // :665-669
-        echo_est = mul(r.b.ch_stored, far);
+        echo_est = mul24(r.b.ch_stored, far);
         echo_est64 = mul(r.b64.ch_stored, far64);
         int e_far = add(W::reduce_add(far), far64);
-        int e_adapt = add(W::reduce_add(mul(r.b.ch_adapt16, far)), mul(r.b64.ch_adapt16, far64));
+        int e_adapt = add(W::reduce_add(mul24(r.b.ch_adapt16, far)), mul(r.b64.ch_adapt16, far64));
         int e_stored = add(W::reduce_add(echo_est), echo_est64);
         u.far_log = log_energy_q8(e_far, far_q);
         r.adapt_log = W::shift_up1(r.adapt_log, log_energy_q8(e_adapt, kResChannel16 + far_q));
@@ -400,7 +408,7 @@ struct BlockEngine {
     static AECM_HD void store_adaptive_channel(Regs &r, vi far, int far64, vi &echo_est, int &echo_est64) {
         r.b.ch_stored = r.b.ch_adapt16;                                                       // :286-306
         r.b64.ch_stored = r.b64.ch_adapt16;
-        echo_est = mul(r.b.ch_stored, far);
+        echo_est = mul24(r.b.ch_stored, far);
         echo_est64 = mul(r.b64.ch_stored, far64);
     }
 
@@ -478,7 +486,7 @@ struct BlockEngine {
         // echoFilt += ((int64)(echoEst - echoFilt) * 50) >> 8 without 64-bit math:
         // d = 256a + b  =>  (50 d) >> 8 = 50 a + ((50 b) >> 8)                                    :523-525
         I d = sub(echo_est, s.echo_filt);
-        s.echo_filt = add(s.echo_filt, add(mul(sar(d, 8), I(50)), sar(mul(d & 255, I(50)), 8)));
+        s.echo_filt = add(s.echo_filt, add(mul24(sar(d, 8), I(50)), sar(mul24(d & 255, I(50)), 8)));
 
         I zeros32 = norm_w32(s.echo_filt) + 1;                                                // :527-550
         int zeros16 = norm_w16(sup_gain) + 1;
@@ -487,10 +495,11 @@ struct BlockEngine {
         int dq = clean_q - zeros_xbuf;
         I res_diff = sel(safe, I(14 - kResChannel16 - kResSupgain + dq),
                          sext16(t16 + (14 - kResChannel16 - kResSupgain + dq)));
-        I g_safe = mul(s.echo_filt, I(zext16(sup_gain)));
-        I g_b = mul(s.echo_filt, zext16(sar(I(sup_gain), t16)));
-        I g_c = mul(sar(s.echo_filt, t16), I(sup_gain));
-        I gained = sel(safe, g_safe, sel(zeros32 > t16, g_b, g_c));
+        // three regimes (:534,:544,:548), all "low 32 bits of a product": select the operands, multiply once
+        auto shift_gain = zeros32 > t16;
+        I lhs = sel(safe | shift_gain, s.echo_filt, sar(s.echo_filt, t16));
+        I rhs = sel(safe, I(zext16(sup_gain)), sel(shift_gain, zext16(sar(I(sup_gain), t16)), I(sup_gain)));
+        I gained = mul(lhs, rhs);
 
         I zn = norm_w16(s.near_filt);                                                         // :552-579
         int dqq = sext16(clean_q - clean_q_old);
@@ -526,8 +535,8 @@ struct BlockEngine {
         auto c11 = sar(s.noise_est, 11) > 0;
         I low_inc = s.low_ctr + 1;
         auto inc = low_inc >= 5;
-        I ne_ge = sel(c19, mul(sar(s.noise_est, 11), I(2049)),
-                      sel(c11, sar(mul(s.noise_est, I(2049)), 11),
+        I ne_ge = sel(c19, mul24(sar(s.noise_est, 11), I(2049)),
+                      sel(c11, sar(mul24(s.noise_est & 0x7ffff, I(2049)), 11),   // c11 && !c19: noise_est < 2^19
                           sel(inc, s.noise_est + sar(s.noise_est, 9) + 1, s.noise_est)));
         I low_ge = sel(c19 | c11, s.low_ctr, sel(inc, I(0), low_inc));
         I ne = sel(lt, ne_lt, ne_ge);
@@ -537,10 +546,10 @@ struct BlockEngine {
         auto clamp = t32 > 32767;
         t32 = sel(clamp, I(32767), t32);
         s.noise_est = sel(clamp, shl(I(32767), shift_n), ne);
-        I n16 = sext16(sar(mul(sext16(I(kOneQ14) - hnl), sext16(t32)), 14));
-        I idx = sext16(sar(mul(I(359), rnd), 15));                                            // :150
-        u_re = sext16(sar(mul(n16, W::cos360(idx)), 13));                                     // :153-156
-        u_im = sext16(sar(mul(neg(n16), W::sin360(idx)), 13));
+        I n16 = sext16(sar(mul24(sext16(I(kOneQ14) - hnl), sext16(t32)), 14));
+        I idx = sext16(sar(mul24(I(359), rnd), 15));                                            // :150
+        u_re = sext16(sar(mul24(n16, sext16(W::cos360(idx))), 13));                                     // :153-156
+        u_im = sext16(sar(mul24(neg(n16), sext16(W::sin360(idx))), 13));
     }
 
     // ------------------------------------------------------------------------------------------
@@ -627,8 +636,11 @@ struct BlockEngine {
         if (u.startup < 2) u.startup = (gtu(u.tot_count, kConvLen - 1) ? 1 : 0) + (gtu(u.tot_count, kConvLen2 - 1) ? 1 : 0);  // :420-424
 
         Spectrum xf, df, cf;
+        AECM_PHASE_MARK(0, far_new, near_new);
         time_to_frequency(r, r.x_old, far_new, xf);                                   // :439
+        AECM_PHASE_MARK(1, xf.mag, xf.re);
         time_to_frequency(r, r.d_old, near_new, df);                                  // :442
+        AECM_PHASE_MARK(2, df.mag, df.re);
         u.dfa_noisy_q_old = u.dfa_noisy_q;
         u.dfa_noisy_q = df.q;
         if (kHasClean) {                                                              // :449-464
@@ -658,11 +670,13 @@ struct BlockEngine {
             r.bh0 = W::shift_up1(r.bh0, word);
             r.bh1 = W::shift_up1(r.bh1, carry);
         }
+        AECM_PHASE_MARK(3, r.bh0, r.mean_far);
         // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
         int delay = process_binary(r, binary_spectrum(r, df.mag, df.q, r.mean_near, u.near_init));
         if (delay == -2) delay = 0;                                                   // :479-483
         if (u.fixed_delay >= 0) delay = u.fixed_delay;                                // :485-488
 
+        AECM_PHASE_MARK(4, r.m0, r.mean_near);
         // AlignedFarend (aecm_core.cc:157-172)
         int pos = u.hist_pos - delay;
         if (pos < 0) pos += kHistory;
@@ -674,18 +688,22 @@ struct BlockEngine {
 
         vi echo_est;
         int echo_est64;
+        AECM_PHASE_MARK(5, far, r.m1);
         calc_energies(r, far, far64, far_q, df.sum, echo_est, echo_est64);            // :498
         const int mu = calc_step_size(u);                                             // :503
         u.tot_count = add(u.tot_count, 1);                                            // :506
+        AECM_PHASE_MARK(6, echo_est, r.near_log);
         update_channel(r, far, far64, far_q, df.mag, df.mag64, mu, echo_est, echo_est64);   // :511
+        AECM_PHASE_MARK(7, r.b.ch_adapt32, echo_est);
         const int sup_gain = calc_suppression_gain(r);                                // :514
 
         vi hnl = wiener_bin<vi>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
         int hnl64 = wiener_bin<int>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
         const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
 
+        AECM_PHASE_MARK(8, hnl, r.b.near_filt);
         if (u.mult == 2) {                                                            // :618-648
-            hnl = sext16(sar(mul(hnl, hnl), 14));
+            hnl = sext16(sar(mul24(hnl, hnl), 14));
             hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
             int avg = W::reduce_add(sel((r.lane >= 4) & (r.lane <= 24), hnl, vi(0)));
             avg = sext16(divi(avg, 21));
@@ -697,11 +715,12 @@ struct BlockEngine {
             hnl64 = hnl64 > kNlpCompHigh ? kOneQ14 : (hnl64 < kNlpCompLow ? 0 : hnl64);
             if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
         }
-        vi e_re = sext16(sar(mul(clean.re, hnl) + 8192, 14));                         // :680-685
-        vi e_im = sext16(sar(mul(clean.im, hnl) + 8192, 14));
+        vi e_re = sext16(sar(mul24(clean.re, hnl) + 8192, 14));                         // :680-685
+        vi e_im = sext16(sar(mul24(clean.im, hnl) + 8192, 14));
         int e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
         int e_im64 = 0;
 
+        AECM_PHASE_MARK(9, e_re, e_im);
         if (u.cng == 1) {                                                             // :702-705
             int shift_n = sext16(15 - u.dfa_clean_q);
             int min_track = 9;
@@ -725,6 +744,7 @@ struct BlockEngine {
             e_im64 = sat16(e_im64 + u_im64);
         }
 
+        AECM_PHASE_MARK(10, e_re, e_im);
         // InverseFFTAndWindow (:193-246) + RealInverseFFT (real_fft.c:74-102):
         // Y[c] = (re[c], -im[c]) for c <= 64, conj-symmetric extension for c > 64 (T7).
         vi y = pack(e_re, sext16(neg(e_im)));
@@ -732,13 +752,15 @@ struct BlockEngine {
         int y64 = zext16(e_re64) | shl(sext16(neg(e_im64)), 16);
         vi a = y;
         vi b = sel(r.lane == 0, vi(y64), mirrored);
-        const int out_cfft = fft128<true, false>(r, a, b);
+        const int out_cfft = fft128<true, false>(a, b);
+        AECM_PHASE_MARK(11, a, b);
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
-        vi first = sext16(sar(mul(lo16(a), r.hann_syn_lo) + 8192, 14));               // :219-221
+        vi first = sext16(sar(mul24(lo16(a), r.hann_syn_lo) + 8192, 14));               // :219-221
         vi out = sat16(add(shift_i(first, sh), r.out_ovl));                           // :222-227
-        vi second = sar(mul(lo16(b), r.hann_syn_hi), 14);                             // :229-234
+        vi second = sar(mul24(lo16(b), r.hann_syn_hi), 14);                             // :229-234
         r.out_ovl = sat16(shift_i(second, sh));
+        AECM_PHASE_MARK(12, out, r.out_ovl);
         r.x_old = far_new;                                                            // :239-245
         r.d_old = near_new;
         if (kHasClean) r.c_old = clean_new;

@@ -20,7 +20,9 @@ namespace aecm {
 
 // LDS tables, filled by the kernel prologue (aecm_kernels.hip).
 struct LdsTables {
-    int twiddle[64];   // lo16: cos (wr), hi16: sin       entries 8r+256 / 8r of kSinTable1024
+    // Packed FFT twiddles, one (w_re, w_im) pair per [direction][stage][lane]: a stage is one
+    // conflict-free ds_read_b64 at lane*8 + constant offset, no VALU address or packing work.
+    int2 twiddle[2][7][64];
     int cossin[360];   // lo16: cos Q13, hi16: sin Q13     comfort-noise phase table
     int hann[65];      // sqrt-Hanning Q14
 };
@@ -53,8 +55,12 @@ struct Gfx950Wave {
 
     // ---- tables ----
     static __device__ __forceinline__ int hann(int i) { return g_lds[0].hann[i]; }
-    static __device__ __forceinline__ int twiddle_cos(int i) { return sext16(g_lds[0].twiddle[i]); }
-    static __device__ __forceinline__ int twiddle_sin(int i) { return g_lds[0].twiddle[i] >> 16; }
+    template <int S, bool kInverse>
+    static __device__ __forceinline__ void twiddles(int &w_re, int &w_im) {
+        const int2 w = g_lds[0].twiddle[kInverse ? 1 : 0][S][lane_id()];
+        w_re = w.x;
+        w_im = w.y;
+    }
     static __device__ __forceinline__ int cos360(int i) { return sext16(g_lds[0].cossin[i]); }
     static __device__ __forceinline__ int sin360(int i) { return g_lds[0].cossin[i] >> 16; }
 
