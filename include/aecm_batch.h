@@ -58,6 +58,22 @@ int32_t WebRtcAecmBatch_ProcessBlocks(AecmBatch *b, const int16_t *far_dev, cons
 int32_t WebRtcAecmBatch_ProcessBlocksHost(AecmBatch *b, const int16_t *far_host, const int16_t *near_host,
                                           const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
                                           int64_t block_stride, int32_t num_blocks);
+/* Whole recordings as sessions (batched form of the reference CLI's loop, main.cc:105-143): every
+ * stream is treated as a freshly initialised WebRtcAecm_* session that receives num_calls pairs of
+ * WebRtcAecm_BufferFarend(far, samples_per_call) + WebRtcAecm_Process(near, NULL, out,
+ * samples_per_call, msInSndCardBuf).  The session wrapper and frame adapter of the reference
+ * (echo_control_mobile.cc:236-408, aecm_core.cc:501-572) only move samples, so they are run once on
+ * the host in the index domain and applied to all streams as a device-side gather / scatter around
+ * WebRtcAecmBatch_ProcessBlocks.  Call after WebRtcAecmBatch_Init (+ set_config) on fresh streams.
+ * far/near/out: [S][stream_stride] with stream_stride >= num_calls * samples_per_call; samples beyond
+ * that are not touched.  Returns 0 or AECM_BAD_PARAMETER_WARNING exactly as each session would.
+ * Synchronous. */
+int32_t WebRtcAecmBatch_ProcessRecordings(AecmBatch *b, const int16_t *far_dev, const int16_t *near_dev, int16_t *out_dev,
+                                          int64_t stream_stride, int32_t samples_per_call, int32_t num_calls,
+                                          int16_t msInSndCardBuf);
+int32_t WebRtcAecmBatch_ProcessRecordingsHost(AecmBatch *b, const int16_t *far_host, const int16_t *near_host,
+                                              int16_t *out_host, int64_t stream_stride, int32_t samples_per_call,
+                                              int32_t num_calls, int16_t msInSndCardBuf);
 int32_t WebRtcAecmBatch_Synchronize(AecmBatch *b);
 
 /* Duration of the most recent ProcessBlocks kernel, from HIP events recorded around the launch on

@@ -12,10 +12,10 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "webrtc_aecm_amd" / "csrc"
 SIM_SO = ROOT / "tests" / "_build" / "libaecm_sim.so"
 _SOURCES = [ROOT / "tests" / "sim" / "sim_lib.cpp", ROOT / "tests" / "sim" / "sim_engine.cpp",
-            CSRC / "aecm_host_state.cpp", CSRC / "aecm_session.cpp"]
+            CSRC / "aecm_host_state.cpp", CSRC / "aecm_session.cpp", CSRC / "aecm_schedule.cpp"]
 _DEPS = _SOURCES + [ROOT / "tests" / "sim" / "wave_sim.h", CSRC / "aecm_wave.h", CSRC / "aecm_ops.h",
                     CSRC / "aecm_state.h", CSRC / "aecm_host_state.h", CSRC / "aecm_tables.h",
-                    CSRC / "aecm_session.h", CSRC / "aecm_engine.h"]
+                    CSRC / "aecm_session.h", CSRC / "aecm_engine.h", CSRC / "aecm_session_flow.h"]
 _i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _lib = None
@@ -43,6 +43,7 @@ def lib():
         l.sim_get_echo_path.argtypes = [C.c_void_p, _i16p]
         l.sim_process.argtypes = [C.c_void_p, _i16p, _i16p, C.c_void_p, _i16p, C.c_int]
         l.sim_digest.argtypes = [C.c_void_p, _u32p]
+        l.sim_recordings.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.simsession_create.restype = C.c_void_p
         l.simsession_free.argtypes = [C.c_void_p]
         l.simsession_init.argtypes = [C.c_void_p, C.c_int32]
@@ -136,3 +137,14 @@ class SimSession:
             self.lib.simsession_free(self.h)
         except Exception:
             pass
+
+
+def sim_recordings(far, near, fs, frame, cng, echo_mode, ms):
+    """Schedule-based batched sessions on the simulator: returns (code, out) like
+    AecmBatch.process_recordings_host."""
+    far = np.ascontiguousarray(far, dtype=np.int16)
+    near = np.ascontiguousarray(near, dtype=np.int16)
+    out = near.copy()
+    rc = lib().sim_recordings(far.shape[0], far.shape[1], fs, frame, cng, echo_mode, ms, far.ctypes.data, near.ctypes.data,
+                              out.ctypes.data)
+    return rc, out

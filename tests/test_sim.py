@@ -133,3 +133,22 @@ def test_session_host_logic_matches_reference_abi_odd_call_patterns():
             rc = r.lib.WebRtcAecm_Process(r.h, near[sl].ctypes.data, None, ob.ctypes.data, frame, ms)
             rc2, o2 = s.process(near[sl], None, ms)
             assert rc == rc2 and np.array_equal(ob, o2), (fs, frame, i)
+
+
+def test_batched_recordings_schedule_matches_reference_fixtures():
+    """The index-domain session schedule (aecm_schedule.cpp) + gather/scatter reproduces, for every
+    stream of a batch, what an individual WebRtcAecm_* session produces."""
+    for f in golden_files("session_"):
+        g = np.load(f)
+        fs, frame, ms = int(g["fs"]), int(g["frame"]), int(g["ms"])
+        far, near = synth_pair(int(g["seed"]), int(g["n_blocks"]), fs, "mixed")
+        n = (far.size // frame) * frame
+        far2, near2 = synth_pair(int(g["seed"]) + 50, int(g["n_blocks"]), fs, "mixed")
+        rc, out = simlib.sim_recordings(np.stack([far[:n], far2[:n]]), np.stack([near[:n], near2[:n]]), fs, frame,
+                                        int(g["cng"]), int(g["echo_mode"]), ms)
+        assert [rc] == [c for c in g["codes"].tolist()] or (rc == 0 and g["codes"].tolist() == [0]), f.name
+        assert np.array_equal(out[0], g["out"]), f.name
+        s = simlib.SimSession()
+        assert s.init(fs) == 0 and s.set_config(int(g["cng"]), int(g["echo_mode"])) == 0
+        exp, _ = _run(s, far2[:n], near2[:n], frame, ms)
+        assert np.array_equal(out[1], exp), f.name

@@ -10,7 +10,9 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "_lib"
 LIB = LIB_DIR / "libaecm_mi355x.so"
-SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_capi.cpp", "aecm_host_state.cpp"]
+CLI = LIB_DIR / "aecm_run"
+SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_schedule.cpp", "aecm_capi.cpp",
+           "aecm_host_state.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-shared"]
 
 
@@ -38,6 +40,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=str(CSRC))
+    # the command-line front end (reference main.cc equivalent + multi-file batch mode)
+    cli = ["g++", "-O2", "-std=c++17", str(CSRC / "aecm_cli.cpp"), "-o", str(CLI), f"-L{LIB_DIR}", "-laecm_mi355x",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cli))
+    subprocess.check_call(cli, cwd=str(CSRC))
     return LIB
 
 

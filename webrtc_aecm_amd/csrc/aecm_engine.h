@@ -28,6 +28,13 @@ public:
     bool Control(int fixed_delay, int nlp_flag, int first, int count);
     bool ProcessBlocks(const IoView &io_dev, int num_blocks);          // async
     bool ProcessBlocksHost(const IoView &io_host, int num_blocks);     // sync
+    // Whole recordings as sessions: every stream is driven like a fresh WebRtcAecm_* session by
+    // n_calls x (BufferFarend, Process) of `frame` samples with a constant msInSndCardBuf
+    // (aecm_session_flow.h).  far/near/out: [S][>= n_calls*frame], device (or host) pointers.
+    // *rc receives the ABI return code a single session would have produced (0 or 12100).
+    bool ProcessRecordings(const int16_t *far, const int16_t *near, int16_t *out, int64_t stream_stride, int frame,
+                           int n_calls, int16_t ms, bool host_pointers, int32_t *rc);
+    int fs() const { return fs_; }
     bool Synchronize();
     bool LastLaunchMs(float *ms);
     bool Timers(double *total_ms, int64_t *launches);
@@ -46,6 +53,7 @@ private:
     int num_streams_ = 0;
     bool initialized_ = false;
     int variant_ = kVariantFast;
+    int fs_ = 0;
     hipStream_t stream_ = nullptr;
     StatePtrs st_{nullptr, nullptr, nullptr};
     uint32_t *image_vec_dev_ = nullptr;

@@ -29,6 +29,15 @@ hipError_t LaunchBroadcastImage(const StatePtrs &st, const uint32_t *image_vec, 
 hipError_t LaunchPatchScalars(const StatePtrs &st, const int32_t *fields_dev, const int32_t *values_dev, int n_fields,
                               int first, int count, hipStream_t stream);
 
+// Session-schedule gather / scatter (aecm_session_flow.h: RecordingSchedule), all streams at once.
+//   dst[s][j] = map[j] >= 0 ? src[s*src_stride + map[j]] : 0            j in [0, n)
+hipError_t LaunchGatherByMap(const int16_t *src, int64_t src_stride, const int32_t *map_dev, int64_t n, int16_t *dst,
+                             int64_t dst_stride, int n_streams, hipStream_t stream);
+//   out[s][j] = v >= 0 ? blocks[s][v] : (v == -1 ? 0 : near[s][-(v+2)])  with v = map[j]
+hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, const int16_t *near, int64_t near_stride,
+                                const int32_t *map_dev, int64_t n, int16_t *out, int64_t out_stride, int n_streams,
+                                hipStream_t stream);
+
 // Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
 //  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,
 //  6 isqrt31 (exhaustive over [0, 2^31) when exhaustive != 0, else 2^24 samples), 7 table upload.

@@ -104,6 +104,47 @@ hipError_t LaunchPatchScalars(const StatePtrs &st, const int32_t *fields_dev, co
     return hipGetLastError();
 }
 
+// ---- session-schedule gather / scatter ---------------------------------------------------------------
+
+__global__ void aecm_gather_by_map_kernel(const int16_t *src, int64_t src_stride, const int32_t *map, int64_t n,
+                                          int16_t *dst, int64_t dst_stride) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t s = blockIdx.y;
+    const int32_t m = map[j];
+    dst[s * dst_stride + j] = m >= 0 ? src[s * src_stride + m] : (int16_t)0;
+}
+
+hipError_t LaunchGatherByMap(const int16_t *src, int64_t src_stride, const int32_t *map_dev, int64_t n, int16_t *dst,
+                             int64_t dst_stride, int n_streams, hipStream_t stream) {
+    if (n <= 0 || n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_gather_by_map_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream, src,
+                       src_stride, map_dev, n, dst, dst_stride);
+    return hipGetLastError();
+}
+
+__global__ void aecm_assemble_output_kernel(const int16_t *blocks, int64_t blocks_stride, const int16_t *near,
+                                            int64_t near_stride, const int32_t *map, int64_t n, int16_t *out,
+                                            int64_t out_stride) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t s = blockIdx.y;
+    const int32_t v = map[j];
+    int16_t r = 0;
+    if (v >= 0) r = blocks[s * blocks_stride + v];
+    else if (v <= -2) r = near[s * near_stride + (-(int64_t)v - 2)];
+    out[s * out_stride + j] = r;
+}
+
+hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, const int16_t *near, int64_t near_stride,
+                                const int32_t *map_dev, int64_t n, int16_t *out, int64_t out_stride, int n_streams,
+                                hipStream_t stream) {
+    if (n <= 0 || n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_assemble_output_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream,
+                       blocks, blocks_stride, near, near_stride, map_dev, n, out, out_stride);
+    return hipGetLastError();
+}
+
 // ---- self test of the wave primitives ------------------------------------------------------------
 
 __device__ __forceinline__ unsigned Mix(unsigned x) {

@@ -35,7 +35,8 @@ SESSION_SYMBOLS = [
 BATCH_SYMBOLS = [
     "WebRtcAecmBatch_Create", "WebRtcAecmBatch_Free", "WebRtcAecmBatch_num_streams", "WebRtcAecmBatch_Init",
     "WebRtcAecmBatch_set_config", "WebRtcAecmBatch_Control", "WebRtcAecmBatch_ProcessBlocks",
-    "WebRtcAecmBatch_ProcessBlocksHost", "WebRtcAecmBatch_Synchronize", "WebRtcAecmBatch_GetLastLaunchMs",
+    "WebRtcAecmBatch_ProcessBlocksHost", "WebRtcAecmBatch_ProcessRecordings", "WebRtcAecmBatch_ProcessRecordingsHost",
+    "WebRtcAecmBatch_Synchronize", "WebRtcAecmBatch_GetLastLaunchMs",
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DeviceInfo",
@@ -91,6 +92,8 @@ def load():
     lib.WebRtcAecmBatch_Control.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_ProcessBlocks.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32]
     lib.WebRtcAecmBatch_ProcessBlocksHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32]
+    lib.WebRtcAecmBatch_ProcessRecordings.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int16]
+    lib.WebRtcAecmBatch_ProcessRecordingsHost.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int16]
     lib.WebRtcAecmBatch_Synchronize.argtypes = [vp]
     lib.WebRtcAecmBatch_GetLastLaunchMs.argtypes = [vp, C.POINTER(C.c_float)]
     lib.WebRtcAecmBatch_GetTimers.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -223,6 +226,21 @@ class AecmBatch:
         self._check(self.lib.WebRtcAecmBatch_ProcessBlocksHost(self.h, far.ctypes.data, near.ctypes.data, cp,
                                                                out.ctypes.data, far.shape[1], BLOCK, t), "ProcessBlocksHost")
         return out
+
+    def process_recordings_host(self, far, near, frame: int, ms: int = 40):
+        """far/near: [S, N] int16 host arrays, each stream a whole recording driven like the reference CLI
+        (BufferFarend + Process per `frame` samples, constant msInSndCardBuf).  Returns (code, out)."""
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        assert far.shape == near.shape and far.shape[0] == self.num_streams
+        out = near.copy()
+        n_calls = far.shape[1] // frame
+        rc = self.lib.WebRtcAecmBatch_ProcessRecordingsHost(self.h, far.ctypes.data, near.ctypes.data, out.ctypes.data,
+                                                            far.shape[1], frame, n_calls, ms)
+        return rc, out
+
+    def process_recordings_device(self, far_ptr, near_ptr, out_ptr, stream_stride, frame, n_calls, ms=40):
+        return self.lib.WebRtcAecmBatch_ProcessRecordings(self.h, far_ptr, near_ptr, out_ptr, stream_stride, frame, n_calls, ms)
 
     def process_device(self, far_ptr, near_ptr, out_ptr, stream_stride, block_stride, num_blocks, clean_ptr=None):
         """Device pointers (e.g. torch .data_ptr()); asynchronous on the engine's stream."""
