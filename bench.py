@@ -121,13 +121,27 @@ def cpu_baseline(fs, budget_s=12.0):
 
 
 def load_traffic(workload_key):
-    """Per-launch HBM bytes measured with rocprofv3 PMC passes (profiles/*.json), if recorded."""
+    """Per-launch HBM bytes measured with rocprofv3 PMC passes (profiles/hbm_traffic.json, written by
+    tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command,
+    FETCH_SIZE calibrated on a known byte count), if recorded for this workload."""
     p = ROOT / "profiles" / "hbm_traffic.json"
     if not p.exists():
         return None
     try:
         rec = json.loads(p.read_text())
         return rec.get(workload_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def load_valu_note():
+    """The counter that actually bounds this kernel (recorded by the last profiling pass)."""
+    p = ROOT / "profiles" / "r01_rocprof_summary.json"
+    try:
+        d = json.loads(p.read_text())["derived"]
+        return {"valu_insts_per_frame": round(d["valu_insts_per_frame"], 1),
+                "valu_issue_busy_frac": round(d["valu_issue_busy_frac_at_4_cycles_per_wave64_inst"], 3),
+                "source": "profiles/r01_rocprof_summary.json (rocprofv3 SQ_INSTS_VALU, GRBM_GUI_ACTIVE)"}
     except Exception:
         return None
 
@@ -211,7 +225,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(workload_key),
                          "kernel": "aecm_process_kernel<fast,noclean>", "kernel_avg_ms": kern_avg_s * 1e3,
                          "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME,
-                         "note": "integer-VALU/latency-bound kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak"},
+                         "note": "integer-VALU-issue-bound kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "
+                                 "see valu_bound for the binding resource",
+                         "valu_bound": load_valu_note()},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.fs)
