@@ -87,6 +87,13 @@ int32_t WebRtcAecmBatch_ResetTimers(AecmBatch *b);
 int32_t WebRtcAecmBatch_InitEchoPath(AecmBatch *b, int32_t stream, const void *echo_path, size_t size_bytes);
 int32_t WebRtcAecmBatch_GetEchoPath(AecmBatch *b, int32_t stream, void *echo_path, size_t size_bytes);
 
+/* Full snapshot of one stream's device state (checkpoint / migration between batches or GPUs):
+ * lane-vector words, scalars and far-spectrum history, WebRtcAecmBatch_state_size_bytes() bytes.
+ * A stream restored with ImportState continues bit-exactly where the exported one stopped. */
+size_t WebRtcAecmBatch_state_size_bytes(void);
+int32_t WebRtcAecmBatch_ExportState(AecmBatch *b, int32_t stream, void *state, size_t size_bytes);
+int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *state, size_t size_bytes);
+
 /* 24-word digest of one stream's complete state (canonical order: oracle/aecm_oracle.c). */
 int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]);
 

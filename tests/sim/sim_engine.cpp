@@ -98,6 +98,8 @@ bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
     aecm::GetEchoPath(&s->vec[(size_t)stream * kVecWordsPerStream], &s->scal[(size_t)stream * kNumScal], path);
     return true;
 }
+bool BatchEngine::ExportState(int, void *) { return false; }
+bool BatchEngine::ImportState(int, const void *) { return false; }
 bool BatchEngine::Digest(int stream, uint32_t d[kDigestWords]) {
     SimStore *s = Store(st_);
     ComputeDigest(&s->vec[(size_t)stream * kVecWordsPerStream], &s->scal[(size_t)stream * kNumScal],

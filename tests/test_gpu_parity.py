@@ -144,6 +144,27 @@ def test_echo_path_roundtrip_and_reinit():
     assert not np.array_equal(out[0], out[1])
 
 
+def test_state_snapshot_migrates_a_stream():
+    """Export a stream's state mid-run, import it into another batch (other slot, other config): both
+    continue bit-exactly."""
+    fs, T1, T2 = 16000, 700, 500
+    far, near = synth_streams([61, 62, 63], T1 + T2, fs)
+    a = aecm.AecmBatch(3, fs, 1, 2)
+    a.process_host(far[:, :T1 * 64], near[:, :T1 * 64])
+    blob = a.export_state(2)
+    assert len(blob) == aecm.load().WebRtcAecmBatch_state_size_bytes() == 17408
+    b = aecm.AecmBatch(2, 8000, 0, 4)                      # deliberately different rate/config: all of it is state
+    b.import_state(1, blob)
+    out_a = a.process_host(far[:, T1 * 64:], near[:, T1 * 64:])
+    fb = np.stack([far[0, T1 * 64:], far[2, T1 * 64:]])
+    nb = np.stack([near[0, T1 * 64:], near[2, T1 * 64:]])
+    out_b = b.process_host(fb, nb)
+    assert np.array_equal(out_b[1], out_a[2])
+    assert np.array_equal(b.digest(1), a.digest(2))
+    exp, dig = oracle_run(63, T1 + T2, fs, 1, 2)
+    assert np.array_equal(out_a[2], exp[T1 * 64:]) and np.array_equal(a.digest(2), dig)
+
+
 def _run_session(sess, far, near, frame, ms):
     out = near.copy()
     codes = set()

@@ -203,6 +203,27 @@ int32_t WebRtcAecmBatch_GetEchoPath(AecmBatch *b, int32_t stream, void *echo_pat
     return 0;
 }
 
+size_t WebRtcAecmBatch_state_size_bytes(void) { return BatchEngine::kStateBytes; }
+
+static int32_t CheckState(const AecmBatch *b, int32_t stream, const void *state, size_t size_bytes) {
+    if (!b) return -1;
+    if (!state) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes != BatchEngine::kStateBytes) return AECM_BAD_PARAMETER_ERROR;
+    if (!b->engine->initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (stream < 0 || stream >= b->engine->num_streams()) return AECM_BAD_PARAMETER_ERROR;
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_ExportState(AecmBatch *b, int32_t stream, void *state, size_t size_bytes) {
+    if (int32_t rc = CheckState(b, stream, state, size_bytes)) return rc;
+    return b->engine->ExportState(stream, state) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *state, size_t size_bytes) {
+    if (int32_t rc = CheckState(b, stream, state, size_bytes)) return rc;
+    return b->engine->ImportState(stream, state) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
 int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]) {
     if (!b) return -1;
     if (!digest) return AECM_NULL_POINTER_ERROR;

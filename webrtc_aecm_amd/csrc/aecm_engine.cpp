@@ -281,6 +281,26 @@ bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
     return true;
 }
 
+bool BatchEngine::ExportState(int stream, void *buf) {
+    if (stream < 0 || stream >= num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    uint8_t *p = static_cast<uint8_t *>(buf);
+    return AECM_HIP_OK(hipMemcpy(p, st_.vec + (size_t)stream * kVecWordsPerStream, kVecWordsPerStream * 4, hipMemcpyDeviceToHost)) &&
+           AECM_HIP_OK(hipMemcpy(p + kVecWordsPerStream * 4, st_.scal + (size_t)stream * kNumScal, kNumScal * 4, hipMemcpyDeviceToHost)) &&
+           AECM_HIP_OK(hipMemcpy(p + kVecWordsPerStream * 4 + kNumScal * 4, st_.hist + (size_t)stream * kHistWordsPerStream,
+                                 kHistWordsPerStream * 2, hipMemcpyDeviceToHost));
+}
+
+bool BatchEngine::ImportState(int stream, const void *buf) {
+    if (stream < 0 || stream >= num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    const uint8_t *p = static_cast<const uint8_t *>(buf);
+    return AECM_HIP_OK(hipMemcpy(st_.vec + (size_t)stream * kVecWordsPerStream, p, kVecWordsPerStream * 4, hipMemcpyHostToDevice)) &&
+           AECM_HIP_OK(hipMemcpy(st_.scal + (size_t)stream * kNumScal, p + kVecWordsPerStream * 4, kNumScal * 4, hipMemcpyHostToDevice)) &&
+           AECM_HIP_OK(hipMemcpy(st_.hist + (size_t)stream * kHistWordsPerStream, p + kVecWordsPerStream * 4 + kNumScal * 4,
+                                 kHistWordsPerStream * 2, hipMemcpyHostToDevice));
+}
+
 bool BatchEngine::Digest(int stream, uint32_t digest[kDigestWords]) {
     if (stream < 0 || stream >= num_streams_) return false;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;

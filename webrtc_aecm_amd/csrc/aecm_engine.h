@@ -42,6 +42,9 @@ public:
     bool SetEchoPath(int stream, const int16_t path[kBins]);
     bool GetEchoPath(int stream, int16_t path[kBins]);
     bool Digest(int stream, uint32_t digest[kDigestWords]);
+    static constexpr size_t kStateBytes = kVecWordsPerStream * 4 + kNumScal * 4 + kHistWordsPerStream * 2;
+    bool ExportState(int stream, void *buf);
+    bool ImportState(int stream, const void *buf);
     void set_variant(int v) { variant_ = v; }
 
 private:

@@ -38,7 +38,8 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_ProcessBlocksHost", "WebRtcAecmBatch_ProcessRecordings", "WebRtcAecmBatch_ProcessRecordingsHost",
     "WebRtcAecmBatch_Synchronize", "WebRtcAecmBatch_GetLastLaunchMs",
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
-    "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
+    "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
+    "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DeviceInfo",
 ]
 
@@ -100,6 +101,9 @@ def load():
     lib.WebRtcAecmBatch_ResetTimers.argtypes = [vp]
     lib.WebRtcAecmBatch_InitEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmBatch_GetEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmBatch_state_size_bytes.restype = C.c_size_t
+    lib.WebRtcAecmBatch_ExportState.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmBatch_ImportState.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmBatch_GetDigest.argtypes = [vp, C.c_int32, vp]
     lib.WebRtcAecmBatch_SetKernelVariant.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
@@ -267,6 +271,14 @@ class AecmBatch:
         d = np.zeros(DIGEST_WORDS, dtype=np.uint32)
         self._check(self.lib.WebRtcAecmBatch_GetDigest(self.h, stream, d.ctypes.data), "GetDigest")
         return d
+
+    def export_state(self, stream: int) -> bytes:
+        buf = C.create_string_buffer(self.lib.WebRtcAecmBatch_state_size_bytes())
+        self._check(self.lib.WebRtcAecmBatch_ExportState(self.h, stream, buf, len(buf)), "ExportState")
+        return buf.raw
+
+    def import_state(self, stream: int, state: bytes):
+        self._check(self.lib.WebRtcAecmBatch_ImportState(self.h, stream, state, len(state)), "ImportState")
 
     def init_echo_path(self, stream, path):
         a, p = _i16(path)
