@@ -97,6 +97,25 @@ int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *st
 /* 24-word digest of one stream's complete state (canonical order: oracle/aecm_oracle.c). */
 int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]);
 
+/* ---- Streaming batch of sessions --------------------------------------------------------------------
+ * S independent WebRtcAecm_* sessions that share one call pattern (a media server's 10 ms clock):
+ * every WebRtcAecmSessions_Tick is, for each stream s,
+ *     WebRtcAecm_BufferFarend(inst_s, far[s], nrOfSamples);
+ *     WebRtcAecm_Process(inst_s, near[s], NULL, out[s], nrOfSamples, msInSndCardBuf);
+ * (reference echo_control_mobile.h:87,135) with identical results and return code.  Audio is held in
+ * per-stream rings in HBM; the reference's jitter buffer / start-up gating / delay compensation /
+ * 80->64 re-blocking run once on the host in the index domain (csrc/aecm_sessions.h).
+ * far/near/out: [S][stream_stride] int16, device pointers (Tick) or host pointers (TickHost). */
+typedef struct AecmSessions AecmSessions;
+AecmSessions *WebRtcAecmSessions_Create(int32_t num_streams, int32_t device_id);
+void WebRtcAecmSessions_Free(AecmSessions *s);
+int32_t WebRtcAecmSessions_Init(AecmSessions *s, int32_t sampFreq);
+int32_t WebRtcAecmSessions_set_config(AecmSessions *s, AecmConfig config);
+int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev, int16_t *out_dev,
+                                int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf);
+int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host, int16_t *out_host,
+                                    int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf);
+
 /* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */
 int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
 

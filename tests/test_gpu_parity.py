@@ -217,6 +217,34 @@ def test_batched_recordings_equal_individual_sessions():
             s.close()
 
 
+def test_streaming_session_batch_ticks_equal_individual_sessions():
+    """WebRtcAecmSessions_Tick: S sessions on a common 10 ms clock, including a jittering msInSndCardBuf."""
+    rs = np.random.RandomState(9)
+    for fs, frame, cng, em in ((16000, 160, 1, 1), (8000, 80, 1, 3), (16000, 80, 0, 2), (8000, 160, 1, 4)):
+        S, secs = 4, 5
+        pairs = [synth_pair(70 + k, secs * fs // 64, fs, "mixed") for k in range(S)]
+        n_ticks = pairs[0][0].size // frame
+        far = np.stack([p[0][:n_ticks * frame] for p in pairs])
+        near = np.stack([p[1][:n_ticks * frame] for p in pairs])
+        ms_seq = [int(40 + rs.randint(-12, 13)) if i % 40 else int(rs.choice([-3, 0, 600, 90])) for i in range(n_ticks)]
+        sb = aecm.AecmSessions(S, fs, cng, em)
+        singles = []
+        for k in range(S):
+            s = aecm.Aecm()
+            assert s.init(fs) == 0 and s.set_config(cng, em) == 0
+            singles.append(s)
+        for i in range(n_ticks):
+            sl = slice(i * frame, (i + 1) * frame)
+            rc, out = sb.tick_host(far[:, sl], near[:, sl], ms_seq[i])
+            for k in (0, S - 1):
+                assert singles[k].buffer_farend(far[k, sl]) == 0
+                rc1, o1 = singles[k].process(near[k, sl], None, ms_seq[i])
+                assert rc == rc1 and np.array_equal(out[k], o1), (fs, frame, i, k)
+        for s in singles:
+            s.close()
+        sb.close()
+
+
 def _write_wav(path, rate, samples):
     import wave
     with wave.open(str(path), "wb") as w:

@@ -11,7 +11,7 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "_lib"
 LIB = LIB_DIR / "libaecm_mi355x.so"
 CLI = LIB_DIR / "aecm_run"
-SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_schedule.cpp", "aecm_capi.cpp",
+SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_schedule.cpp", "aecm_sessions.cpp", "aecm_capi.cpp",
            "aecm_host_state.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-shared"]
 

@@ -9,12 +9,17 @@
 #include "../../include/echo_control_mobile.h"
 #include "aecm_engine.h"
 #include "aecm_session.h"
+#include "aecm_sessions.h"
 
 using aecm::BatchEngine;
 using aecm::Session;
 
 struct AecmBatch {
     BatchEngine *engine;
+};
+
+struct AecmSessions {
+    aecm::SessionBatch *batch;
 };
 
 extern "C" {
@@ -237,6 +242,38 @@ int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant) {
     if (variant != AECM_KERNEL_SAFE && variant != AECM_KERNEL_FAST) return AECM_BAD_PARAMETER_ERROR;
     b->engine->set_variant(variant);
     return 0;
+}
+
+// ---- streaming batch of sessions ---------------------------------------------------------------------
+
+AecmSessions *WebRtcAecmSessions_Create(int32_t num_streams, int32_t device_id) {
+    aecm::SessionBatch *sb = aecm::SessionBatch::Create(num_streams, device_id);
+    if (!sb) return nullptr;
+    return new AecmSessions{sb};
+}
+
+void WebRtcAecmSessions_Free(AecmSessions *s) {
+    if (!s) return;
+    delete s->batch;
+    delete s;
+}
+
+int32_t WebRtcAecmSessions_Init(AecmSessions *s, int32_t sampFreq) { return s ? s->batch->Init(sampFreq) : -1; }
+
+int32_t WebRtcAecmSessions_set_config(AecmSessions *s, AecmConfig config) {
+    return s ? s->batch->SetConfig(config.cngMode, config.echoMode) : -1;
+}
+
+int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev, int16_t *out_dev,
+                                int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf) {
+    if (!s) return -1;
+    return s->batch->Tick(far_dev, near_dev, out_dev, stream_stride, (int)nrOfSamples, msInSndCardBuf, false);
+}
+
+int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host, int16_t *out_host,
+                                    int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf) {
+    if (!s) return -1;
+    return s->batch->Tick(far_host, near_host, out_host, stream_stride, (int)nrOfSamples, msInSndCardBuf, true);
 }
 
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]) {

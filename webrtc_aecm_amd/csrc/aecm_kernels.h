@@ -38,6 +38,17 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
                                 const int32_t *map_dev, int64_t n, int16_t *out, int64_t out_stride, int n_streams,
                                 hipStream_t stream);
 
+// Streaming sessions (aecm_sessions.cpp): per-stream sample rings of `ring` (power of two) elements.
+//   ring[s][(pos0 + j) & (ring-1)] = src[s*src_stride + j]                                 j in [0, n)
+hipError_t LaunchRingAppend(const int16_t *src, int64_t src_stride, int64_t n, int16_t *ring, int64_t ring_len,
+                            int64_t pos0, int n_streams, hipStream_t stream);
+//   dst[s][j] = tag[j] >= 0 ? ring[s][tag[j] & (ring-1)] : 0
+hipError_t LaunchRingGather(const int16_t *ring, int64_t ring_len, const int64_t *tags_dev, int64_t n, int16_t *dst,
+                            int64_t dst_stride, int n_streams, hipStream_t stream);
+//   out[s][j] = v >= 0 ? out_ring[s][v & (ring-1)] : (v == -1 ? 0 : near_ring[s][(-(v+2)) & (ring-1)])
+hipError_t LaunchRingAssemble(const int16_t *out_ring, const int16_t *near_ring, int64_t ring_len, const int64_t *tags_dev,
+                              int64_t n, int16_t *out, int64_t out_stride, int n_streams, hipStream_t stream);
+
 // Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
 //  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,
 //  6 isqrt31 (exhaustive over [0, 2^31) when exhaustive != 0, else 2^24 samples), 7 table upload.

@@ -145,6 +145,58 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
     return hipGetLastError();
 }
 
+// ---- streaming-session sample rings --------------------------------------------------------------------
+
+__global__ void aecm_ring_append_kernel(const int16_t *src, int64_t src_stride, int64_t n, int16_t *ring, int64_t ring_len,
+                                        int64_t pos0) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t s = blockIdx.y;
+    ring[s * ring_len + ((pos0 + j) & (ring_len - 1))] = src[s * src_stride + j];
+}
+hipError_t LaunchRingAppend(const int16_t *src, int64_t src_stride, int64_t n, int16_t *ring, int64_t ring_len,
+                            int64_t pos0, int n_streams, hipStream_t stream) {
+    if (n <= 0 || n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_ring_append_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream, src,
+                       src_stride, n, ring, ring_len, pos0);
+    return hipGetLastError();
+}
+
+__global__ void aecm_ring_gather_kernel(const int16_t *ring, int64_t ring_len, const int64_t *tags, int64_t n, int16_t *dst,
+                                        int64_t dst_stride) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t s = blockIdx.y;
+    const int64_t t = tags[j];
+    dst[s * dst_stride + j] = t >= 0 ? ring[s * ring_len + (t & (ring_len - 1))] : (int16_t)0;
+}
+hipError_t LaunchRingGather(const int16_t *ring, int64_t ring_len, const int64_t *tags_dev, int64_t n, int16_t *dst,
+                            int64_t dst_stride, int n_streams, hipStream_t stream) {
+    if (n <= 0 || n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_ring_gather_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream, ring,
+                       ring_len, tags_dev, n, dst, dst_stride);
+    return hipGetLastError();
+}
+
+__global__ void aecm_ring_assemble_kernel(const int16_t *out_ring, const int16_t *near_ring, int64_t ring_len,
+                                          const int64_t *tags, int64_t n, int16_t *out, int64_t out_stride) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t s = blockIdx.y;
+    const int64_t v = tags[j];
+    int16_t r = 0;
+    if (v >= 0) r = out_ring[s * ring_len + (v & (ring_len - 1))];
+    else if (v <= -2) r = near_ring[s * ring_len + ((-v - 2) & (ring_len - 1))];
+    out[s * out_stride + j] = r;
+}
+hipError_t LaunchRingAssemble(const int16_t *out_ring, const int16_t *near_ring, int64_t ring_len, const int64_t *tags_dev,
+                              int64_t n, int16_t *out, int64_t out_stride, int n_streams, hipStream_t stream) {
+    if (n <= 0 || n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_ring_assemble_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream,
+                       out_ring, near_ring, ring_len, tags_dev, n, out, out_stride);
+    return hipGetLastError();
+}
+
 // ---- self test of the wave primitives ------------------------------------------------------------
 
 __device__ __forceinline__ unsigned Mix(unsigned x) {

@@ -42,6 +42,10 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DeviceInfo",
 ]
+SESSIONS_SYMBOLS = [
+    "WebRtcAecmSessions_Create", "WebRtcAecmSessions_Free", "WebRtcAecmSessions_Init", "WebRtcAecmSessions_set_config",
+    "WebRtcAecmSessions_Tick", "WebRtcAecmSessions_TickHost",
+]
 
 
 class AecmConfig(C.Structure):
@@ -106,6 +110,14 @@ def load():
     lib.WebRtcAecmBatch_ImportState.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmBatch_GetDigest.argtypes = [vp, C.c_int32, vp]
     lib.WebRtcAecmBatch_SetKernelVariant.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmSessions_Create.restype = vp
+    lib.WebRtcAecmSessions_Create.argtypes = [C.c_int32, C.c_int32]
+    lib.WebRtcAecmSessions_Free.argtypes = [vp]
+    lib.WebRtcAecmSessions_Free.restype = None
+    lib.WebRtcAecmSessions_Init.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmSessions_set_config.argtypes = [vp, AecmConfig]
+    lib.WebRtcAecmSessions_Tick.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
+    lib.WebRtcAecmSessions_TickHost.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
     lib.WebRtcAecmBatch_DeviceInfo.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _lib = lib
@@ -292,6 +304,46 @@ class AecmBatch:
     def close(self):
         if getattr(self, "h", None):
             self.lib.WebRtcAecmBatch_Free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AecmSessions:
+    """S streaming sessions with a common call pattern (include/aecm_batch.h, WebRtcAecmSessions_*)."""
+
+    def __init__(self, num_streams: int, fs: int = 16000, cng_mode: int = 1, echo_mode: int = 3, device: int = 0):
+        self.lib = load()
+        self.num_streams = num_streams
+        self.h = self.lib.WebRtcAecmSessions_Create(num_streams, device)
+        if not self.h:
+            raise RuntimeError("WebRtcAecmSessions_Create failed: the HIP engine needs a usable MI355X (no CPU fallback exists)")
+        rc = self.lib.WebRtcAecmSessions_Init(self.h, fs)
+        if rc != 0:
+            raise AecmError(rc, "WebRtcAecmSessions_Init")
+        rc = self.lib.WebRtcAecmSessions_set_config(self.h, AecmConfig(cng_mode, echo_mode))
+        if rc != 0:
+            raise AecmError(rc, "WebRtcAecmSessions_set_config")
+
+    def tick_host(self, far, near, ms: int = 40):
+        """far/near: [S, n] int16 (n = 80 or 160).  Returns (code, out)."""
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        out = np.empty_like(near)
+        rc = self.lib.WebRtcAecmSessions_TickHost(self.h, far.ctypes.data, near.ctypes.data, out.ctypes.data, far.shape[1],
+                                                  far.shape[1], ms)
+        return rc, out
+
+    def tick_device(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms=40):
+        return self.lib.WebRtcAecmSessions_Tick(self.h, far_ptr, near_ptr, out_ptr, stream_stride, n, ms)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.WebRtcAecmSessions_Free(self.h)
             self.h = None
 
     def __del__(self):
