@@ -117,7 +117,13 @@ AECM_HD int pk_max_i16(int a, int b) {
 AECM_HD int max_halves_i16(int a) { return imax(sext16(a), sar(a, 16)); }
 
 // ---- generic (scalar or lane-vector) helpers built on the overload set above --------------------
+// WebRtcSpl_NormU32 / NormW32 / NormW16 (aecm/spl_inl.h:97-111): leading zeros of a (0 for a == 0) /
+// redundant sign bits of a (0 for a == 0, 31 resp. 15 for a == -1).
+#if defined(__HIP_DEVICE_COMPILE__)
+AECM_HD int norm_u32(int a) { return clz32(a) & 31; }          // clz32(0) == 32: "& 31" is the a == 0 case
+#else
 template <class I> AECM_HD I norm_u32(I a) { return sel(a == 0, I(0), clz32(a)); }
+#endif
 template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 1); }
 template <class I> AECM_HD I norm_w16(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 17); }
 template <class I> AECM_HD I add_sat32(I a, I b) {

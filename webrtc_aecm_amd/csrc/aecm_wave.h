@@ -177,24 +177,30 @@ struct BlockEngine {
             }                                                                                      \
             vi w_re, w_im;                                                                         \
             W::template twiddles<S, kInverse>(w_re, w_im);   /* (wr,-wi) and (wi,wr), packed */    \
+            /* Last stage: the caller only consumes the real parts (inverse: real_fft.c:97-99)    \
+               resp. bins 0..63 complex and the real part of bin 64 (forward: aecm_core_c.cc:297) */\
+            const bool need_im_a = !(S == 6 && kInverse), need_im_b = !(S == 6);                  \
             if (shift == 1) {                                                                      \
                 vi acc_re = dot2_i16(b, w_re, shl_add(lo16(a), 15, 32769));  /* base + T_re */     \
-                vi acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));  /* base + T_im */     \
-                /* Z = 2*base + 1 - acc with 2*base = x_a << 16 */                                 \
-                vi z_re = sub(shl_add(a, 16, 65537), acc_re);                                      \
-                vi z_im = sub((a & (int)0xffff0000) + 65537, acc_im);                              \
-                a = pack_hi16(acc_re, acc_im);                                                     \
-                b = pack_hi16(z_re, z_im);                                                         \
+                vi z_re = sub(shl_add(a, 16, 65537), acc_re);  /* Z = 2*base + 1 - acc */          \
+                vi acc_im = vi(0), z_im = vi(0);                                                   \
+                if (need_im_a) acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));            \
+                if (need_im_b) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);                  \
+                a = need_im_a ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);                       \
+                b = need_im_b ? pack_hi16(z_re, z_im) : lsr(z_re, 16);                             \
             } else {                                                                               \
-                vi t_re = dot2_i16(b, w_re, vi(1));                                                \
-                vi t_im = dot2_i16(b, w_im, vi(1));                                                \
                 const int up = 2 - shift;                    /* 16 - sh */                         \
-                t_re = shl(sar(t_re, 1), up);                                                      \
-                t_im = shl(sar(t_im, 1), up);                                                      \
+                vi t_re = shl(sar(dot2_i16(b, w_re, vi(1)), 1), up);                               \
                 vi base_re = shl(lo16(a), 14 + up) + 32768;                                        \
-                vi base_im = shl(hi16(a), 14 + up) + 32768;                                        \
-                a = pack_hi16(add(base_re, t_re), add(base_im, t_im));                             \
-                b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));                             \
+                if (need_im_a) {                                                                   \
+                    vi t_im = shl(sar(dot2_i16(b, w_im, vi(1)), 1), up);                           \
+                    vi base_im = shl(hi16(a), 14 + up) + 32768;                                    \
+                    a = pack_hi16(add(base_re, t_re), add(base_im, t_im));                         \
+                    b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));                         \
+                } else {                                                                           \
+                    a = lsr(add(base_re, t_re), 16);                                               \
+                    b = lsr(sub(base_re, t_re), 16);                                               \
+                }                                                                                  \
             }                                                                                      \
         }
         AECM_FFT_STAGE(0) AECM_FFT_STAGE(1) AECM_FFT_STAGE(2) AECM_FFT_STAGE(3)

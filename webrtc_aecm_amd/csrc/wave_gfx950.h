@@ -162,13 +162,14 @@ struct Gfx950Wave {
         }
     }
 
-    // floor(sqrt(x)) for 0 <= x <= 2^31-1: v_sqrt_f32 is within 1 ulp, float(x) within 2^-24
-    // relative, so the truncated root is off by at most one either way; two exact corrections.
+    // floor(sqrt(x)) for 0 <= x <= 2^31: v_sqrt_f32 is within 1 ulp and float(x) within 2^-24
+    // relative, i.e. the computed root is within 0.0083 of the true one; adding 0.02 (>= 0.0156 after
+    // rounding at magnitude 2^15) makes the truncation land on floor or floor + 1, so one exact
+    // downward correction suffices.  Verified exhaustively on the device by the self test.
     static __device__ __forceinline__ int isqrt31(int x) {
-        unsigned ux = (unsigned)x;
-        unsigned r = (unsigned)__builtin_amdgcn_sqrtf((float)ux);
-        r = (r * r > ux) ? r - 1 : r;
-        r = ((r + 1) * (r + 1) <= ux) ? r + 1 : r;
+        const unsigned ux = (unsigned)x;
+        unsigned r = (unsigned)(__builtin_amdgcn_sqrtf((float)ux) + 0.02f);
+        r -= (r * r > ux) ? 1u : 0u;
         return (int)r;
     }
 
