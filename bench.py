@@ -156,6 +156,10 @@ def main():
     ap.add_argument("--fs", type=int, default=16000)
     ap.add_argument("--variant", choices=["fast", "safe"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the counter gather (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None,
+                    help="force this HIP device index on every rank (only for exercising the N>1 code path on a 1-GPU box, "
+                         "with --dist-backend gloo)")
     ap.add_argument("--fixed-delay", type=int, default=-1,
                     help="WebRtcAecm_Control fixed delay (>= 0 disables the estimator's choice; 0 = no far-history reads; "
                          "used to calibrate the FETCH_SIZE counter on a known byte count)")
@@ -166,7 +170,9 @@ def main():
     import webrtc_aecm_amd as aecm
     from webrtc_aecm_amd import dist as adist
 
-    rank, local_rank, world = adist.init("nccl")
+    rank, local_rank, world = adist.init(args.dist_backend)
+    if args.device is not None:
+        local_rank = args.device
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -206,7 +212,8 @@ def main():
     kernel_ms_total, launches = batch.timers()
     assert launches == K, (launches, K)
 
-    frames, wall_max, kernel_ms_max = adist.gather_counters(S * T * K, wall, kernel_ms_total, device)
+    frames, wall_max, kernel_ms_max = adist.gather_counters(S * T * K, wall, kernel_ms_total,
+                                                            device if args.dist_backend == "nccl" else torch.device("cpu"))
     if rank == 0:
         value = frames / wall_max
         kern_avg_s = kernel_ms_total / launches / 1e3
