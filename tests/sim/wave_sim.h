@@ -42,6 +42,7 @@ SIM_BIN(sar, sar(x, y))
 SIM_BIN(lsr, lsr(x, y))
 SIM_BIN(mul, mul(x, y))
 SIM_BIN(mul24, mul24(x, y))
+SIM_BIN(mulhi_u32, mulhi_u32(x, y))
 SIM_BIN(add, add(x, y))
 SIM_BIN(sub, sub(x, y))
 SIM_BIN(imin, imin(x, y))
@@ -129,6 +130,9 @@ struct SimWave {
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
     static bool is_first_lane() { return true; }
+    static void div_magic_lanes(const vi &d, vi &magic, vi &shift) {
+        for (int i = 0; i < 64; ++i) div_magic(d.v[i], &magic.v[i], &shift.v[i]);
+    }
     static int uni(int x) { return x; }   // device: v_readfirstlane (value is wave-uniform)
 
     static vi lut(const int16_t *t, int n, const vi &idx) {

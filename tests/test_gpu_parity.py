@@ -61,6 +61,35 @@ def test_chunked_launches_equal_one_launch():
         assert np.array_equal(one.digest(s), chunked.digest(s))
 
 
+def test_ragged_batch_shapes_and_empty_calls():
+    """Stream counts that do not fill a workgroup, one-block launches, zero-block calls, bad arguments."""
+    fs = 16000
+    lib = aecm.load()
+    for S in (1, 3, 5, 67):
+        seeds = list(range(800, 800 + S))
+        far, near = synth_streams(seeds, 70, fs)
+        b = aecm.AecmBatch(S, fs)
+        outs = []
+        pos = 0
+        for n in (1, 1, 2, 63, 3):
+            outs.append(b.process_host(far[:, pos * 64:(pos + n) * 64], near[:, pos * 64:(pos + n) * 64]))
+            pos += n
+        got = np.concatenate(outs, axis=1)
+        for s in range(S):
+            exp, dig = oracle_run(seeds[s], 70, fs, 1, 3)
+            assert np.array_equal(got[s], exp), (S, s)
+            assert np.array_equal(b.digest(s), dig), (S, s)
+        z = np.zeros((S, 0), dtype=np.int16)
+        assert lib.WebRtcAecmBatch_ProcessBlocksHost(b.h, far.ctypes.data, near.ctypes.data, None, got.ctypes.data, 0, 64, 0) == 0
+        assert lib.WebRtcAecmBatch_ProcessBlocksHost(b.h, far.ctypes.data, near.ctypes.data, None, got.ctypes.data, 0, 64, -1) == 12004
+        assert lib.WebRtcAecmBatch_ProcessBlocksHost(b.h, None, near.ctypes.data, None, got.ctypes.data, 64, 64, 1) == 12003
+        assert lib.WebRtcAecmBatch_GetDigest(b.h, S, np.zeros(24, np.uint32).ctypes.data) == 12004
+        assert lib.WebRtcAecmBatch_set_config(b.h, aecm.AecmConfig(1, 9), 0, -1) == 12004
+    assert lib.WebRtcAecmBatch_Init(None, 16000) == -1
+    assert lib.WebRtcAecmBatch_Create(0, 0) is None
+    assert lib.WebRtcAecmBatch_Create(4, 99) is None            # no such device
+
+
 def test_golden_block_vectors():
     """Committed outputs + digests produced by the unmodified reference (tools/gen_golden.py)."""
     files = golden_files("block_")

@@ -126,11 +126,37 @@ template <class I> AECM_HD I norm_u32(I a) { return sel(a == 0, I(0), clz32(a));
 #endif
 template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 1); }
 template <class I> AECM_HD I norm_w16(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 17); }
+// High 32 bits of the unsigned 64-bit product                                -> v_mul_hi_u32
+AECM_HD int mulhi_u32(int a, int b) { return (int)(((uint64_t)(uint32_t)a * (uint64_t)(uint32_t)b) >> 32); }
+
+// Truncating signed division by a small positive constant divisor d (2 <= d <= 2^16) through a
+// precomputed reciprocal: with L = ceil(log2 d) and M = ceil(2^(31+L) / d) < 2^32,
+//   floor(n / d) == mulhi_u32(n, M) >> (L - 1)      for every 0 <= n <= 2^31
+// (Granlund-Montgomery: the error e = M*d - 2^(31+L) < 2^L, so n*e < 2^(31+L)).  d == 1 passes
+// magic == 0 and is returned unchanged.
+AECM_HD void div_magic(int d, int *magic, int *shift) {
+    if (d <= 1) { *magic = 0; *shift = 0; return; }
+    int L = 32 - clz32(d - 1);                                   // ceil(log2 d)
+    const uint64_t num = (uint64_t)1 << (31 + L);
+    *magic = (int)(uint32_t)((num + (uint64_t)d - 1) / (uint64_t)d);
+    *shift = L - 1;
+}
+template <class I> AECM_HD I div_by_magic(I x, I magic, I shift) {
+    I sign = sar(x, 31);
+    I n = sub(x ^ sign, sign);                                   // |x| (2^31 for INT_MIN, still in range)
+    I q = sel(magic == 0, n, lsr(mulhi_u32(n, magic), shift));
+    return sub(q ^ sign, sign);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+AECM_HD int add_sat32(int a, int b) { return __builtin_elementwise_add_sat(a, b); }   // v_add_i32 clamp
+#else
 template <class I> AECM_HD I add_sat32(I a, I b) {
     I s = add(a, b);
     auto ovf = ((a < 0) == (b < 0)) & ((a < 0) != (s < 0));
     return sel(ovf, sel(s < 0, I(0x7fffffff), I((int)0x80000000)), s);
 }
+#endif
 template <class I> AECM_HD I sat16(I v) { return imax(imin(v, I(32767)), I(-32768)); }
 // c >= 0: x * 2^c (wrapping); c < 0: arithmetic / logical right shift by -c.
 template <class I, class C> AECM_HD I shift_i(I x, C c) { return sel(c >= 0, shl(x, c), sar(x, neg(c))); }

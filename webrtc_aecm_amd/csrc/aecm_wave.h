@@ -82,7 +82,8 @@ struct BlockEngine {
         vi near_log, adapt_log, stored_log;
         // lane constants
         vi lane, brev, hann_lo, hann_hi, hann_syn_lo, hann_syn_hi, lcg_mul, lcg_add;
-        int lcg_mul64, lcg_add64;
+        vi bin_div_magic, bin_div_shift;   // reciprocal of (bin index + 1), aecm_core.cc:904
+        int lcg_mul64, lcg_add64, bin64_div_magic, bin64_div_shift;
     };
 
     struct Spectrum {
@@ -121,6 +122,8 @@ struct BlockEngine {
         }
         r.lcg_mul = a;
         r.lcg_add = c;
+        W::div_magic_lanes(r.lane + 1, r.bin_div_magic, r.bin_div_shift);
+        div_magic(65, &r.bin64_div_magic, &r.bin64_div_shift);
         r.lcg_mul64 = a64;
         r.lcg_add64 = c64;
     }
@@ -377,9 +380,10 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     // Channel update (reference aecm/aecm_core.cc:810-986)
     // ------------------------------------------------------------------------------------------
-    // NLMS step of one bin (:831-921).  kp1 = bin index + 1.
+    // NLMS step of one bin (:831-921).  div_magic_k/div_shift_k: reciprocal of (bin index + 1).
     template <class I>
-    static AECM_HD void nlms_bin(BinState<I> &s, I far, I dfa, I kp1, int dfa_noisy_q, int far_q, int mu) {
+    static AECM_HD void nlms_bin(BinState<I> &s, I far, I dfa, I div_magic_k, I div_shift_k, int dfa_noisy_q, int far_q,
+                                 int mu) {
         I zeros_ch = norm_u32(s.ch_adapt32);
         I zeros_far = norm_u32(far);
         auto safe = (zeros_ch + zeros_far) > 31;
@@ -402,7 +406,7 @@ struct BlockEngine {
         auto pos = t1 > 0;
         I t2 = mul(sar(sel(pos, t1, neg(t1)), shift_num), far);
         t2 = sel(pos, t2, neg(t2));
-        t2 = divi(t2, kp1);                                                                   // :904
+        t2 = div_by_magic(t2, div_magic_k, div_shift_k);                                      // :904  / (bin + 1)
         I shift2res = sext16(shift_num + shift_ch_far - xfa_q - mu - shl(I(30) - zeros_far, 1));
         t2 = sel(norm_w32(t2) < shift2res, I(0x7fffffff), shift_i(t2, shift2res));            // :906-912
         I n32 = add_sat32(s.ch_adapt32, t2);                                                  // :913-919
@@ -422,8 +426,8 @@ struct BlockEngine {
                                        vi &echo_est, int &echo_est64) {
         Uniform &u = r.u;
         if (mu) {
-            nlms_bin<vi>(r.b, far, dfa, r.lane + 1, u.dfa_noisy_q, far_q, mu);
-            nlms_bin<int>(r.b64, far64, dfa64, 65, u.dfa_noisy_q, far_q, mu);
+            nlms_bin<vi>(r.b, far, dfa, r.bin_div_magic, r.bin_div_shift, u.dfa_noisy_q, far_q, mu);
+            nlms_bin<int>(r.b64, far64, dfa64, r.bin64_div_magic, r.bin64_div_shift, u.dfa_noisy_q, far_q, mu);
         }
         if ((u.startup == 0) & (u.cur_vad != 0)) {                                            // :926-929
             store_adaptive_channel(r, far, far64, echo_est, echo_est64);

@@ -52,6 +52,7 @@ struct Gfx950Wave {
     static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool is_first_lane() { return lane_id() == 0; }
     static __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+    static __device__ __forceinline__ void div_magic_lanes(int d, int &magic, int &shift) { div_magic(d, &magic, &shift); }
 
     // ---- tables ----
     static __device__ __forceinline__ int hann(int i) { return g_lds[0].hann[i]; }
