@@ -140,8 +140,9 @@ def load_valu_note():
     try:
         d = json.loads(p.read_text())["derived"]
         return {"valu_insts_per_frame": round(d["valu_insts_per_frame"], 1),
-                "valu_issue_busy_frac": round(d["valu_issue_busy_frac_at_4_cycles_per_wave64_inst"], 3),
-                "source": "profiles/r01_rocprof_summary.json (rocprofv3 SQ_INSTS_VALU, GRBM_GUI_ACTIVE)"}
+                "ns_per_valu_inst_per_simd": round(d["ns_per_valu_inst_per_simd"], 2),
+                "valu_inst_cost_ns_microbench": [1.2, 1.8],
+                "source": "profiles/r01_rocprof_summary.json (rocprofv3 SQ_INSTS_VALU) + profiles/r01_valu_rate_microbench.txt"}
     except Exception:
         return None
 

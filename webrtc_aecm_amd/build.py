@@ -13,7 +13,9 @@ LIB = LIB_DIR / "libaecm_mi355x.so"
 CLI = LIB_DIR / "aecm_run"
 SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_schedule.cpp", "aecm_sessions.cpp", "aecm_capi.cpp",
            "aecm_host_state.cpp"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-shared"]
+# max-ilp machine scheduling measured +1.7 % on the VALU-bound block kernel (MI355X, 65 536 streams)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-shared",
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def _hipcc() -> str:
