@@ -201,13 +201,13 @@ def main():
         step(i)
     torch.cuda.synchronize()
     batch.reset_timers()
-    adist.barrier()
+    adist.barrier(local_rank)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
         step(W + i)
     torch.cuda.synchronize()
-    adist.barrier()
+    adist.barrier(local_rank)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     kernel_ms_total, launches = batch.timers()
@@ -240,8 +240,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.fs)
         print(json.dumps(res))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -23,16 +23,21 @@ def env_rank_world():
 
 def init(backend: str):
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    # AECM_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL path on a 1-GPU box)
+    if (world > 1 or os.environ.get("AECM_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
-def barrier():
+def barrier(device_index=None):
+    """Line the ranks up.  With the NCCL/RCCL backend the barrier runs on `device_index`."""
     if dist.is_initialized():
-        dist.barrier()
+        if device_index is not None and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device_index])
+        else:
+            dist.barrier()
 
 
 def gather_counters(frames: int, seconds: float, kernel_ms: float, device):
