@@ -239,7 +239,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.fs)
-        print(json.dumps(res))
+        # RCCL writes its version banner to C stdout; flush that first so the JSON is the last line we emit
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
