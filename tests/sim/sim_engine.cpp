@@ -75,7 +75,7 @@ bool BatchEngine::Control(int fixed_delay, int nlp, int first, int count) {
 }
 bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
     SimStore *s = Store(st_);
-    StatePtrs st{s->vec.data(), s->scal.data(), s->hist.data()};
+    StatePtrs st{s->vec.data(), s->scal.data(), s->hist.data(), nullptr};
     for (int i = 0; i < num_streams_; ++i) {
         if (io.near_clean) BlockEngine<SimWave, true>::run_stream(st, io, i, num_blocks);
         else BlockEngine<SimWave, false>::run_stream(st, io, i, num_blocks);

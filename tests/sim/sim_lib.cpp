@@ -41,10 +41,30 @@ void sim_get_echo_path(void *h, int16_t *path) {
 // n_blocks consecutive blocks; clean may be NULL.
 void sim_process(void *h, const int16_t *far_s, const int16_t *near_s, const int16_t *clean, int16_t *out, int n_blocks) {
     SimStream *s = (SimStream *)h;
-    StatePtrs st{s->img.vec.data(), s->img.scal.data(), s->hist.data()};
+    StatePtrs st{s->img.vec.data(), s->img.scal.data(), s->hist.data(), nullptr};
     IoView io{far_s, near_s, clean, out, 0, kBlock};
     if (clean) BlockEngine<SimWave, true>::run_stream(st, io, 0, n_blocks);
     else BlockEngine<SimWave, false>::run_stream(st, io, 0, n_blocks);
+}
+
+// The constants blob the HOST builds for the GPU kernels, next to the same quantities evaluated from
+// their definitions in aecm_wave.h / the simulator policy (rows: LaneConstRow order, then twiddles).
+void sim_constants(uint32_t *blob_out, uint32_t *defined_lane_rows, uint32_t *defined_twiddles) {
+    std::vector<uint32_t> blob;
+    BuildKernelConstants(&blob);
+    memcpy(blob_out, blob.data(), blob.size() * 4);
+    BlockEngine<SimWave, false>::Regs r;
+    BlockEngine<SimWave, false>::init_lane_constants(r, nullptr);
+    const VecI *rows[kLaneConstRows] = {&r.lcg_mul, &r.lcg_add, &r.bin_div_magic, &r.bin_div_shift,
+                                        &r.hann_lo, &r.hann_hi, &r.hann_syn_lo, &r.hann_syn_hi};
+    for (int k = 0; k < kLaneConstRows; ++k)
+        for (int t = 0; t < kLanes; ++t) defined_lane_rows[k * kLanes + t] = (uint32_t)rows[k]->v[t];
+    VecI wre, wim;
+    uint32_t *o = defined_twiddles;
+#define SIM_TW(INV, S) SimWave::twiddles<S, INV>(wre, wim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)wre.v[t]; *o++ = (uint32_t)wim.v[t]; }
+    SIM_TW(false, 0) SIM_TW(false, 1) SIM_TW(false, 2) SIM_TW(false, 3) SIM_TW(false, 4) SIM_TW(false, 5) SIM_TW(false, 6)
+    SIM_TW(true, 0) SIM_TW(true, 1) SIM_TW(true, 2) SIM_TW(true, 3) SIM_TW(true, 4) SIM_TW(true, 5) SIM_TW(true, 6)
+#undef SIM_TW
 }
 
 void sim_digest(void *h, uint32_t *digest) {

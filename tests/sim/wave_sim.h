@@ -127,6 +127,7 @@ struct SimTables {
 struct SimWave {
     using vi = VecI;
     using vb = VecB;
+    static constexpr bool kPrecomputedConstants = false;   // the simulator evaluates the definitions
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
     static bool is_first_lane() { return true; }

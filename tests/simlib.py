@@ -43,6 +43,7 @@ def lib():
         l.sim_get_echo_path.argtypes = [C.c_void_p, _i16p]
         l.sim_process.argtypes = [C.c_void_p, _i16p, _i16p, C.c_void_p, _i16p, C.c_int]
         l.sim_digest.argtypes = [C.c_void_p, _u32p]
+        l.sim_constants.argtypes = [_u32p, _u32p, _u32p]
         l.sim_recordings.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.simsession_create.restype = C.c_void_p
         l.simsession_free.argtypes = [C.c_void_p]
@@ -148,3 +149,12 @@ def sim_recordings(far, near, fs, frame, cng, echo_mode, ms):
     rc = lib().sim_recordings(far.shape[0], far.shape[1], fs, frame, cng, echo_mode, ms, far.ctypes.data, near.ctypes.data,
                               out.ctypes.data)
     return rc, out
+
+
+def constants():
+    """(host-built blob, lane-constant rows from their definitions, twiddle pairs from their definitions)."""
+    blob = np.zeros(8 * 64 + 2 * 7 * 64 * 2 + 360 + 66, dtype=np.uint32)
+    rows = np.zeros(8 * 64, dtype=np.uint32)
+    tw = np.zeros(2 * 7 * 64 * 2, dtype=np.uint32)
+    lib().sim_constants(blob, rows, tw)
+    return blob, rows, tw

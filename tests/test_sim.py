@@ -152,3 +152,13 @@ def test_batched_recordings_schedule_matches_reference_fixtures():
         assert s.init(fs) == 0 and s.set_config(int(g["cng"]), int(g["echo_mode"])) == 0
         exp, _ = _run(s, far2[:n], near2[:n], frame, ms)
         assert np.array_equal(out[1], exp), f.name
+
+
+def test_host_built_kernel_constants_equal_their_definitions():
+    """The GPU kernels read lane constants and LDS tables from a blob built on the host
+    (BuildKernelConstants); it must equal what aecm_wave.h / the simulator compute from the definitions."""
+    blob, rows, tw = simlib.constants()
+    assert np.array_equal(blob[:512], rows)
+    assert np.array_equal(blob[512:512 + tw.size], tw)
+    hann = blob[512 + tw.size + 360:]
+    assert hann.size == 66 and hann[0] == 0 and hann[64] == 16384

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Serving-shaped measurement: S concurrent WebRtcAecm_* sessions on a 10 ms clock
+(WebRtcAecmSessions_Tick, device-resident audio).  Reports the time per tick and how many real-time
+streams one GPU sustains.  Not the headline metric (bench.py is); a row for DESIGN.md."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=65536)
+    ap.add_argument("--fs", type=int, default=16000)
+    ap.add_argument("--ticks", type=int, default=300)
+    args = ap.parse_args()
+    import torch
+
+    import webrtc_aecm_amd as aecm
+    S, fs = args.streams, args.fs
+    n = fs // 100                                     # one 10 ms tick
+    g = torch.Generator(device="cuda").manual_seed(1)
+    far = (torch.randn((S, n * 8), generator=g, device="cuda") * 3000).clamp_(-32768, 32767).to(torch.int16)
+    near = (far.roll(37, dims=1) // 3 + (torch.randn((S, n * 8), generator=g, device="cuda") * 200).to(torch.int16))
+    out = torch.empty((S, n), dtype=torch.int16, device="cuda")
+    sess = aecm.AecmSessions(S, fs, 1, 1)
+    torch.cuda.synchronize()
+
+    def tick(i):
+        off = (i % 8) * n * 2
+        rc = sess.tick_device(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, 40)
+        assert rc == 0, rc
+    for i in range(40):                               # through the start-up phase
+        tick(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.ticks):
+        tick(40 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.ticks
+    blocks_per_tick = n / 64.0
+    print(json.dumps({"streams": S, "fs": fs, "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
+                      "realtime_streams_per_gpu": int(S * 0.010 / dt)}))
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "../../include/aecm_batch.h"
 #include "../../include/echo_control_mobile.h"
@@ -280,13 +281,19 @@ int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t
     if (!failures) return AECM_NULL_POINTER_ERROR;
     if (hipSetDevice(device_id) != hipSuccess) return AECM_UNSPECIFIED_ERROR;
     uint64_t *dev = nullptr;
+    uint32_t *consts = nullptr;
+    std::vector<uint32_t> blob;
+    aecm::BuildKernelConstants(&blob);
     if (hipMalloc((void **)&dev, 8 * sizeof(uint64_t)) != hipSuccess) return AECM_UNSPECIFIED_ERROR;
+    if (hipMalloc((void **)&consts, blob.size() * 4) != hipSuccess) { (void)hipFree(dev); return AECM_UNSPECIFIED_ERROR; }
     int32_t rc = AECM_UNSPECIFIED_ERROR;
-    if (hipMemset(dev, 0, 8 * sizeof(uint64_t)) == hipSuccess && aecm::LaunchSelfTest(dev, exhaustive, nullptr) == hipSuccess &&
+    if (hipMemcpy(consts, blob.data(), blob.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemset(dev, 0, 8 * sizeof(uint64_t)) == hipSuccess && aecm::LaunchSelfTest(dev, exhaustive, consts, nullptr) == hipSuccess &&
         hipDeviceSynchronize() == hipSuccess &&
         hipMemcpy(failures, dev, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess)
         rc = 0;
     (void)hipFree(dev);
+    (void)hipFree(consts);
     return rc;
 }
 

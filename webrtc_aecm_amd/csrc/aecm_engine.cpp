@@ -27,7 +27,14 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
               AECM_HIP_OK(hipMalloc((void **)&e->image_vec_dev_, kVecWordsPerStream * sizeof(uint32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&e->image_scal_dev_, kNumScal * sizeof(int32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&e->patch_dev_, 32 * sizeof(int32_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&e->consts_dev_, kConstBlobWords * sizeof(uint32_t))) &&
               AECM_HIP_OK(hipEventCreate(&e->ev_start_)) && AECM_HIP_OK(hipEventCreate(&e->ev_stop_));
+    if (ok) {
+        std::vector<uint32_t> blob;
+        BuildKernelConstants(&blob);
+        ok = AECM_HIP_OK(hipMemcpy(e->consts_dev_, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        e->st_.consts = e->consts_dev_;
+    }
     if (!ok) {
         delete e;
         return nullptr;
@@ -46,6 +53,7 @@ BatchEngine::~BatchEngine() {
     (void)hipFree(image_vec_dev_);
     (void)hipFree(image_scal_dev_);
     (void)hipFree(patch_dev_);
+    (void)hipFree(consts_dev_);
     (void)hipFree(stage_dev_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }

@@ -58,7 +58,8 @@ private:
     int variant_ = kVariantFast;
     int fs_ = 0;
     hipStream_t stream_ = nullptr;
-    StatePtrs st_{nullptr, nullptr, nullptr};
+    StatePtrs st_{nullptr, nullptr, nullptr, nullptr};
+    uint32_t *consts_dev_ = nullptr;     // kernel constants blob (aecm_state.h)
     uint32_t *image_vec_dev_ = nullptr;
     int32_t *image_scal_dev_ = nullptr;
     int32_t *patch_dev_ = nullptr;       // 2 x 16 ints

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 
+#include "aecm_ops.h"
 #include "aecm_tables.h"
 
 namespace aecm {
@@ -112,6 +113,44 @@ bool BuildInitImage(int fs, StreamImage *img) {
     scal[S_FIRSTVAD] = 1;
     scal[S_CNG] = 1;                                        // :423
     return ApplyConfig(scal, 1, 3);
+}
+
+void BuildKernelConstants(std::vector<uint32_t> *blob) {
+    blob->assign(kConstBlobWords, 0u);
+    uint32_t *lc = blob->data();
+    uint32_t a = 1, c = 0;
+    for (int t = 0; t < kLanes; ++t) {
+        if (t > 0) { a *= 69069u; c = c * 69069u + 1u; }      // A^t, C_t: state after t LCG steps
+        lc[LC_LCG_MUL * kLanes + t] = a;
+        lc[LC_LCG_ADD * kLanes + t] = c;
+        int magic = 0, shift = 0;
+        div_magic(t + 1, &magic, &shift);
+        lc[LC_DIV_MAGIC * kLanes + t] = (uint32_t)magic;
+        lc[LC_DIV_SHIFT * kLanes + t] = (uint32_t)shift;
+        const int brev = BitRev6(t);
+        lc[LC_HANN_LO * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[t];
+        lc[LC_HANN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - t];
+        lc[LC_HANN_SYN_LO * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[brev];
+        lc[LC_HANN_SYN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - brev];
+    }
+    // LDS image: packed twiddles (w_re = (wr, -wi), w_im = (wi, wr)) per [direction][stage][lane],
+    // wr = cos, wi = -sin (forward) / +sin (inverse) of entry m << k, m = position & (2^stage - 1)
+    // (reference complex_fft.c:296-303, 412-420); positions are bit-reversed lanes.
+    uint32_t *img = blob->data() + kLaneConstRows * kLanes;
+    for (int inverse = 0; inverse < 2; ++inverse)
+        for (int stage = 0; stage < 7; ++stage)
+            for (int t = 0; t < kLanes; ++t) {
+                const int idx = (BitRev6(t) & ((1 << stage) - 1)) << (6 - stage);
+                const int wr = kAecmTwiddleCosQ15[idx];
+                const int wi = inverse ? kAecmTwiddleSinQ15[idx] : -kAecmTwiddleSinQ15[idx];
+                uint32_t *e = img + ((inverse * 7 + stage) * kLanes + t) * 2;
+                e[0] = Pack16(wr, -wi);
+                e[1] = Pack16(wi, wr);
+            }
+    uint32_t *cs = img + kLdsTwiddleWords;
+    for (int i = 0; i < kLdsCosSinWords; ++i) cs[i] = Pack16(kAecmCosQ13[i], kAecmSinQ13[i]);
+    uint32_t *hn = cs + kLdsCosSinWords;
+    for (int i = 0; i < 65; ++i) hn[i] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[i];
 }
 
 void ComputeDigest(const uint32_t *vec, const int32_t *scal, const uint16_t *hist, uint32_t d[kDigestWords]) {

@@ -36,6 +36,9 @@ void ApplyControl(int32_t *scal, int fixed_delay, int nlp_flag);
 void SetEchoPath(uint32_t *vec, int32_t *scal, const int16_t path[kBins]);
 void GetEchoPath(const uint32_t *vec, const int32_t *scal, int16_t path[kBins]);
 
+// The read-only constants blob of the kernels (layout: aecm_state.h, kConstBlobWords words).
+void BuildKernelConstants(std::vector<uint32_t> *blob);
+
 // 24-word digest of one stream's state in the oracle's canonical order
 // (oracle/aecm_oracle.c:aecm_oracle_digest, include/aecm_batch.h).
 void ComputeDigest(const uint32_t *vec, const int32_t *scal, const uint16_t *hist, uint32_t digest[kDigestWords]);

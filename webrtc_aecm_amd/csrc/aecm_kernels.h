@@ -52,7 +52,7 @@ hipError_t LaunchRingAssemble(const int16_t *out_ring, const int16_t *near_ring,
 // Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
 //  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,
 //  6 isqrt31 (exhaustive over [0, 2^31) when exhaustive != 0, else 2^24 samples), 7 table upload.
-hipError_t LaunchSelfTest(uint64_t *counters_dev, int exhaustive, hipStream_t stream);
+hipError_t LaunchSelfTest(uint64_t *counters_dev, int exhaustive, const uint32_t *consts_dev, hipStream_t stream);
 
 }  // namespace aecm
 #endif  // AECM_AMD_KERNELS_H_

@@ -16,20 +16,11 @@
 
 namespace aecm {
 
-__device__ __forceinline__ void FillLdsTables() {
-    LdsTables &t = g_lds[0];
-    for (int i = threadIdx.x; i < 2 * 7 * 64; i += blockDim.x) {
-        const int lane = i & 63, stage = (i >> 6) % 7, inverse = i / (7 * 64);
-        int brev = 0;
-        for (int b = 0; b < 6; ++b) brev |= ((lane >> b) & 1) << (5 - b);
-        const int idx = (brev & ((1 << stage) - 1)) << (6 - stage);   // m << k in units of 8 (complex_fft.c:296,412)
-        const int wr = kAecmTwiddleCosQ15[idx];
-        const int wi = inverse ? kAecmTwiddleSinQ15[idx] : -kAecmTwiddleSinQ15[idx];
-        t.twiddle[inverse][stage][lane] = make_int2(zext16(wr) | shl(-wi, 16), zext16(wi) | shl(wr, 16));
-    }
-    for (int i = threadIdx.x; i < 360; i += blockDim.x)
-        t.cossin[i] = zext16(kAecmCosQ13[i]) | shl(kAecmSinQ13[i], 16);
-    for (int i = threadIdx.x; i < 65; i += blockDim.x) t.hann[i] = kAecmSqrtHanningQ14[i];
+// The LDS tables are an image inside the host-built constants blob: one coalesced copy per workgroup.
+__device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
+    uint32_t *lds = reinterpret_cast<uint32_t *>(&g_lds[0]);
+    const uint32_t *image = consts + kLaneConstRows * kLanes;
+    for (int i = threadIdx.x; i < kLdsImageWords; i += blockDim.x) lds[i] = image[i];
     __syncthreads();
 }
 
@@ -40,7 +31,7 @@ template <bool kFast, bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
 void aecm_process_kernel(StatePtrs st, IoView io, int n_streams,
                                                                               int n_blocks) {
-    FillLdsTables();
+    FillLdsTables(st.consts);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t stream = (int64_t)blockIdx.x * kWavesPerWorkgroup + wave;
     if (stream >= n_streams) return;
@@ -217,8 +208,8 @@ __device__ __forceinline__ void TestExchange(int va, int vb, uint64_t *fails) {
     if (a1 != ea || b1 != eb) atomicAdd((unsigned long long *)&fails[1], 1ull);
 }
 
-__global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int exhaustive) {
-    FillLdsTables();
+__global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int exhaustive, const uint32_t *consts) {
+    FillLdsTables(consts);
     using S = Gfx950Wave<false>;
     using F = Gfx950Wave<true>;
     const int lane = threadIdx.x & 63;
@@ -315,9 +306,9 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
     }
 }
 
-hipError_t LaunchSelfTest(uint64_t *counters_dev, int exhaustive, hipStream_t stream) {
+hipError_t LaunchSelfTest(uint64_t *counters_dev, int exhaustive, const uint32_t *consts_dev, hipStream_t stream) {
     hipLaunchKernelGGL(aecm_selftest_kernel, dim3(exhaustive ? 4096 : 256), dim3(256), sizeof(LdsTables), stream,
-                       counters_dev, exhaustive);
+                       counters_dev, exhaustive, consts_dev);
     return hipGetLastError();
 }
 

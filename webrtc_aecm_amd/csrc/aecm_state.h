@@ -72,10 +72,26 @@ static_assert(kNumScalUsed <= kNumScal, "scalar block overflow");
 constexpr size_t kVecWordsPerStream = size_t(kNumVec) * kLanes;
 constexpr size_t kHistWordsPerStream = size_t(kHistory) * kLanes;   // uint16 units
 
+// Read-only constants blob shared by all streams (built once on the host, aecm_host_state.cpp):
+//   rows of per-lane constants, then the image of the kernel's LDS tables.
+enum LaneConstRow : int {
+    LC_LCG_MUL = 0, LC_LCG_ADD,          // LCG jump-ahead A^t, C_t (reference spl.cc:129-147)
+    LC_DIV_MAGIC, LC_DIV_SHIFT,          // reciprocal of (bin index + 1) (aecm_core.cc:904)
+    LC_HANN_LO, LC_HANN_HI,              // analysis window hann[t], hann[64-t]
+    LC_HANN_SYN_LO, LC_HANN_SYN_HI,      // synthesis window in IFFT output lane order
+    kLaneConstRows
+};
+constexpr int kLdsTwiddleWords = 2 * 7 * kLanes * 2;   // [direction][stage][lane] (w_re, w_im)
+constexpr int kLdsCosSinWords = 360;
+constexpr int kLdsHannWords = 66;   // 65 entries + 1 pad (8-byte struct alignment)
+constexpr int kLdsImageWords = kLdsTwiddleWords + kLdsCosSinWords + kLdsHannWords;
+constexpr int kConstBlobWords = kLaneConstRows * kLanes + kLdsImageWords;
+
 struct StatePtrs {
     uint32_t *vec;
     int32_t *scal;
     uint16_t *hist;
+    const uint32_t *consts;   // kConstBlobWords words
 };
 
 // Strided view of the audio I/O of one launch: sample (stream s, block b, i) lives at

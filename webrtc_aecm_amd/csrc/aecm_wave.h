@@ -101,19 +101,35 @@ struct BlockEngine {
         return r;
     }
 
-    static AECM_HD void init_lane_constants(Regs &r) {
+    // LCG jump-ahead: after j steps seed_j = A^j * seed + C_j (mod 2^31); draw j-1 feeds bin j
+    // (reference spl.cc:129-147, aecm_core_c.cc:143-150), so lane t needs j = t, bin 64 and the
+    // carried-over seed need j = 64.
+    static constexpr uint32_t lcg_pow(int j) { uint32_t a = 1; for (int i = 0; i < j; ++i) a *= 69069u; return a; }
+    static constexpr uint32_t lcg_inc(int j) { uint32_t c = 0; for (int i = 0; i < j; ++i) c = c * 69069u + 1u; return c; }
+
+    static AECM_HD void init_lane_constants(Regs &r, const uint32_t *consts) {
         r.lane = W::lane_id();
         r.brev = bitrev6(r.lane);
+        r.lcg_mul64 = (int)lcg_pow(64);
+        r.lcg_add64 = (int)lcg_inc(64);
+        r.bin64_div_magic = (int)4228890877u;            // ceil(2^38 / 65), see div_magic()
+        r.bin64_div_shift = 6;
+        if (W::kPrecomputedConstants) {                  // device: one coalesced load per row
+            auto row = [&](int k) { return W::load_u32(consts + k * kLanes, r.lane); };
+            r.lcg_mul = row(LC_LCG_MUL); r.lcg_add = row(LC_LCG_ADD);
+            r.bin_div_magic = row(LC_DIV_MAGIC); r.bin_div_shift = row(LC_DIV_SHIFT);
+            r.hann_lo = sext16(row(LC_HANN_LO)); r.hann_hi = sext16(row(LC_HANN_HI));
+            r.hann_syn_lo = sext16(row(LC_HANN_SYN_LO)); r.hann_syn_hi = sext16(row(LC_HANN_SYN_HI));
+            return;
+        }
+        // definition (the host builds the blob from the same formulas; tests compare the two)
         r.hann_lo = sext16(W::hann(r.lane));                    // analysis window, first half : hann[t]
         r.hann_hi = sext16(W::hann(vi(64) - r.lane));           //                  second half: hann[64-t]
         r.hann_syn_lo = sext16(W::hann(r.brev));                // synthesis window in IFFT output lane order
         r.hann_syn_hi = sext16(W::hann(vi(64) - r.brev));
-        // LCG jump-ahead: after j steps seed_j = A^j * seed + C_j (mod 2^31); draw j-1 feeds bin j
-        // (reference spl.cc:129-147, aecm_core_c.cc:143-150), so lane t needs j = t, bin 64 and the
-        // carried-over seed need j = 64.
         vi a = vi(1), c = vi(0);
         int a64 = 1, c64 = 0;
-        for (int j = 1; j <= 64; ++j) {
+        for (int j = 1; j < 64; ++j) {
             a64 = mul(a64, 69069);
             c64 = add(mul(c64, 69069), 1);
             auto here = (r.lane == vi(j));
@@ -123,9 +139,6 @@ struct BlockEngine {
         r.lcg_mul = a;
         r.lcg_add = c;
         W::div_magic_lanes(r.lane + 1, r.bin_div_magic, r.bin_div_shift);
-        div_magic(65, &r.bin64_div_magic, &r.bin64_div_shift);
-        r.lcg_mul64 = a64;
-        r.lcg_add64 = c64;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -782,7 +795,7 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     static AECM_HD void run_stream(const StatePtrs &st, const IoView &io, int64_t stream, int n_blocks) {
         Regs r;
-        init_lane_constants(r);
+        init_lane_constants(r, st.consts);
         uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
         int32_t *scal = st.scal + stream * (int64_t)kNumScal;
         uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aecm_ops.h"
+#include "aecm_state.h"
 
 namespace aecm {
 
@@ -24,8 +25,9 @@ struct LdsTables {
     // conflict-free ds_read_b64 at lane*8 + constant offset, no VALU address or packing work.
     int2 twiddle[2][7][64];
     int cossin[360];   // lo16: cos Q13, hi16: sin Q13     comfort-noise phase table
-    int hann[65];      // sqrt-Hanning Q14
+    int hann[kLdsHannWords];   // sqrt-Hanning Q14 (65 entries + pad)
 };
+static_assert(sizeof(LdsTables) == kLdsImageWords * 4, "LDS image layout (aecm_state.h) out of sync");
 extern __shared__ LdsTables g_lds[];   // one instance (dynamic LDS)
 
 #define AECM_DPP(old, src, ctrl, row_mask, bank_mask, bound) \
@@ -48,6 +50,7 @@ template <bool kFast>
 struct Gfx950Wave {
     using vi = int;
     using vb = bool;
+    static constexpr bool kPrecomputedConstants = true;    // lane constants and LDS tables come from the host-built blob
 
     static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool is_first_lane() { return lane_id() == 0; }
