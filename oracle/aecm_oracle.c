@@ -157,10 +157,18 @@ static int max_abs_w16(const int16_t *v, int n) {                            /* 
 /* 128-point complex radix-2 transforms, "mode 1" (reference aecm/complex_fft.c:181-491)        */
 /* ------------------------------------------------------------------------------------------ */
 
-static unsigned bitrev7(unsigned v) {
-    unsigned r = 0;
-    for (int b = 0; b < 7; ++b) r |= ((v >> b) & 1u) << (6 - b);
-    return r;
+/* Pairs (i, bitrev7(i)) with i < bitrev7(i): exactly the 56 swaps of the reference's index_7 table
+ * (complex_fft.c:152-160), computed once instead of stored. */
+static unsigned char g_swap_a[56], g_swap_b[56];
+static int g_swap_ready = 0;
+static void init_swaps(void) {
+    int n = 0;
+    for (unsigned i = 0; i < 128; ++i) {
+        unsigned r = 0;
+        for (int b = 0; b < 7; ++b) r |= ((i >> b) & 1u) << (6 - b);
+        if (i < r) { g_swap_a[n] = (unsigned char)i; g_swap_b[n] = (unsigned char)r; ++n; }
+    }
+    g_swap_ready = 1;
 }
 
 /* In place.  Forward (complex_fft.c:241-359): every stage halves the data (net 1/128).
@@ -169,12 +177,11 @@ static unsigned bitrev7(unsigned v) {
  * The bit-reversal (complex_fft.c:181-209, table index_7 = all pairs (i, bitrev7(i)), i < rev) is
  * part of WebRtcSpl_RealForwardFFT/RealInverseFFT (real_fft.c:67,94) and is done here as well. */
 void aecm_oracle_fft128(int16_t re[128], int16_t im[128], int inverse, int *scale_out) {
-    for (unsigned i = 0; i < 128; ++i) {
-        unsigned r = bitrev7(i);
-        if (i < r) {
-            int16_t t = re[i]; re[i] = re[r]; re[r] = t;
-            t = im[i]; im[i] = im[r]; im[r] = t;
-        }
+    if (!g_swap_ready) init_swaps();
+    for (int n = 0; n < 56; ++n) {
+        const unsigned i = g_swap_a[n], r = g_swap_b[n];
+        int16_t t = re[i]; re[i] = re[r]; re[r] = t;
+        t = im[i]; im[i] = im[r]; im[r] = t;
     }
     int scale = 0;
     for (int stage = 0; stage < 7; ++stage) {
