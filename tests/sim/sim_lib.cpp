@@ -67,6 +67,34 @@ void sim_constants(uint32_t *blob_out, uint32_t *defined_lane_rows, uint32_t *de
 #undef SIM_TW
 }
 
+// One 128-point transform of the kernel's fft128 on natural-order data (re/im in, re/im out): lane t
+// starts with points t and t + 64 and ends with bins bitrev6(t) and bitrev6(t) + 64.  variant:
+// 0 = forward of real input (im ignored), 1 = forward complex, 2 = inverse.  The last stage only
+// produces what its caller consumes: forward -> im of bins >= 64 is not computed (returned as 0),
+// inverse -> real parts only.  Returns the inverse transform's accumulated scale (0 for forward).
+int sim_fft128(int16_t *re, int16_t *im, int variant) {
+    using E = BlockEngine<SimWave, false>;
+    VecI a, b;
+    for (int t = 0; t < kLanes; ++t) {
+        const int im_a = variant == 0 ? 0 : im[t], im_b = variant == 0 ? 0 : im[t + 64];
+        a.v[t] = (re[t] & 0xffff) | (int)((unsigned)im_a << 16);
+        b.v[t] = (re[t + 64] & 0xffff) | (int)((unsigned)im_b << 16);
+    }
+    int scale = 0;
+    if (variant == 0) scale = E::fft128<false, true>(a, b);
+    else if (variant == 1) scale = E::fft128<false, false>(a, b);
+    else scale = E::fft128<true, false>(a, b);
+    for (int t = 0; t < kLanes; ++t) {
+        int r = 0;
+        for (int k = 0; k < 6; ++k) r |= ((t >> k) & 1) << (5 - k);
+        re[r] = (int16_t)a.v[t];
+        re[r + 64] = (int16_t)b.v[t];
+        im[r] = variant == 2 ? (int16_t)0 : (int16_t)(a.v[t] >> 16);
+        im[r + 64] = 0;
+    }
+    return scale;
+}
+
 void sim_digest(void *h, uint32_t *digest) {
     SimStream *s = (SimStream *)h;
     ComputeDigest(s->img.vec.data(), s->img.scal.data(), s->hist.data(), digest);

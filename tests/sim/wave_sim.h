@@ -102,6 +102,11 @@ inline VecI shl_add(const VecI &a, int n, int c) {
     for (int i = 0; i < 64; ++i) r.v[i] = shl_add(a.v[i], n, c);
     return r;
 }
+inline VecI shl_add(const VecI &a, int n, const VecI &c) {
+    VecI r;
+    for (int i = 0; i < 64; ++i) r.v[i] = shl_add(a.v[i], n, c.v[i]);
+    return r;
+}
 inline VecI dot2_i16(const VecI &a, const VecI &b, const VecI &c) {
     VecI r;
     for (int i = 0; i < 64; ++i) r.v[i] = dot2_i16(a.v[i], b.v[i], c.v[i]);
@@ -178,6 +183,12 @@ struct SimWave {
     static int reduce_max(const vi &v) { int m = v.v[0]; for (int i = 1; i < 64; ++i) m = v.v[i] > m ? v.v[i] : m; return m; }
     static int reduce_min(const vi &v) { int m = v.v[0]; for (int i = 1; i < 64; ++i) m = v.v[i] < m ? v.v[i] : m; return m; }
     static int reduce_add(const vi &v) { int s = 0; for (int i = 0; i < 64; ++i) s = add(s, v.v[i]); return s; }
+    // Several independent reductions at once (the GPU merges their butterfly steps).
+    static void reduce_max2(const vi &x, const vi &y, int &rx, int &ry) { rx = reduce_max(x); ry = reduce_max(y); }
+    static void reduce_min_max(const vi &x, const vi &y, int &min_x, int &max_y) { min_x = reduce_min(x); max_y = reduce_max(y); }
+    static void reduce_add4(const vi &x, const vi &y, const vi &z, const vi &w, int &rx, int &ry, int &rz, int &rw) {
+        rx = reduce_add(x); ry = reduce_add(y); rz = reduce_add(z); rw = reduce_add(w);
+    }
     static uint64_t ballot(const vb &m) { uint64_t r = 0; for (int i = 0; i < 64; ++i) r |= (uint64_t)(m.v[i] ? 1 : 0) << i; return r; }
     static int readlane(const vi &v, int lane) { return v.v[lane & 63]; }
     static vi writelane(const vi &v, int value, int lane) { vi r = v; r.v[lane & 63] = value; return r; }

@@ -43,6 +43,7 @@ def lib():
         l.sim_get_echo_path.argtypes = [C.c_void_p, _i16p]
         l.sim_process.argtypes = [C.c_void_p, _i16p, _i16p, C.c_void_p, _i16p, C.c_int]
         l.sim_digest.argtypes = [C.c_void_p, _u32p]
+        l.sim_fft128.argtypes = [_i16p, _i16p, C.c_int]
         l.sim_constants.argtypes = [_u32p, _u32p, _u32p]
         l.sim_recordings.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.simsession_create.restype = C.c_void_p

@@ -64,6 +64,54 @@ def test_forward_fft_of_impulse_and_dc():
     assert re[0] == 6400 and np.all(re[1:] == 0) and np.all(im == 0)
 
 
+def fft_fuzz_cases(n_cases=400, seed=5):
+    """(re, im) int16 pairs covering every per-stage scaling regime of the inverse transform:
+    amplitudes from a few LSB to full scale, plus the -32768 / 32767 corner patterns."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for k in range(n_cases):
+        amp = int(2 ** rng.uniform(1, 15.2))
+        re = rng.integers(-min(amp, 32768), min(amp, 32767) + 1, 128).astype(np.int16)
+        im = rng.integers(-min(amp, 32768), min(amp, 32767) + 1, 128).astype(np.int16)
+        if k % 7 == 0:
+            re[rng.integers(0, 128, 4)] = -32768
+        if k % 11 == 0:
+            im[rng.integers(0, 128, 4)] = 32767
+        if k % 13 == 0:
+            re[:] = np.where(np.arange(128) % 2 == 0, 32767, -32768)
+        cases.append((re, im))
+    cases.append((np.full(128, -32768, np.int16), np.full(128, -32768, np.int16)))
+    cases.append((np.zeros(128, np.int16), np.zeros(128, np.int16)))
+    return cases
+
+
+@needs_ref
+def test_oracle_fft_equals_reference_complex_fft():
+    """aecm_oracle_fft128 (bit reversal + transform) against the reference's own
+    WebRtcSpl_ComplexBitReverse + WebRtcSpl_ComplexFFT / ComplexIFFT (complex_fft.c:181-491)."""
+    import ctypes as C
+    olib, rlib = pyoracle.oracle_lib(), pyoracle.ref_lib()
+    i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+    rlib.WebRtcSpl_ComplexBitReverse.argtypes = [i16p, C.c_int]
+    rlib.WebRtcSpl_ComplexFFT.argtypes = [i16p, C.c_int, C.c_int]
+    rlib.WebRtcSpl_ComplexIFFT.argtypes = [i16p, C.c_int, C.c_int]
+    shifts_seen = set()
+    for re, im in fft_fuzz_cases():
+        for inverse in (0, 1):
+            frfi = np.empty(256, dtype=np.int16)
+            frfi[0::2], frfi[1::2] = re, im
+            rlib.WebRtcSpl_ComplexBitReverse(frfi, 7)
+            ref_scale = (rlib.WebRtcSpl_ComplexIFFT if inverse else rlib.WebRtcSpl_ComplexFFT)(frfi, 7, 1)
+            ore, oim = re.copy(), im.copy()
+            scale = C.c_int(0)
+            olib.aecm_oracle_fft128(ore, oim, inverse, C.byref(scale))
+            assert np.array_equal(ore, frfi[0::2]) and np.array_equal(oim, frfi[1::2])
+            if inverse:
+                assert scale.value == ref_scale
+                shifts_seen.add(scale.value)
+    assert min(shifts_seen) == 0 and len(shifts_seen) >= 8       # from "never scales" to "scales at every stage"
+
+
 @needs_ref
 @pytest.mark.parametrize("fs", [16000, 8000])
 def test_oracle_equals_reference_on_seeded_streams(fs):

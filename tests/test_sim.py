@@ -26,6 +26,31 @@ def test_wave_dsp_equals_oracle(fs):
             assert np.array_equal(o.digest(), s.digest()), (seed, c, describe_digest_diff(o.digest(), s.digest()))
 
 
+def test_wave_fft128_equals_oracle_fft_on_arbitrary_complex_data():
+    """The kernel's fft128 (every per-stage scaling path of the inverse transform, the real-input
+    forward specialisation and the generic complex forward) against the oracle's transform, which
+    test_oracle pins to the reference's WebRtcSpl_ComplexFFT/IFFT.  The whole-block tests only ever
+    feed the inverse transform conjugate-symmetric spectra; this feeds it anything."""
+    import ctypes as C
+    from test_oracle import fft_fuzz_cases
+    olib, slib = pyoracle.oracle_lib(), simlib.lib()
+    scales = set()
+    for re, im in fft_fuzz_cases():
+        for variant in (0, 1, 2):
+            ore, oim = re.copy(), (np.zeros_like(im) if variant == 0 else im.copy())
+            scale = C.c_int(0)
+            olib.aecm_oracle_fft128(ore, oim, 1 if variant == 2 else 0, C.byref(scale))
+            sre, sim_ = re.copy(), im.copy()
+            got_scale = slib.sim_fft128(sre, sim_, variant)
+            assert np.array_equal(sre, ore), (variant,)
+            if variant != 2:
+                assert np.array_equal(sim_[:64], oim[:64]), (variant,)
+            else:
+                assert got_scale == scale.value
+                scales.add(got_scale)
+    assert min(scales) == 0 and max(scales) >= 7 and len(scales) >= 8
+
+
 def test_wave_dsp_rare_branches():
     fs = 16000
     far, near = synth_pair(100, 4200, fs, "silent")

@@ -239,6 +239,30 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
             if (F::reduce_max(v) != mx || S::reduce_max(v) != mx) bump(2);
             if (F::reduce_min(v) != mn || S::reduce_min(v) != mn) bump(2);
             if (F::reduce_add(v) != sm || S::reduce_add(v) != sm) bump(2);
+            {   // merged reductions
+                int a0, a1, a2, a3, mn2, mx2;
+                int sw = 0, mxw = (int)0x80000000, mnv = 0x7fffffff, mxq = (int)0x80000000;
+                const int q = (int)(Mix((unsigned)w) >> 1);            // >= 0 (reduce_min_max negates)
+                const int z = (int)Mix((unsigned)v ^ 0x51ed27u), u4 = (int)Mix((unsigned)w + 77u);
+                int sz = 0, su = 0;
+                for (int i = 0; i < 64; ++i) {
+                    const int xw = __shfl(w, i), xz = __shfl(z, i), xu = __shfl(u4, i), xq = __shfl(q, i), xv = __shfl(v, i);
+                    sw = add(sw, xw); sz = add(sz, xz); su = add(su, xu);
+                    mxw = xw > mxw ? xw : mxw; mnv = xv < mnv ? xv : mnv; mxq = xq > mxq ? xq : mxq;
+                }
+                F::reduce_max2(v, w, a0, a1);
+                if (a0 != mx || a1 != mxw) bump(2);
+                S::reduce_max2(v, w, a0, a1);
+                if (a0 != mx || a1 != mxw) bump(2);
+                F::reduce_min_max(v, q, mn2, mx2);
+                if (mn2 != mnv || mx2 != mxq) bump(2);
+                S::reduce_min_max(v, q, mn2, mx2);
+                if (mn2 != mnv || mx2 != mxq) bump(2);
+                F::reduce_add4(v, w, z, u4, a0, a1, a2, a3);
+                if (a0 != sm || a1 != sw || a2 != sz || a3 != su) bump(2);
+                S::reduce_add4(v, w, z, u4, a0, a1, a2, a3);
+                if (a0 != sm || a1 != sw || a2 != sz || a3 != su) bump(2);
+            }
             // 3: whole-wave shift by one lane with fill
             const int up = __shfl(v, lane == 0 ? 0 : lane - 1);
             const int expect_up = lane == 0 ? 12345 + round : up;

@@ -89,7 +89,6 @@ struct BlockEngine {
     struct Spectrum {
         vi re, im, mag;       // bins 0..63
         int re64, mag64;      // bin 64 (imaginary part is 0 by construction)
-        int sum;              // sum of |X| over the 65 bins (uint32 wrap)
         int q;                // dynamic Q of the block
     };
 
@@ -204,13 +203,31 @@ struct BlockEngine {
                 if (need_im_b) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);                  \
                 a = need_im_a ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);                       \
                 b = need_im_b ? pack_hi16(z_re, z_im) : lsr(z_re, 16);                             \
-            } else {                                                                               \
-                const int up = 2 - shift;                    /* 16 - sh */                         \
-                vi t_re = shl(sar(dot2_i16(b, w_re, vi(1)), 1), up);                               \
-                vi base_re = shl(lo16(a), 14 + up) + 32768;                                        \
+            } else if (shift == 0) {                                                               \
+                /* sh = 14 (the usual case of the inverse transform: the suppressed output is      \
+                   small).  base = (x_a << 16) + 2^15 has 15 zero low bits and (T >> 1) << 2 is    \
+                   2T with bit 1 cleared, so V = base + 2T equals Y+ except possibly in bit 1, and \
+                   Z = 2*base + 2 - V equals Y- or Y- + 2 with Y- a multiple of 4: the upper       \
+                   halves are those of Y+ and Y-. */                                               \
+                vi v_re = shl_add(dot2_i16(b, w_re, vi(1)), 1, shl_add(a, 16, 32768));             \
+                vi z_re = sub(shl_add(a, 17, 65538), v_re);                                        \
                 if (need_im_a) {                                                                   \
-                    vi t_im = shl(sar(dot2_i16(b, w_im, vi(1)), 1), up);                           \
-                    vi base_im = shl(hi16(a), 14 + up) + 32768;                                    \
+                    vi base_im = (a & (int)0xffff0000) | 32768;                                    \
+                    vi v_im = shl_add(dot2_i16(b, w_im, vi(1)), 1, base_im);                       \
+                    vi z_im = sub(shl_add(base_im, 1, 2), v_im);                                   \
+                    a = pack_hi16(v_re, v_im);                                                     \
+                    b = pack_hi16(z_re, z_im);                                                     \
+                } else {                                                                           \
+                    a = lsr(v_re, 16);                                                             \
+                    b = lsr(z_re, 16);                                                             \
+                }                                                                                  \
+            } else {                                                                               \
+                /* shift == 2, sh = 16 (rare): Y = (x_a << 14) +- (T >> 1) + 2^15 */               \
+                vi t_re = sar(dot2_i16(b, w_re, vi(1)), 1);                                        \
+                vi base_re = shl(lo16(a), 14) + 32768;                                             \
+                if (need_im_a) {                                                                   \
+                    vi t_im = sar(dot2_i16(b, w_im, vi(1)), 1);                                    \
+                    vi base_im = shl(hi16(a), 14) + 32768;                                         \
                     a = pack_hi16(add(base_re, t_re), add(base_im, t_im));                         \
                     b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));                         \
                 } else {                                                                           \
@@ -228,9 +245,12 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     // TimeToFrequencyDomain + WindowAndFFT (reference aecm/aecm_core_c.cc:166-191, 261-365)
     // ------------------------------------------------------------------------------------------
-    static AECM_HD void time_to_frequency(const Regs &r, vi old_s, vi new_s, Spectrum &sp) {
-        // dynamic Q: norm of max |x| over the 128 samples, |-32768| clamped to 32767 (:288-289)
-        int mx = imin(W::reduce_max(imax(iabs(old_s), iabs(new_s))), 32767);
+    // max_abs: max |x| over the 128 samples of the analysis window (the caller reduces the transforms
+    // of one block together, see process_block).
+    static AECM_HD vi abs_max(vi old_s, vi new_s) { return imax(iabs(old_s), iabs(new_s)); }
+    static AECM_HD void time_to_frequency(const Regs &r, vi old_s, vi new_s, int max_abs, Spectrum &sp) {
+        // dynamic Q: norm of max |x|, |-32768| clamped to 32767 (:288-289)
+        int mx = imin(max_abs, 32767);
         int q = norm_w16(mx);
         // window (:174-182): scale, truncate to int16, multiply by sqrt-Hanning Q14, truncate
         vi wo = sext16(sar(mul24(sext16(shl(old_s, q)), r.hann_lo), 14));
@@ -253,7 +273,6 @@ struct BlockEngine {
         vi sq = add(mul24(re, re), mul24(im, im));          // <= 2^31 as unsigned
         sp.mag = W::isqrt31(sq);                            // <= 46340 < 2^16
         sp.mag64 = zext16(iabs(sp.re64));
-        sp.sum = add(W::reduce_add(sp.mag), sp.mag64);
         sp.q = q;
     }
 
@@ -286,10 +305,11 @@ struct BlockEngine {
         // first minimum / maximum over the 100 means (:568-576): (mean << 7 | slot) is a total order
         vi key0 = shl(r.m0, 7) | r.lane;
         vi key1 = sel(valid1, shl(r.m1, 7) | (r.lane + 64), vi(0x7fffffff));
-        int kmin = W::reduce_min(imin(key0, key1));
+        int kmin, worst;
+        W::reduce_min_max(imin(key0, key1), imax(r.m0, sel(valid1, r.m1, vi(0))), kmin, worst);
         int best = kmin >> 7, candidate = kmin & 127;
         if (best >= kMaxBitCountsQ9) { best = kMaxBitCountsQ9; candidate = -1; }
-        int worst = imax(0, W::reduce_max(imax(r.m0, sel(valid1, r.m1, vi(0)))));
+        worst = imax(0, worst);
         int valley = worst - best;
         if (u.min_prob > kProbLowerLimit && valley > kProbMinSpread) {               // :593-606
             int thr = imax(best + kProbOffset, kProbLowerLimit);
@@ -324,15 +344,19 @@ struct BlockEngine {
     }
 
     // CalcLinearEnergies + CalcEnergies (:267-284, :644-755).  echo_est = channelStored * far.
-    static AECM_HD void calc_energies(Regs &r, vi far, int far64, int far_q, int near_energy, vi &echo_est,
+    // near / near64: the near-end magnitudes, whose sum is the reference's dfaNoisySum (aecm_core_c.cc:446).
+    static AECM_HD void calc_energies(Regs &r, vi far, int far64, int far_q, vi near, int near64, vi &echo_est,
                                       int &echo_est64) {
         Uniform &u = r.u;
-        r.near_log = W::shift_up1(r.near_log, log_energy_q8(near_energy, u.dfa_noisy_q));   // :665-669
         echo_est = mul24(r.b.ch_stored, far);
         echo_est64 = mul(r.b64.ch_stored, far64);
-        int e_far = add(W::reduce_add(far), far64);
-        int e_adapt = add(W::reduce_add(mul24(r.b.ch_adapt16, far)), mul(r.b64.ch_adapt16, far64));
-        int e_stored = add(W::reduce_add(echo_est), echo_est64);
+        int e_near, e_far, e_adapt, e_stored;            // the four uint32-wrapping sums in one pass
+        W::reduce_add4(near, far, mul24(r.b.ch_adapt16, far), echo_est, e_near, e_far, e_adapt, e_stored);
+        e_near = add(e_near, near64);
+        e_far = add(e_far, far64);
+        e_adapt = add(e_adapt, mul(r.b64.ch_adapt16, far64));
+        e_stored = add(e_stored, echo_est64);
+        r.near_log = W::shift_up1(r.near_log, log_energy_q8(e_near, u.dfa_noisy_q));        // :665-669
         u.far_log = log_energy_q8(e_far, far_q);
         r.adapt_log = W::shift_up1(r.adapt_log, log_energy_q8(e_adapt, kResChannel16 + far_q));
         r.stored_log = W::shift_up1(r.stored_log, log_energy_q8(e_stored, kResChannel16 + far_q));
@@ -660,14 +684,16 @@ struct BlockEngine {
 
         Spectrum xf, df, cf;
         AECM_PHASE_MARK(0, far_new, near_new);
-        time_to_frequency(r, r.x_old, far_new, xf);                                   // :439
+        int max_far, max_near;
+        W::reduce_max2(abs_max(r.x_old, far_new), abs_max(r.d_old, near_new), max_far, max_near);
+        time_to_frequency(r, r.x_old, far_new, max_far, xf);                          // :439
         AECM_PHASE_MARK(1, xf.mag, xf.re);
-        time_to_frequency(r, r.d_old, near_new, df);                                  // :442
+        time_to_frequency(r, r.d_old, near_new, max_near, df);                        // :442
         AECM_PHASE_MARK(2, df.mag, df.re);
         u.dfa_noisy_q_old = u.dfa_noisy_q;
         u.dfa_noisy_q = df.q;
         if (kHasClean) {                                                              // :449-464
-            time_to_frequency(r, r.c_old, clean_new, cf);
+            time_to_frequency(r, r.c_old, clean_new, W::reduce_max(abs_max(r.c_old, clean_new)), cf);
             u.dfa_clean_q_old = u.dfa_clean_q;
             u.dfa_clean_q = cf.q;
         } else {
@@ -712,7 +738,7 @@ struct BlockEngine {
         vi echo_est;
         int echo_est64;
         AECM_PHASE_MARK(5, far, r.m1);
-        calc_energies(r, far, far64, far_q, df.sum, echo_est, echo_est64);            // :498
+        calc_energies(r, far, far64, far_q, df.mag, df.mag64, echo_est, echo_est64);  // :498
         const int mu = calc_step_size(u);                                             // :503
         u.tot_count = add(u.tot_count, 1);                                            // :506
         AECM_PHASE_MARK(6, echo_est, r.near_log);

@@ -153,6 +153,56 @@ struct Gfx950Wave {
     static __device__ __forceinline__ int reduce_min(int v) { return reduce(v, 0x7fffffff, [](int a, int b) { return a < b ? a : b; }); }
     static __device__ __forceinline__ int reduce_add(int v) { return reduce(v, 0, [](int a, int b) { return add(a, b); }); }
 
+    // Several independent reductions sharing their butterfly steps.  exchange<5>(x, y) leaves
+    // a = [x lanes 0..31 | y lanes 0..31], b = [x lanes 32..63 | y lanes 32..63], so op(a, b) holds x's
+    // partials in the lower half of the wave and y's in the upper half; exchange<4> does the same
+    // across the 16-lane rows.  Then the rows are reduced in place (4 DPP steps) and read back.
+    template <class Op>
+    static __device__ __forceinline__ int reduce_row(int v, int identity, Op op) {
+        v = op(v, AECM_DPP(identity, v, kDppQuadXor1, 0xf, 0xf, true));
+        v = op(v, AECM_DPP(identity, v, kDppQuadXor2, 0xf, 0xf, true));
+        v = op(v, AECM_DPP(identity, v, kDppRowHalfMirror, 0xf, 0xf, true));
+        return op(v, AECM_DPP(identity, v, kDppRowMirror, 0xf, 0xf, true));
+    }
+    template <class Op>
+    static __device__ __forceinline__ void reduce2(int x, int y, int identity, Op op, int &rx, int &ry) {
+        if constexpr (kFast) {
+            exchange<5>(x, y);
+            int v = reduce_row(op(x, y), identity, op);
+            v = op(v, AECM_DPP(identity, v, kDppRowBcast15, 0xa, 0xf, false));   // rows 1,3 += rows 0,2
+            rx = __builtin_amdgcn_readlane(v, 31);
+            ry = __builtin_amdgcn_readlane(v, 63);
+        } else {
+            rx = reduce(x, identity, op);
+            ry = reduce(y, identity, op);
+        }
+    }
+    static __device__ __forceinline__ void reduce_max2(int x, int y, int &rx, int &ry) {
+        reduce2(x, y, (int)0x80000000, [](int a, int b) { return a > b ? a : b; }, rx, ry);
+    }
+    // min over x and max over y in one pass: max(y) = -min(-y) (y != INT_MIN: callers pass means / keys >= 0)
+    static __device__ __forceinline__ void reduce_min_max(int x, int y, int &min_x, int &max_y) {
+        int neg_max;
+        reduce2(x, neg(y), 0x7fffffff, [](int a, int b) { return a < b ? a : b; }, min_x, neg_max);
+        max_y = neg(neg_max);
+    }
+    static __device__ __forceinline__ void reduce_add4(int x, int y, int z, int w, int &rx, int &ry, int &rz, int &rw) {
+        if constexpr (kFast) {
+            exchange<5>(x, y);
+            exchange<5>(z, w);
+            int xy = add(x, y), zw = add(z, w);      // [x | y] and [z | w], 32-lane partials
+            exchange<4>(xy, zw);
+            // rows: [x, z, y, w], 16-lane partials
+            const int v = reduce_row(add(xy, zw), 0, [](int a, int b) { return add(a, b); });
+            rx = __builtin_amdgcn_readlane(v, 15);
+            rz = __builtin_amdgcn_readlane(v, 31);
+            ry = __builtin_amdgcn_readlane(v, 47);
+            rw = __builtin_amdgcn_readlane(v, 63);
+        } else {
+            rx = reduce_add(x); ry = reduce_add(y); rz = reduce_add(z); rw = reduce_add(w);
+        }
+    }
+
     static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
     static __device__ __forceinline__ int readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
     static __device__ __forceinline__ int writelane(int v, int value, int lane) { return lane_id() == lane ? value : v; }
