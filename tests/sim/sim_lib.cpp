@@ -55,10 +55,8 @@ void sim_constants(uint32_t *blob_out, uint32_t *defined_lane_rows, uint32_t *de
     memcpy(blob_out, blob.data(), blob.size() * 4);
     BlockEngine<SimWave, false>::Regs r;
     BlockEngine<SimWave, false>::init_lane_constants(r, nullptr);
-    const VecI *rows[kLaneConstRows] = {&r.lcg_mul, &r.lcg_add, &r.bin_div_magic, &r.bin_div_shift,
-                                        &r.hann_lo, &r.hann_hi, &r.hann_syn_lo, &r.hann_syn_hi};
     for (int k = 0; k < kLaneConstRows; ++k)
-        for (int t = 0; t < kLanes; ++t) defined_lane_rows[k * kLanes + t] = (uint32_t)rows[k]->v[t];
+        for (int t = 0; t < kLanes; ++t) defined_lane_rows[k * kLanes + t] = (uint32_t)r.lc[k].v[t];
     VecI wre, wim;
     uint32_t *o = defined_twiddles;
 #define SIM_TW(INV, S) SimWave::twiddles<S, INV>(wre, wim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)wre.v[t]; *o++ = (uint32_t)wim.v[t]; }

@@ -133,6 +133,9 @@ struct SimWave {
     using vi = VecI;
     using vb = VecB;
     static constexpr bool kPrecomputedConstants = false;   // the simulator evaluates the definitions
+    static constexpr bool kLaneConstsInTable = false;
+    template <int ROW> static vi table_lane_const(const vi &) { return vi(0); }   // never used (kLaneConstsInTable == false)
+    static vi table_index_for_this_block() { return vi(0); }
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
     static bool is_first_lane() { return true; }

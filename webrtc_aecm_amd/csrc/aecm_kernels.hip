@@ -19,8 +19,7 @@ namespace aecm {
 // The LDS tables are an image inside the host-built constants blob: one coalesced copy per workgroup.
 __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
     uint32_t *lds = reinterpret_cast<uint32_t *>(&g_lds[0]);
-    const uint32_t *image = consts + kLaneConstRows * kLanes;
-    for (int i = threadIdx.x; i < kLdsImageWords; i += blockDim.x) lds[i] = image[i];
+    for (int i = threadIdx.x; i < kConstBlobWords; i += blockDim.x) lds[i] = consts[i];
     __syncthreads();
 }
 

@@ -81,8 +81,9 @@ struct BlockEngine {
         vi mean_far, mean_near, bh0, bh1, m0, m1, hq0, hq1;
         vi near_log, adapt_log, stored_log;
         // lane constants
-        vi lane, brev, hann_lo, hann_hi, hann_syn_lo, hann_syn_hi, lcg_mul, lcg_add;
-        vi bin_div_magic, bin_div_shift;   // reciprocal of (bin index + 1), aecm_core.cc:904
+        vi lane, brev;
+        vi lc[kLaneConstRows];             // LaneConstRow (aecm_state.h); unused when the policy serves them from a table
+        vi table_index;                    // this lane's index into the policy's constant table, renewed every block
         int lcg_mul64, lcg_add64, bin64_div_magic, bin64_div_shift;
     };
 
@@ -113,19 +114,16 @@ struct BlockEngine {
         r.lcg_add64 = (int)lcg_inc(64);
         r.bin64_div_magic = (int)4228890877u;            // ceil(2^38 / 65), see div_magic()
         r.bin64_div_shift = 6;
+        if (W::kLaneConstsInTable) return;               // device: read from the LDS copy of the blob at each use
         if (W::kPrecomputedConstants) {                  // device: one coalesced load per row
-            auto row = [&](int k) { return W::load_u32(consts + k * kLanes, r.lane); };
-            r.lcg_mul = row(LC_LCG_MUL); r.lcg_add = row(LC_LCG_ADD);
-            r.bin_div_magic = row(LC_DIV_MAGIC); r.bin_div_shift = row(LC_DIV_SHIFT);
-            r.hann_lo = sext16(row(LC_HANN_LO)); r.hann_hi = sext16(row(LC_HANN_HI));
-            r.hann_syn_lo = sext16(row(LC_HANN_SYN_LO)); r.hann_syn_hi = sext16(row(LC_HANN_SYN_HI));
+            for (int k = 0; k < kLaneConstRows; ++k) r.lc[k] = W::load_u32(consts + k * kLanes, r.lane);
             return;
         }
         // definition (the host builds the blob from the same formulas; tests compare the two)
-        r.hann_lo = sext16(W::hann(r.lane));                    // analysis window, first half : hann[t]
-        r.hann_hi = sext16(W::hann(vi(64) - r.lane));           //                  second half: hann[64-t]
-        r.hann_syn_lo = sext16(W::hann(r.brev));                // synthesis window in IFFT output lane order
-        r.hann_syn_hi = sext16(W::hann(vi(64) - r.brev));
+        r.lc[LC_HANN_LO] = sext16(W::hann(r.lane));                 // analysis window, first half : hann[t]
+        r.lc[LC_HANN_HI] = sext16(W::hann(vi(64) - r.lane));        //                  second half: hann[64-t]
+        r.lc[LC_HANN_SYN_LO] = sext16(W::hann(r.brev));             // synthesis window in IFFT output lane order
+        r.lc[LC_HANN_SYN_HI] = sext16(W::hann(vi(64) - r.brev));
         vi a = vi(1), c = vi(0);
         int a64 = 1, c64 = 0;
         for (int j = 1; j < 64; ++j) {
@@ -135,9 +133,16 @@ struct BlockEngine {
             a = sel(here, vi(a64), a);
             c = sel(here, vi(c64), c);
         }
-        r.lcg_mul = a;
-        r.lcg_add = c;
-        W::div_magic_lanes(r.lane + 1, r.bin_div_magic, r.bin_div_shift);
+        r.lc[LC_LCG_MUL] = a;
+        r.lc[LC_LCG_ADD] = c;
+        W::div_magic_lanes(r.lane + 1, r.lc[LC_DIV_MAGIC], r.lc[LC_DIV_SHIFT]);
+    }
+
+    // Per-lane constant of row ROW (hann rows are stored sign-extended).
+    template <int ROW>
+    static AECM_HD vi lane_const(const Regs &r) {
+        if constexpr (W::kLaneConstsInTable) return W::template table_lane_const<ROW>(r.table_index);
+        else return r.lc[ROW];
     }
 
     // ------------------------------------------------------------------------------------------
@@ -253,8 +258,8 @@ struct BlockEngine {
         int mx = imin(max_abs, 32767);
         int q = norm_w16(mx);
         // window (:174-182): scale, truncate to int16, multiply by sqrt-Hanning Q14, truncate
-        vi wo = sext16(sar(mul24(sext16(shl(old_s, q)), r.hann_lo), 14));
-        vi wn = sext16(sar(mul24(sext16(shl(new_s, q)), r.hann_hi), 14));
+        vi wo = sext16(sar(mul24(sext16(shl(old_s, q)), lane_const<LC_HANN_LO>(r)), 14));
+        vi wn = sext16(sar(mul24(sext16(shl(new_s, q)), lane_const<LC_HANN_HI>(r)), 14));
         vi a = zext16(wo), b = zext16(wn);                  // packed (re, 0): imaginary input is zero (real_fft.c:59-65)
         fft128<false, true>(a, b);
         // lane t now holds X[bitrev6(t)] in a and X[bitrev6(t)+64] in b
@@ -463,7 +468,7 @@ struct BlockEngine {
                                        vi &echo_est, int &echo_est64) {
         Uniform &u = r.u;
         if (mu) {
-            nlms_bin<vi>(r.b, far, dfa, r.bin_div_magic, r.bin_div_shift, u.dfa_noisy_q, far_q, mu);
+            nlms_bin<vi>(r.b, far, dfa, lane_const<LC_DIV_MAGIC>(r), lane_const<LC_DIV_SHIFT>(r), u.dfa_noisy_q, far_q, mu);
             nlms_bin<int>(r.b64, far64, dfa64, r.bin64_div_magic, r.bin64_div_shift, u.dfa_noisy_q, far_q, mu);
         }
         if ((u.startup == 0) & (u.cur_vad != 0)) {                                            // :926-929
@@ -682,6 +687,8 @@ struct BlockEngine {
         Uniform &u = r.u;
         if (u.startup < 2) u.startup = (gtu(u.tot_count, kConvLen - 1) ? 1 : 0) + (gtu(u.tot_count, kConvLen2 - 1) ? 1 : 0);  // :420-424
 
+        if (W::kLaneConstsInTable) r.table_index = W::table_index_for_this_block();
+
         Spectrum xf, df, cf;
         AECM_PHASE_MARK(0, far_new, near_new);
         int max_far, max_near;
@@ -775,7 +782,7 @@ struct BlockEngine {
             int min_track = 9;
             if (u.noise_ctr < 100) { u.noise_ctr = sext16(u.noise_ctr + 1); min_track = 6; }
             // LCG jump-ahead: lane t gets the t-th of this block's 64 draws
-            vi st = add(mul(r.lcg_mul, vi(u.seed)), r.lcg_add) & 0x7fffffff;
+            vi st = add(mul(lane_const<LC_LCG_MUL>(r), vi(u.seed)), lane_const<LC_LCG_ADD>(r)) & 0x7fffffff;
             int s64 = add(mul(r.lcg_mul64, u.seed), r.lcg_add64) & 0x7fffffff;
             vi rnd = sext16(lsr(st, 16));
             int rnd64 = sext16(lsr(s64, 16));
@@ -805,9 +812,9 @@ struct BlockEngine {
         AECM_PHASE_MARK(11, a, b);
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
-        vi first = sext16(sar(mul24(lo16(a), r.hann_syn_lo) + 8192, 14));               // :219-221
+        vi first = sext16(sar(mul24(lo16(a), lane_const<LC_HANN_SYN_LO>(r)) + 8192, 14));               // :219-221
         vi out = sat16(add(shift_i(first, sh), r.out_ovl));                           // :222-227
-        vi second = sar(mul24(lo16(b), r.hann_syn_hi), 14);                             // :229-234
+        vi second = sar(mul24(lo16(b), lane_const<LC_HANN_SYN_HI>(r)), 14);                             // :229-234
         r.out_ovl = sat16(shift_i(second, sh));
         AECM_PHASE_MARK(12, out, r.out_ovl);
         r.x_old = far_new;                                                            // :239-245

@@ -21,14 +21,19 @@ namespace aecm {
 
 // LDS tables, filled by the kernel prologue (aecm_kernels.hip).
 struct LdsTables {
+    int lane_rows[kLaneConstRows][kLanes];   // LaneConstRow: per-lane constants (see lane_const() in aecm_wave.h)
     // Packed FFT twiddles, one (w_re, w_im) pair per [direction][stage][lane]: a stage is one
     // conflict-free ds_read_b64 at lane*8 + constant offset, no VALU address or packing work.
     int2 twiddle[2][7][64];
     int cossin[360];   // lo16: cos Q13, hi16: sin Q13     comfort-noise phase table
     int hann[kLdsHannWords];   // sqrt-Hanning Q14 (65 entries + pad)
 };
-static_assert(sizeof(LdsTables) == kLdsImageWords * 4, "LDS image layout (aecm_state.h) out of sync");
+static_assert(sizeof(LdsTables) == kConstBlobWords * 4, "LDS image layout (aecm_state.h) out of sync");
 extern __shared__ LdsTables g_lds[];   // one instance (dynamic LDS)
+
+#ifndef AECM_LANE_CONSTS_IN_LDS
+#define AECM_LANE_CONSTS_IN_LDS 1
+#endif
 
 #define AECM_DPP(old, src, ctrl, row_mask, bank_mask, bound) \
     __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), (bank_mask), (bound))
@@ -51,6 +56,18 @@ struct Gfx950Wave {
     using vi = int;
     using vb = bool;
     static constexpr bool kPrecomputedConstants = true;    // lane constants and LDS tables come from the host-built blob
+    // Per-lane constants are read from the LDS copy of the blob where they are used (one ds_read_b32
+    // each, off the VALU) instead of occupying 8 VGPRs for the whole launch.
+    static constexpr bool kLaneConstsInTable = AECM_LANE_CONSTS_IN_LDS;
+    // The index is lane_id() plus a zero the compiler cannot see through, re-made every block, so the
+    // reads stay inside the block loop next to their uses instead of being hoisted into registers.
+    static __device__ __forceinline__ int table_index_for_this_block() {
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        return lane_id() + zero;
+    }
+    template <int ROW>
+    static __device__ __forceinline__ int table_lane_const(int index) { return g_lds[0].lane_rows[ROW][index]; }
 
     static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool is_first_lane() { return lane_id() == 0; }
