@@ -63,6 +63,13 @@ void sim_constants(uint32_t *blob_out, uint32_t *defined_lane_rows, uint32_t *de
     SIM_TW(false, 0) SIM_TW(false, 1) SIM_TW(false, 2) SIM_TW(false, 3) SIM_TW(false, 4) SIM_TW(false, 5) SIM_TW(false, 6)
     SIM_TW(true, 0) SIM_TW(true, 1) SIM_TW(true, 2) SIM_TW(true, 3) SIM_TW(true, 4) SIM_TW(true, 5) SIM_TW(true, 6)
 #undef SIM_TW
+    VecI nwre, nwim, sre, cre, sim_, cim;
+#define SIM_FT(S) SimWave::fwd_twiddles<S>(wre, wim, nwre, nwim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)wre.v[t]; *o++ = (uint32_t)wim.v[t]; *o++ = (uint32_t)nwre.v[t]; *o++ = (uint32_t)nwim.v[t]; }
+    SIM_FT(1) SIM_FT(2) SIM_FT(3) SIM_FT(4) SIM_FT(5) SIM_FT(6)
+#undef SIM_FT
+#define SIM_FO(S) SimWave::fwd_offsets<S>(sre, cre, sim_, cim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)sre.v[t]; *o++ = (uint32_t)cre.v[t]; *o++ = (uint32_t)sim_.v[t]; *o++ = (uint32_t)cim.v[t]; }
+    SIM_FO(2) SIM_FO(4) SIM_FO(6)
+#undef SIM_FO
 }
 
 // One 128-point transform of the kernel's fft128 on natural-order data (re/im in, re/im out): lane t

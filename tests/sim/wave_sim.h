@@ -107,6 +107,18 @@ inline VecI shl_add(const VecI &a, int n, const VecI &c) {
     for (int i = 0; i < 64; ++i) r.v[i] = shl_add(a.v[i], n, c.v[i]);
     return r;
 }
+#define SIM_MAD16(NAME)                                                       \
+    inline VecI NAME(const VecI &a, const VecI &k, const VecI &c) {           \
+        VecI r;                                                               \
+        for (int i = 0; i < 64; ++i) r.v[i] = NAME(a.v[i], k.v[i], c.v[i]);   \
+        return r;                                                             \
+    }                                                                         \
+    inline VecI NAME(const VecI &a, const VecI &k, int c) { return NAME(a, k, VecI(c)); }
+SIM_MAD16(mad16_lo)
+SIM_MAD16(mad16_hi)
+SIM_MAD16(mad16_lo_uc)
+SIM_MAD16(mad16_hi_uc)
+#undef SIM_MAD16
 inline VecI dot2_i16(const VecI &a, const VecI &b, const VecI &c) {
     VecI r;
     for (int i = 0; i < 64; ++i) r.v[i] = dot2_i16(a.v[i], b.v[i], c.v[i]);
@@ -163,6 +175,27 @@ struct SimWave {
             const int wi = kInverse ? kAecmTwiddleSinQ15[idx] : -kAecmTwiddleSinQ15[idx];
             w_re.v[t] = (wr & 0xffff) | (int)((unsigned)(-wi) << 16);
             w_im.v[t] = (wi & 0xffff) | (int)((unsigned)wr << 16);
+        }
+    }
+    // Forward stages 1..6 in multiply-add form: the twiddles, their negations, and (even stages) the
+    // accumulator offsets s and 1 - s, s = sum of the halves of the packed twiddle (see fft128).
+    template <int S>
+    static void fwd_twiddles(vi &w_re, vi &w_im, vi &nw_re, vi &nw_im) {
+        twiddles<S, false>(w_re, w_im);
+        for (int t = 0; t < 64; ++t) {
+            nw_re.v[t] = ((-sext16(w_re.v[t])) & 0xffff) | (int)((unsigned)(-(w_re.v[t] >> 16)) << 16);
+            nw_im.v[t] = ((-sext16(w_im.v[t])) & 0xffff) | (int)((unsigned)(-(w_im.v[t] >> 16)) << 16);
+        }
+    }
+    template <int S>
+    static void fwd_offsets(vi &s_re, vi &one_minus_s_re, vi &s_im, vi &one_minus_s_im) {
+        vi w_re, w_im;
+        twiddles<S, false>(w_re, w_im);
+        for (int t = 0; t < 64; ++t) {
+            s_re.v[t] = sext16(w_re.v[t]) + (w_re.v[t] >> 16);
+            s_im.v[t] = sext16(w_im.v[t]) + (w_im.v[t] >> 16);
+            one_minus_s_re.v[t] = 1 - s_re.v[t];
+            one_minus_s_im.v[t] = 1 - s_im.v[t];
         }
     }
     static vi cos360(const vi &i) { return lut(kAecmCosQ13, 360, i); }

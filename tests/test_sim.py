@@ -186,4 +186,4 @@ def test_host_built_kernel_constants_equal_their_definitions():
     assert np.array_equal(blob[:512], rows)
     assert np.array_equal(blob[512:512 + tw.size], tw)
     hann = blob[512 + tw.size + 360:]
-    assert hann.size == 66 and hann[0] == 0 and hann[64] == 16384
+    assert hann.size == 68 and hann[0] == 0 and hann[64] == 16384

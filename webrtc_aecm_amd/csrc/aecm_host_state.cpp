@@ -147,7 +147,30 @@ void BuildKernelConstants(std::vector<uint32_t> *blob) {
                 e[0] = Pack16(wr, -wi);
                 e[1] = Pack16(wi, wr);
             }
-    uint32_t *cs = img + kLdsTwiddleWords;
+    // Forward stages 1..6 in the multiply-add form of fft128 (aecm_wave.h): (w_re, w_im, -w_re, -w_im) per
+    // lane, and for the even stages the accumulator offsets (s_re, 1 - s_re, s_im, 1 - s_im) with
+    // s = sum of the two halves of the packed twiddle.
+    uint32_t *ft = img + kLdsTwiddleWords;
+    uint32_t *fo = ft + kLdsFwdTwiddleWords;
+    for (int stage = 1; stage < 7; ++stage)
+        for (int t = 0; t < kLanes; ++t) {
+            const int idx = (BitRev6(t) & ((1 << stage) - 1)) << (6 - stage);
+            const int wr = kAecmTwiddleCosQ15[idx], wi = -kAecmTwiddleSinQ15[idx];
+            uint32_t *e = ft + ((stage - 1) * kLanes + t) * 4;
+            e[0] = Pack16(wr, -wi);
+            e[1] = Pack16(wi, wr);
+            e[2] = Pack16(-wr, wi);
+            e[3] = Pack16(-wi, -wr);
+            if ((stage & 1) == 0) {
+                uint32_t *o = fo + ((stage / 2 - 1) * kLanes + t) * 4;
+                const int s_re = wr - wi, s_im = wi + wr;
+                o[0] = (uint32_t)s_re;
+                o[1] = (uint32_t)(1 - s_re);
+                o[2] = (uint32_t)s_im;
+                o[3] = (uint32_t)(1 - s_im);
+            }
+        }
+    uint32_t *cs = fo + kLdsFwdOffsetWords;
     for (int i = 0; i < kLdsCosSinWords; ++i) cs[i] = Pack16(kAecmCosQ13[i], kAecmSinQ13[i]);
     uint32_t *hn = cs + kLdsCosSinWords;
     for (int i = 0; i < 65; ++i) hn[i] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[i];

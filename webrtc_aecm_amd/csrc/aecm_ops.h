@@ -81,6 +81,19 @@ AECM_HD int dot2_i16(int a, int b, int c) {
     return add(add(mul(sext16(a), sext16(b)), mul(sar(a, 16), sar(b, 16))), c);
 #endif
 }
+// sext(a.lo) * sext(k.lo) + c resp. sext(a.hi) * sext(k.lo) + c  (wrapping)    -> v_mad_i32_i16 (op_sel picks the half)
+// The _uc forms take a wave-uniform c (kept in an SGPR on the GPU).
+#if defined(__HIP_DEVICE_COMPILE__)
+AECM_HD int mad16_lo(int a, int k, int c) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "v"(c)); return r; }
+AECM_HD int mad16_hi(int a, int k, int c) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(a), "v"(k), "v"(c)); return r; }
+AECM_HD int mad16_lo_uc(int a, int k, int c) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "s"(c)); return r; }
+AECM_HD int mad16_hi_uc(int a, int k, int c) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(a), "v"(k), "s"(c)); return r; }
+#else
+AECM_HD int mad16_lo(int a, int k, int c) { return add(mul(sext16(a), sext16(k)), c); }
+AECM_HD int mad16_hi(int a, int k, int c) { return add(mul(sar(a, 16), sext16(k)), c); }
+AECM_HD int mad16_lo_uc(int a, int k, int c) { return mad16_lo(a, k, c); }
+AECM_HD int mad16_hi_uc(int a, int k, int c) { return mad16_hi(a, k, c); }
+#endif
 // (upper half of yr) | (upper half of yi) << 16                              -> v_perm_b32
 AECM_HD int pack_hi16(int yr, int yi) {
 #if defined(__HIP_DEVICE_COMPILE__)

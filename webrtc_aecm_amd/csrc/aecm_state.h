@@ -82,9 +82,11 @@ enum LaneConstRow : int {
     kLaneConstRows
 };
 constexpr int kLdsTwiddleWords = 2 * 7 * kLanes * 2;   // [direction][stage][lane] (w_re, w_im)
+constexpr int kLdsFwdTwiddleWords = 6 * kLanes * 4;    // forward stages 1..6: (w_re, w_im, -w_re, -w_im) per lane
+constexpr int kLdsFwdOffsetWords = 3 * kLanes * 4;     // forward stages 2,4,6: accumulator offsets (see fft128)
 constexpr int kLdsCosSinWords = 360;
-constexpr int kLdsHannWords = 66;   // 65 entries + 1 pad (8-byte struct alignment)
-constexpr int kLdsImageWords = kLdsTwiddleWords + kLdsCosSinWords + kLdsHannWords;
+constexpr int kLdsHannWords = 68;   // 65 entries + pad (16-byte struct alignment)
+constexpr int kLdsImageWords = kLdsTwiddleWords + kLdsFwdTwiddleWords + kLdsFwdOffsetWords + kLdsCosSinWords + kLdsHannWords;
 constexpr int kConstBlobWords = kLaneConstRows * kLanes + kLdsImageWords;
 
 struct StatePtrs {

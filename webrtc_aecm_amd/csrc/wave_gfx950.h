@@ -25,6 +25,10 @@ struct LdsTables {
     // Packed FFT twiddles, one (w_re, w_im) pair per [direction][stage][lane]: a stage is one
     // conflict-free ds_read_b64 at lane*8 + constant offset, no VALU address or packing work.
     int2 twiddle[2][7][64];
+    // Forward stages 1..6 in the multiply-add form of fft128: (w_re, w_im, -w_re, -w_im), one ds_read_b128;
+    // stages 2, 4, 6 additionally (s_re, 1 - s_re, s_im, 1 - s_im).
+    int4 fwd_twiddle[6][64];
+    int4 fwd_offset[3][64];
     int cossin[360];   // lo16: cos Q13, hi16: sin Q13     comfort-noise phase table
     int hann[kLdsHannWords];   // sqrt-Hanning Q14 (65 entries + pad)
 };
@@ -81,6 +85,16 @@ struct Gfx950Wave {
         const int2 w = g_lds[0].twiddle[kInverse ? 1 : 0][S][lane_id()];
         w_re = w.x;
         w_im = w.y;
+    }
+    template <int S>
+    static __device__ __forceinline__ void fwd_twiddles(int &w_re, int &w_im, int &nw_re, int &nw_im) {
+        const int4 w = g_lds[0].fwd_twiddle[S - 1][lane_id()];
+        w_re = w.x; w_im = w.y; nw_re = w.z; nw_im = w.w;
+    }
+    template <int S>
+    static __device__ __forceinline__ void fwd_offsets(int &s_re, int &one_minus_s_re, int &s_im, int &one_minus_s_im) {
+        const int4 o = g_lds[0].fwd_offset[S / 2 - 1][lane_id()];
+        s_re = o.x; one_minus_s_re = o.y; s_im = o.z; one_minus_s_im = o.w;
     }
     static __device__ __forceinline__ int cos360(int i) { return sext16(g_lds[0].cossin[i]); }
     static __device__ __forceinline__ int sin360(int i) { return g_lds[0].cossin[i] >> 16; }
