@@ -19,6 +19,16 @@
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;   \
     }
 
+#define KERNEL_SCLOB(NAME, ASM8)                                                               \
+    __global__ __launch_bounds__(256) void NAME(int *out, int iters) {                         \
+        int a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 ^ 5, a3 = a0 + 7, a4 = a0 * 5, a5 = a0 + 11, a6 = a0 ^ 9, a7 = a0 + 13; \
+        int b = blockIdx.x + 3, c = threadIdx.x & 7;                                           \
+        for (int it = 0; it < iters; ++it) {                                                   \
+            _Pragma("unroll") for (int r = 0; r < 64; ++r) { asm volatile(ASM8 OPS : "s20", "s21", "s22", "s23", "scc"); } \
+        }                                                                                      \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;   \
+    }
+
 #define F_ADD(i) "v_add_u32 %" #i ", %" #i ", %8\n"
 #define F_SUB(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
 #define F_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
@@ -111,6 +121,67 @@ KERNEL(k_bcnt, X8(F_BCNT))
 KERNEL(k_addclamp, X8(F_ADDCLAMP))
 KERNEL(k_sdwa, X8(F_SDWA))
 
+// ---- second batch: candidates for substitutions, literal operands, mixes -------------------------
+#define F_MAD16(i) "v_mad_i32_i16 %" #i ", %" #i ", %8, %9\n"
+#define F_MAD16HI(i) "v_mad_i32_i16 %" #i ", %" #i ", %8, %9 op_sel:[1,0,0,0]\n"
+#define F_DOT2(i) "v_dot2_i32_i16 %" #i ", %8, %9, %" #i "\n"
+#define F_ADDLIT(i) "v_add_u32 %" #i ", 0x8001, %" #i "\n"
+#define F_ANDLIT(i) "v_and_b32 %" #i ", 0xffff8000, %" #i "\n"
+#define F_MOVSDWA(i) "v_mov_b32_sdwa %" #i ", %" #i " dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0\n"
+#define F_ADDSDWA(i) "v_add_u32_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define F_ALIGNBIT(i) "v_alignbit_b32 %" #i ", %" #i ", %8, 15\n"
+#define F_LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", 16, %8\n"
+#define F_BFI(i) "v_bfi_b32 %" #i ", %8, %" #i ", %9\n"
+#define F_NOT(i) "v_not_b32 %" #i ", %" #i "\n"
+#define F_PKADD(i) "v_pk_add_i16 %" #i ", %" #i ", %8\n"
+#define F_MADU24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define F_SUBREV(i) "v_subrev_u32 %" #i ", %8, %" #i "\n"
+#define F_ASHR16(i) "v_ashrrev_i32 %" #i ", 16, %" #i "\n"
+#define F_MED3(i) "v_med3_i32 %" #i ", %" #i ", %8, %9\n"
+#define F_MAX3(i) "v_max3_i32 %" #i ", %" #i ", %8, %9\n"
+#define F_XAD(i) "v_xad_u32 %" #i ", %" #i ", %8, %9\n"
+#define F_ADDCO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
+#define F_CNDE64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+KERNEL(k_mad16, X8(F_MAD16))
+KERNEL(k_mad16hi, X8(F_MAD16HI))
+KERNEL(k_dot2, X8(F_DOT2))
+KERNEL(k_addlit, X8(F_ADDLIT))
+KERNEL(k_andlit, X8(F_ANDLIT))
+KERNEL(k_movsdwa, X8(F_MOVSDWA))
+KERNEL(k_addsdwa, X8(F_ADDSDWA))
+KERNEL(k_alignbit, X8(F_ALIGNBIT))
+KERNEL(k_lshlor, X8(F_LSHLOR))
+KERNEL(k_bfi, X8(F_BFI))
+KERNEL(k_not, X8(F_NOT))
+KERNEL(k_pkadd, X8(F_PKADD))
+KERNEL(k_madu24, X8(F_MADU24))
+KERNEL(k_subrev, X8(F_SUBREV))
+KERNEL(k_ashr16, X8(F_ASHR16))
+KERNEL(k_med3, X8(F_MED3))
+KERNEL(k_max3, X8(F_MAX3))
+KERNEL(k_xad, X8(F_XAD))
+KERNEL(k_addco, X8(F_ADDCO))
+KERNEL(k_cnde64, X8(F_CNDE64))
+KERNEL(k_swap32, "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                 "v_permlane32_swap_b32 %1, %2\n v_permlane32_swap_b32 %3, %4\n v_permlane32_swap_b32 %5, %6\n v_permlane32_swap_b32 %7, %0\n")
+KERNEL(k_swap16, "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                 "v_permlane16_swap_b32 %1, %2\n v_permlane16_swap_b32 %3, %4\n v_permlane16_swap_b32 %5, %6\n v_permlane16_swap_b32 %7, %0\n")
+// mixes: do the two classes simply add up?
+KERNEL(k_mix_add_shl, "v_add_u32 %0, %0, %8\n v_lshlrev_b32 %1, 3, %1\n v_add_u32 %2, %2, %8\n v_lshlrev_b32 %3, 3, %3\n"
+                      "v_add_u32 %4, %4, %8\n v_lshlrev_b32 %5, 3, %5\n v_add_u32 %6, %6, %8\n v_lshlrev_b32 %7, 3, %7\n")
+KERNEL(k_mix_add_dot, "v_add_u32 %0, %0, %8\n v_dot2c_i32_i16 %1, %8, %9\n v_add_u32 %2, %2, %8\n v_dot2c_i32_i16 %3, %8, %9\n"
+                      "v_add_u32 %4, %4, %8\n v_dot2c_i32_i16 %5, %8, %9\n v_add_u32 %6, %6, %8\n v_dot2c_i32_i16 %7, %8, %9\n")
+// dependent chain on ONE register (latency of back-to-back dependent ops from one wave; other waves fill in)
+KERNEL(k_dep_add, "v_add_u32 %0, %0, %8\n v_add_u32 %0, %0, %8\n v_add_u32 %0, %0, %8\n v_add_u32 %0, %0, %8\n"
+                  "v_add_u32 %0, %0, %8\n v_add_u32 %0, %0, %8\n v_add_u32 %0, %0, %8\n v_add_u32 %0, %0, %8\n")
+KERNEL(k_dep_shl, "v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %0, 1, %0\n"
+                  "v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %0, 1, %0\n")
+// scalar ALU and a VALU/SALU interleave
+KERNEL_SCLOB(k_salu, "s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n"
+               "s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n")
+KERNEL_SCLOB(k_valu_salu, "v_lshlrev_b32 %0, 3, %0\n s_add_u32 s20, s20, 1\n v_lshlrev_b32 %1, 3, %1\n s_add_u32 s21, s21, 1\n"
+                    "v_lshlrev_b32 %2, 3, %2\n s_add_u32 s22, s22, 1\n v_lshlrev_b32 %3, 3, %3\n s_add_u32 s23, s23, 1\n")
+
 typedef void (*kern_t)(int *, int);
 static void run(const char *name, kern_t fn, int waves_per_simd, double extra_per_8 = 0) {
     int *out;
@@ -132,7 +203,7 @@ static void run(const char *name, kern_t fn, int waves_per_simd, double extra_pe
     hipFree(out);
 }
 
-int main() {
+int main(int argc, char **argv) {
     struct { const char *n; kern_t f; double extra; } t[] = {
         {"v_add_u32", k_add, 0}, {"v_sub_u32", k_sub, 0}, {"v_and_b32", k_and, 0}, {"v_xor_b32", k_xor, 0},
         {"v_lshlrev_b32", k_shl, 0}, {"v_ashrrev_i32", k_ashr, 0}, {"v_max_i32", k_max, 0}, {"v_min_u32", k_minu, 0},
@@ -148,7 +219,22 @@ int main() {
         {"v_mov_b32_dpp", k_movdpp, 0}, {"v_max_i32_dpp", k_maxdpp, 0}, {"v_sqrt_f32", k_sqrt, 0}, {"v_cvt_f32_u32", k_cvt, 0},
         {"v_bcnt_u32_b32", k_bcnt, 0}, {"v_add_i32 clamp", k_addclamp, 0}, {"v_mul_i32_i24_sdwa", k_sdwa, 0},
     };
-    for (int w : {5})
-        for (auto &e : t) run(e.n, e.f, w, e.extra);
+    struct { const char *n; kern_t f; double extra; } t2[] = {
+        {"v_mad_i32_i16", k_mad16, 0}, {"v_mad_i32_i16 op_sel hi", k_mad16hi, 0}, {"v_dot2_i32_i16 (VOP3P)", k_dot2, 0},
+        {"v_add_u32 literal", k_addlit, 0}, {"v_and_b32 literal", k_andlit, 0}, {"v_mov_b32_sdwa", k_movsdwa, 0},
+        {"v_add_u32_sdwa", k_addsdwa, 0}, {"v_alignbit_b32", k_alignbit, 0}, {"v_lshl_or_b32", k_lshlor, 0}, {"v_bfi_b32", k_bfi, 0},
+        {"v_not_b32", k_not, 0}, {"v_pk_add_i16", k_pkadd, 0}, {"v_mad_u32_u24", k_madu24, 0}, {"v_subrev_u32", k_subrev, 0},
+        {"v_ashrrev_i32 16", k_ashr16, 0}, {"v_med3_i32", k_med3, 0}, {"v_max3_i32", k_max3, 0}, {"v_xad_u32", k_xad, 0},
+        {"v_add_co_u32", k_addco, 0}, {"v_cndmask_b32_e64 sgpr", k_cnde64, 0}, {"v_permlane32_swap", k_swap32, 0},
+        {"v_permlane16_swap", k_swap16, 0}, {"mix add/lshl", k_mix_add_shl, 0}, {"mix add/dot2c", k_mix_add_dot, 0},
+        {"dependent v_add chain", k_dep_add, 0}, {"dependent v_lshl chain", k_dep_shl, 0}, {"s_add_u32", k_salu, 0},
+        {"v_lshl + s_add interleaved (per pair)", k_valu_salu, -4},
+    };
+    const bool second = argc > 1 && !strcmp(argv[1], "--batch2");
+    if (!second)
+        for (auto &e : t) run(e.n, e.f, 5, e.extra);
+    else
+        for (int w : {1, 2, 6})
+            for (auto &e : t2) run(e.n, e.f, w, e.extra);
     return 0;
 }
