@@ -25,7 +25,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     far = (torch.randn((S, n * 8), generator=g, device="cuda") * 3000).clamp_(-32768, 32767).to(torch.int16)
     near = (far.roll(37, dims=1) // 3 + (torch.randn((S, n * 8), generator=g, device="cuda") * 200).to(torch.int16))
-    out = torch.empty((S, n), dtype=torch.int16, device="cuda")
+    out = torch.empty_like(far)                       # Tick() uses ONE row stride for far, near and out
     sess = aecm.AecmSessions(S, fs, 1, 1)
     torch.cuda.synchronize()
 
