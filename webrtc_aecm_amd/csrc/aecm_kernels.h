@@ -9,7 +9,10 @@
 
 namespace aecm {
 
-constexpr int kWavesPerWorkgroup = 4;    // 256 threads: 4 streams share one copy of the LDS tables
+#ifndef AECM_WAVES_PER_WORKGROUP
+#define AECM_WAVES_PER_WORKGROUP 4
+#endif
+constexpr int kWavesPerWorkgroup = AECM_WAVES_PER_WORKGROUP;    // 256 threads: 4 streams share one copy of the LDS tables
 
 enum KernelVariant : int {
     kVariantSafe = 0,   // ds_bpermute shuffles only
@@ -38,16 +41,31 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
                                 const int32_t *map_dev, int64_t n, int16_t *out, int64_t out_stride, int n_streams,
                                 hipStream_t stream);
 
-// Streaming sessions (aecm_sessions.cpp): per-stream sample rings of `ring` (power of two) elements.
-//   ring[s][(pos0 + j) & (ring-1)] = src[s*src_stride + j]                                 j in [0, n)
-hipError_t LaunchRingAppend(const int16_t *src, int64_t src_stride, int64_t n, int16_t *ring, int64_t ring_len,
-                            int64_t pos0, int n_streams, hipStream_t stream);
-//   dst[s][j] = tag[j] >= 0 ? ring[s][tag[j] & (ring-1)] : 0
-hipError_t LaunchRingGather(const int16_t *ring, int64_t ring_len, const int64_t *tags_dev, int64_t n, int16_t *dst,
-                            int64_t dst_stride, int n_streams, hipStream_t stream);
-//   out[s][j] = v >= 0 ? out_ring[s][v & (ring-1)] : (v == -1 ? 0 : near_ring[s][(-(v+2)) & (ring-1)])
-hipError_t LaunchRingAssemble(const int16_t *out_ring, const int16_t *near_ring, int64_t ring_len, const int64_t *tags_dev,
-                              int64_t n, int16_t *out, int64_t out_stride, int n_streams, hipStream_t stream);
+// Streaming sessions (aecm_sessions.cpp): per-stream sample rings of `ring_len` (power of two) elements.
+// A tick is three launches: prepare -> LaunchProcessBlocks -> finish.  Where each sample comes from is
+// decided on the host (SessionFlow in the index domain) and travels as kernel arguments, one int32
+// source code per sample: -1 = zero, else (kind << 28) | index.
+constexpr int kTickMaxBlockSamples = 256;   // <= 4 blocks per tick
+constexpr int kTickMaxSamples = 160;
+enum TickSource : int32_t {
+    kTickFromInput = 0,      // gather: this tick's far/near input row          assemble: this tick's block outputs
+    kTickFromRing = 1,       // gather: the far/near ring                       assemble: the output ring
+    kTickNearInput = 2,      //                                                 assemble: this tick's near input (pass-through)
+    kTickNearRing = 3        //                                                 assemble: the near ring (pass-through)
+};
+struct TickGatherCodes { int32_t far[kTickMaxBlockSamples], near[kTickMaxBlockSamples]; };
+struct TickAssembleCodes { int32_t out[kTickMaxSamples]; };
+// prepare: append the tick's n far/near samples to the rings (at far_pos / near_pos) and gather the
+// tick's nb blocks: bfar/bnear[s][j] for j in [0, nb*64).
+hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, int64_t in_stride, int n, int16_t *far_ring,
+                             int16_t *near_ring, int64_t ring_len, int64_t far_pos, int64_t near_pos, int16_t *bfar,
+                             int16_t *bnear, int n_block_samples, const TickGatherCodes &codes, int n_streams,
+                             hipStream_t stream);
+// finish: append the nb*64 block outputs to the output ring (at out_pos) and assemble the tick's n
+// output samples.
+hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *out_ring, const int16_t *near_ring,
+                            int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride, int16_t *out,
+                            int n, const TickAssembleCodes &codes, int n_streams, hipStream_t stream);
 
 // Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
 //  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,

@@ -137,53 +137,71 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
 
 // ---- streaming-session sample rings --------------------------------------------------------------------
 
-__global__ void aecm_ring_append_kernel(const int16_t *src, int64_t src_stride, int64_t n, int16_t *ring, int64_t ring_len,
-                                        int64_t pos0) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int64_t s = blockIdx.y;
-    ring[s * ring_len + ((pos0 + j) & (ring_len - 1))] = src[s * src_stride + j];
+__global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *near_in, int64_t in_stride, int n,
+                                         int16_t *far_ring, int16_t *near_ring, int64_t ring_len, int64_t far_pos,
+                                         int64_t near_pos, int16_t *bfar, int16_t *bnear, int nbs, int n_streams,
+                                         TickGatherCodes codes) {
+    // one wavefront per stream (4 streams per workgroup), lanes stride over the samples
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
+    if (s >= n_streams) return;
+    const int16_t *fin = far_in + s * in_stride, *nin = near_in + s * in_stride;
+    int16_t *fr = far_ring + s * ring_len, *nr = near_ring + s * ring_len;
+    const int64_t mask = ring_len - 1;
+    // reads of ring entries never alias this tick's appends: in-tick samples come from the input rows
+    for (int j = threadIdx.x & 63; j < nbs; j += 64) {
+        const int cf = codes.far[j], cn = codes.near[j];
+        const int idf = cf & 0x0fffffff, idn = cn & 0x0fffffff;
+        bfar[s * nbs + j] = cf < 0 ? (int16_t)0 : ((cf >> 28) == kTickFromInput ? fin[idf] : fr[idf]);
+        bnear[s * nbs + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? nin[idn] : nr[idn]);
+    }
+    for (int j = threadIdx.x & 63; j < n; j += 64) {
+        fr[(far_pos + j) & mask] = fin[j];
+        nr[(near_pos + j) & mask] = nin[j];
+    }
 }
-hipError_t LaunchRingAppend(const int16_t *src, int64_t src_stride, int64_t n, int16_t *ring, int64_t ring_len,
-                            int64_t pos0, int n_streams, hipStream_t stream) {
-    if (n <= 0 || n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_ring_append_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream, src,
-                       src_stride, n, ring, ring_len, pos0);
+hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, int64_t in_stride, int n, int16_t *far_ring,
+                             int16_t *near_ring, int64_t ring_len, int64_t far_pos, int64_t near_pos, int16_t *bfar,
+                             int16_t *bnear, int n_block_samples, const TickGatherCodes &codes, int n_streams,
+                             hipStream_t stream) {
+    if (n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_tick_prepare_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
+                       dim3(64 * kWavesPerWorkgroup), 0, stream, far_in, near_in, in_stride, n, far_ring, near_ring, ring_len,
+                       far_pos, near_pos, bfar, bnear, n_block_samples, n_streams, codes);
     return hipGetLastError();
 }
 
-__global__ void aecm_ring_gather_kernel(const int16_t *ring, int64_t ring_len, const int64_t *tags, int64_t n, int16_t *dst,
-                                        int64_t dst_stride) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int64_t s = blockIdx.y;
-    const int64_t t = tags[j];
-    dst[s * dst_stride + j] = t >= 0 ? ring[s * ring_len + (t & (ring_len - 1))] : (int16_t)0;
+__global__ void aecm_tick_finish_kernel(const int16_t *bout, int nbs, int16_t *out_ring, const int16_t *near_ring,
+                                        int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride,
+                                        int16_t *out, int n, int n_streams, TickAssembleCodes codes) {
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
+    if (s >= n_streams) return;
+    const int16_t *bo = bout + s * nbs;
+    int16_t *ring = out_ring + s * ring_len;
+    const int64_t mask = ring_len - 1;
+    // in-tick block outputs are read from bout, so the ring reads never alias the appends below
+    for (int j = threadIdx.x & 63; j < n; j += 64) {
+        const int c = codes.out[j];
+        const int idx = c & 0x0fffffff;
+        int16_t r = 0;
+        if (c >= 0) {
+            switch (c >> 28) {
+                case kTickFromInput: r = bo[idx]; break;
+                case kTickFromRing: r = ring[idx]; break;
+                case kTickNearInput: r = near_in[s * io_stride + idx]; break;
+                default: r = near_ring[s * ring_len + idx]; break;
+            }
+        }
+        out[s * io_stride + j] = r;
+    }
+    for (int j = threadIdx.x & 63; j < nbs; j += 64) ring[(out_pos + j) & mask] = bo[j];
 }
-hipError_t LaunchRingGather(const int16_t *ring, int64_t ring_len, const int64_t *tags_dev, int64_t n, int16_t *dst,
-                            int64_t dst_stride, int n_streams, hipStream_t stream) {
-    if (n <= 0 || n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_ring_gather_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream, ring,
-                       ring_len, tags_dev, n, dst, dst_stride);
-    return hipGetLastError();
-}
-
-__global__ void aecm_ring_assemble_kernel(const int16_t *out_ring, const int16_t *near_ring, int64_t ring_len,
-                                          const int64_t *tags, int64_t n, int16_t *out, int64_t out_stride) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int64_t s = blockIdx.y;
-    const int64_t v = tags[j];
-    int16_t r = 0;
-    if (v >= 0) r = out_ring[s * ring_len + (v & (ring_len - 1))];
-    else if (v <= -2) r = near_ring[s * ring_len + ((-v - 2) & (ring_len - 1))];
-    out[s * out_stride + j] = r;
-}
-hipError_t LaunchRingAssemble(const int16_t *out_ring, const int16_t *near_ring, int64_t ring_len, const int64_t *tags_dev,
-                              int64_t n, int16_t *out, int64_t out_stride, int n_streams, hipStream_t stream) {
-    if (n <= 0 || n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_ring_assemble_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream,
-                       out_ring, near_ring, ring_len, tags_dev, n, out, out_stride);
+hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *out_ring, const int16_t *near_ring,
+                            int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride, int16_t *out,
+                            int n, const TickAssembleCodes &codes, int n_streams, hipStream_t stream) {
+    if (n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_tick_finish_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
+                       dim3(64 * kWavesPerWorkgroup), 0, stream, bout, n_block_samples, out_ring, near_ring, ring_len, out_pos,
+                       near_in, io_stride, out, n, n_streams, codes);
     return hipGetLastError();
 }
 

@@ -19,7 +19,6 @@ SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
               AECM_HIP_OK(hipMalloc((void **)&b->near_ring_, S * kRing * 2)) &&
               AECM_HIP_OK(hipMalloc((void **)&b->out_ring_, S * kRing * 2)) &&
               AECM_HIP_OK(hipMalloc((void **)&b->blk_, 3 * S * 4 * kBlock * 2)) &&
-              AECM_HIP_OK(hipMalloc((void **)&b->tags_dev_, (256 + 256 + 160) * sizeof(int64_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&b->io_dev_, 3 * S * 160 * 2));
     if (!ok) {
         delete b;
@@ -35,7 +34,6 @@ SessionBatch::~SessionBatch() {
     (void)hipFree(near_ring_);
     (void)hipFree(out_ring_);
     (void)hipFree(blk_);
-    (void)hipFree(tags_dev_);
     (void)hipFree(io_dev_);
 }
 
@@ -82,60 +80,74 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, int16_t *out
         dnear = d;
         dout = io_dev_ + 2 * (size_t)S * 160;
     }
-    // 1. the tick's samples into the rings; their tags are absolute sample counts
-    if (!AECM_HIP_OK(LaunchRingAppend(dfar, dstride, n, far_ring_, kRing, far_pos_, S, st)) ||
-        !AECM_HIP_OK(LaunchRingAppend(dnear, dstride, n, near_ring_, kRing, near_pos_, S, st)))
-        return AECM_UNSPECIFIED_ERROR;
-    int64_t far_tags[160], near_tags[160], out_tags[160];
+    // 1. the session machinery in the index domain; a tag is the absolute sample count of a far / near
+    //    sample, the tick's samples are [far_pos_, far_pos_ + n) and [near_pos_, near_pos_ + n)
+    int64_t far_tags[kTickMaxSamples], near_tags[kTickMaxSamples], out_tags[kTickMaxSamples];
     for (int i = 0; i < n; ++i) { far_tags[i] = far_pos_ + i; near_tags[i] = near_pos_ + i; }
-    // 2. the session machinery in the index domain
     int32_t rc = flow_.BufferFarend(far_tags, (size_t)n);
     if (rc != 0) return rc;
-    far_pos_ += n;
-    int64_t blk_far[256], blk_near[256];
+    int64_t blk_far[kTickMaxBlockSamples], blk_near[kTickMaxBlockSamples];
     int n_blocks = 0;
     bool passthrough = false, stale = false;
+    const int64_t out_base = blocks_done_ * kBlock;
     rc = flow_.Process(near_tags, nullptr, out_tags, (size_t)n, ms,
                        [&](const int64_t *fb, const int64_t *nb, const int64_t *, int64_t *ob, int nblk) {
                            memcpy(blk_far, fb, sizeof(int64_t) * nblk * kBlock);
                            memcpy(blk_near, nb, sizeof(int64_t) * nblk * kBlock);
-                           for (int k = 0; k < nblk * kBlock; ++k) ob[k] = blocks_done_ * kBlock + k;
+                           for (int k = 0; k < nblk * kBlock; ++k) ob[k] = out_base + k;
                            n_blocks = nblk;
                            return true;
                        },
                        &passthrough);
-    near_pos_ += n;
-    if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) return rc;
+    if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) {
+        // the far samples were consumed by BufferFarend: keep the rings in step with the flow
+        TickGatherCodes none;
+        if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dstride, n, far_ring_, near_ring_, kRing, far_pos_, near_pos_,
+                                           blk_, blk_, 0, none, S, st)))
+            return AECM_UNSPECIFIED_ERROR;
+        far_pos_ += n;
+        near_pos_ += n;
+        return rc;
+    }
     if (passthrough)
         for (int i = 0; i < n; ++i) out_tags[i] = -(out_tags[i] + 2);
-    // every tag must still be inside its ring
-    for (int k = 0; k < n_blocks * kBlock; ++k)
-        stale |= (blk_far[k] >= 0 && far_pos_ - blk_far[k] > kRing) || (blk_near[k] >= 0 && near_pos_ - blk_near[k] > kRing);
-    const int64_t out_head = (blocks_done_ + n_blocks) * kBlock;
+    // 2. every sample's source as a code the kernels understand; every tag must still be inside its ring
+    const int nbs = n_blocks * kBlock;
+    const int64_t far_end = far_pos_ + n, near_end = near_pos_ + n, out_end = out_base + nbs;
+    auto code = [&](int64_t tag, int64_t first_of_tick, int64_t end, int kind_now, int kind_ring) -> int32_t {
+        if (tag < 0) return -1;
+        if (end - tag > kRing) stale = true;
+        if (tag >= first_of_tick) return (int32_t)((kind_now << 28) | (int32_t)(tag - first_of_tick));
+        return (int32_t)((kind_ring << 28) | (int32_t)(tag & (kRing - 1)));
+    };
+    TickGatherCodes gather;
+    for (int k = 0; k < nbs; ++k) {
+        gather.far[k] = code(blk_far[k], far_pos_, far_end, kTickFromInput, kTickFromRing);
+        gather.near[k] = code(blk_near[k], near_pos_, near_end, kTickFromInput, kTickFromRing);
+    }
+    TickAssembleCodes assemble;
     for (int i = 0; i < n; ++i) {
         const int64_t v = out_tags[i];
-        stale |= (v >= 0 && out_head - v > kRing) || (v <= -2 && near_pos_ - (-v - 2) > kRing);
+        assemble.out[i] = v >= 0    ? code(v, out_base, out_end, kTickFromInput, kTickFromRing)
+                          : v <= -2 ? code(-v - 2, near_pos_, near_end, kTickNearInput, kTickNearRing)
+                                    : -1;
     }
     if (stale) return AECM_UNSPECIFIED_ERROR;
-    // 3. device side of the tick
+    // 3. device side of the tick: prepare -> blocks -> finish
+    int16_t *bfar = blk_, *bnear = blk_ + (size_t)S * kTickMaxBlockSamples, *bout = blk_ + 2 * (size_t)S * kTickMaxBlockSamples;
+    if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dstride, n, far_ring_, near_ring_, kRing, far_pos_, near_pos_, bfar,
+                                       bnear, nbs, gather, S, st)))
+        return AECM_UNSPECIFIED_ERROR;
+    far_pos_ += n;
+    near_pos_ += n;
     if (n_blocks > 0) {
-        const int64_t nb64 = (int64_t)n_blocks * kBlock;
-        int16_t *bfar = blk_, *bnear = blk_ + (size_t)S * 256, *bout = blk_ + 2 * (size_t)S * 256;
-        if (!AECM_HIP_OK(hipMemcpyAsync(tags_dev_, blk_far, nb64 * sizeof(int64_t), hipMemcpyHostToDevice, st)) ||
-            !AECM_HIP_OK(hipMemcpyAsync(tags_dev_ + 256, blk_near, nb64 * sizeof(int64_t), hipMemcpyHostToDevice, st)) ||
-            !AECM_HIP_OK(LaunchRingGather(far_ring_, kRing, tags_dev_, nb64, bfar, nb64, S, st)) ||
-            !AECM_HIP_OK(LaunchRingGather(near_ring_, kRing, tags_dev_ + 256, nb64, bnear, nb64, S, st)))
-            return AECM_UNSPECIFIED_ERROR;
-        IoView io{bfar, bnear, nullptr, bout, nb64, kBlock};
+        IoView io{bfar, bnear, nullptr, bout, nbs, kBlock};
         if (!engine_->ProcessBlocks(io, n_blocks)) return AECM_UNSPECIFIED_ERROR;
-        if (!AECM_HIP_OK(LaunchRingAppend(bout, nb64, nb64, out_ring_, kRing, blocks_done_ * kBlock, S, st)))
-            return AECM_UNSPECIFIED_ERROR;
         blocks_done_ += n_blocks;
     }
-    if (!AECM_HIP_OK(hipMemcpyAsync(tags_dev_ + 512, out_tags, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st)) ||
-        !AECM_HIP_OK(LaunchRingAssemble(out_ring_, near_ring_, kRing, tags_dev_ + 512, n, dout, dstride, S, st)))
+    if (!AECM_HIP_OK(LaunchTickFinish(bout, nbs, out_ring_, near_ring_, kRing, out_base, dnear, dstride, dout, n, assemble,
+                                      S, st)))
         return AECM_UNSPECIFIED_ERROR;
-    // the tag arrays live on this stack frame: the copies above must have been consumed before returning
     if (host_pointers &&
         !AECM_HIP_OK(hipMemcpy2DAsync(out, stride * 2, dout, 320, (size_t)n * 2, S, hipMemcpyDeviceToHost, st)))
         return AECM_UNSPECIFIED_ERROR;

@@ -5,8 +5,9 @@
 // The session wrapper and the frame adapter only move samples (aecm_session_flow.h), so ONE
 // SessionFlow runs on the host in the index domain (64-bit absolute sample tags) and its decisions are
 // applied to all streams on the device: the audio lives in per-stream rings in HBM, each tick is
-//   append far/near -> gather the tick's blocks by tag -> WebRtcAecm_ProcessBlock x nb (one launch)
-//   -> block outputs into the output ring -> assemble the tick's output by tag.
+//   prepare (append far/near to the rings + gather the tick's blocks) -> WebRtcAecm_ProcessBlock x nb
+//   -> finish (block outputs into the output ring + assemble the tick's output): three launches, the
+//   per-sample source decisions travel as kernel arguments.
 #ifndef AECM_AMD_SESSIONS_H_
 #define AECM_AMD_SESSIONS_H_
 
@@ -42,7 +43,6 @@ private:
     int64_t far_pos_ = 0, near_pos_ = 0, blocks_done_ = 0;
     int16_t *far_ring_ = nullptr, *near_ring_ = nullptr, *out_ring_ = nullptr;   // [S][kRing]
     int16_t *blk_ = nullptr;          // [3][S][4*64] gathered far / near blocks and block outputs of a tick
-    int64_t *tags_dev_ = nullptr;     // far tags [256], near tags [256], out tags [160]
     int16_t *io_dev_ = nullptr;       // [3][S][160] staging when the caller passes host pointers
     int device_ = 0;
 };
