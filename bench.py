@@ -134,15 +134,17 @@ def load_traffic(workload_key):
         return None
 
 
-def load_valu_note():
-    """The counter that actually bounds this kernel (recorded by the last profiling pass)."""
+def load_issue_note():
+    """The resource that actually bounds this kernel (recorded by the last profiling pass)."""
     p = ROOT / "profiles" / "r01_rocprof_summary.json"
     try:
         d = json.loads(p.read_text())["derived"]
         return {"valu_insts_per_frame": round(d["valu_insts_per_frame"], 1),
-                "ns_per_valu_inst_per_simd": round(d["ns_per_valu_inst_per_simd"], 2),
-                "valu_inst_cost_ns_microbench": [1.2, 1.8],
-                "source": "profiles/r01_rocprof_summary.json (rocprofv3 SQ_INSTS_VALU) + profiles/r01_valu_rate_microbench.txt"}
+                "salu_insts_per_frame": round(d["salu_insts_per_frame"], 1),
+                "valu_port_busy_frac": round(d["valu_port_busy_frac"], 3),
+                "scalar_port_busy_frac": round(d["scalar_port_busy_frac"], 3),
+                "model": "one wave64 VALU and one scalar instruction per SIMD per 4 shader cycles",
+                "source": "profiles/r01_rocprof_summary.json (rocprofv3 SQ_*), profiles/r01_issue_port_experiments.md"}
     except Exception:
         return None
 
@@ -233,9 +235,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(workload_key),
                          "kernel": "aecm_process_kernel<fast,noclean>", "kernel_avg_ms": kern_avg_s * 1e3,
                          "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME,
-                         "note": "integer-VALU-issue-bound kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "
-                                 "see valu_bound for the binding resource",
-                         "valu_bound": load_valu_note()},
+                         "note": "instruction-issue-bound integer kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "
+                                 "see issue_bound for the binding resource",
+                         "issue_bound": load_issue_note()},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.fs)

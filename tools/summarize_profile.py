@@ -56,11 +56,12 @@ summary = {
         "lds_insts_per_frame": pmc["SQ_INSTS_LDS"] / frames,
         "lds_bank_conflict_cycles_per_frame": pmc["SQ_LDS_BANK_CONFLICT"] / frames,
         "shader_cycles_per_launch": gui, "effective_clock_GHz": gui / kern_ns,
-        # time one SIMD had per VALU instruction it executed; the micro-benchmark
-        # (profiles/r01_valu_rate_microbench.txt) puts a wave64 integer VALU instruction at 1.2 ns (add/sub/
-        # logic/right shifts) to 1.8 ns (everything else), so ~1.8 ns here means the VALU pipes are saturated
+        # Issue ports (profiles/r01_issue_port_experiments.md): a SIMD accepts one wave64 VALU and one
+        # scalar instruction per 4 shader cycles.  SQ_ACTIVE_INST_VALU counts VALU issue slots of 4 cycles
+        # (8-cycle instructions such as v_permlane*_swap / v_sqrt_f32 count twice).
         "ns_per_valu_inst_per_simd": kern_ns * 1024 / pmc["SQ_INSTS_VALU"],
-        "valu_issue_busy_frac_at_4_cycles_per_wave64_inst": valu_per_simd * 4 / gui,
+        "valu_port_busy_frac": pmc["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / gui,
+        "scalar_port_busy_frac": pmc["SQ_ACTIVE_INST_SCA"] * 4 / 1024 / gui,
         "wave_cycle_split": {k: pmc[k] / pmc["SQ_WAVE_CYCLES"] for k in
                              ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
         "avg_resident_waves_per_simd": pmc["SQ_WAVE_CYCLES"] * 4 / 1024 / gui,
