@@ -123,6 +123,15 @@ int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
  * (see webrtc_aecm_amd/csrc/aecm_kernels.h).  exhaustive != 0 checks floor-sqrt on all of [0, 2^31). */
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]);
 
+/* Diagnostics: `count` independent 128-point transforms of the block kernel's own FFT code, on host
+ * data in natural order (transform k: data[k*256 .. +128) = re, [.. +256) = im, in place).  variant 0 =
+ * forward of real input (im ignored), 1 = forward complex, 2 = inverse (reference
+ * WebRtcSpl_ComplexBitReverse + ComplexFFT / ComplexIFFT, aecm/complex_fft.c:181-491, mode 1);
+ * scales[k] receives the inverse transform's return value.  Outputs the block path never consumes
+ * come back as 0: forward -> im of bins >= 64, inverse -> im.  kernel_variant as in SetKernelVariant. */
+int32_t WebRtcAecmBatch_DebugFft128(int32_t device_id, int16_t *data_host, int32_t *scales_host, int32_t variant,
+                                    int32_t kernel_variant, int32_t count);
+
 /* Name, CU count and clock of the device the library would use (diagnostics). */
 int32_t WebRtcAecmBatch_DeviceInfo(int32_t device_id, char *name, size_t name_len, int32_t *compute_units,
                                    int32_t *clock_khz);

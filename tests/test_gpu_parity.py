@@ -22,6 +22,30 @@ def test_wave_primitives_selftest():
     assert f.tolist() == [0] * 8, f"self-test failures {f.tolist()} (see csrc/aecm_kernels.h for the index meaning)"
 
 
+@pytest.mark.parametrize("variant", [aecm.KERNEL_FAST, aecm.KERNEL_SAFE])
+def test_device_fft128_on_arbitrary_complex_data(variant):
+    """The kernel's own transform code on the device (every per-stage scaling path of the inverse,
+    the multiply-add forward stages, the generic complex forward) against the oracle's transform,
+    which test_oracle pins to the reference's WebRtcSpl_ComplexFFT / ComplexIFFT."""
+    import ctypes as C
+    from test_oracle import fft_fuzz_cases
+    olib = pyoracle.oracle_lib()
+    cases = fft_fuzz_cases(n_cases=600, seed=11)
+    re = np.stack([c[0] for c in cases])
+    im = np.stack([c[1] for c in cases])
+    for fft_variant in (0, 1, 2):
+        gre, gim, gscale = aecm.debug_fft128(re, im, fft_variant, variant)
+        for k in range(re.shape[0]):
+            ore, oim = re[k].copy(), (np.zeros(128, np.int16) if fft_variant == 0 else im[k].copy())
+            scale = C.c_int(0)
+            olib.aecm_oracle_fft128(ore, oim, 1 if fft_variant == 2 else 0, C.byref(scale))
+            assert np.array_equal(gre[k], ore), (fft_variant, k)
+            if fft_variant != 2:
+                assert np.array_equal(gim[k][:64], oim[:64]), (fft_variant, k)
+            else:
+                assert gscale[k] == scale.value, (fft_variant, k)
+
+
 @pytest.mark.parametrize("variant", [aecm.KERNEL_SAFE, aecm.KERNEL_FAST])
 @pytest.mark.parametrize("fs", [16000, 8000])
 def test_block_parity_vs_oracle(fs, variant):

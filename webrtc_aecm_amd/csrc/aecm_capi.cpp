@@ -297,6 +297,33 @@ int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t
     return rc;
 }
 
+int32_t WebRtcAecmBatch_DebugFft128(int32_t device_id, int16_t *data_host, int32_t *scales_host, int32_t variant,
+                                    int32_t kernel_variant, int32_t count) {
+    if (!data_host || !scales_host) return AECM_NULL_POINTER_ERROR;
+    if (variant < 0 || variant > 2 || count < 0) return AECM_BAD_PARAMETER_ERROR;
+    if (count == 0) return 0;
+    if (hipSetDevice(device_id) != hipSuccess) return AECM_UNSPECIFIED_ERROR;
+    std::vector<uint32_t> blob;
+    aecm::BuildKernelConstants(&blob);
+    int16_t *data = nullptr;
+    int32_t *scales = nullptr;
+    uint32_t *consts = nullptr;
+    const size_t bytes = (size_t)count * 256 * sizeof(int16_t);
+    int32_t rc = AECM_UNSPECIFIED_ERROR;
+    if (hipMalloc((void **)&data, bytes) == hipSuccess && hipMalloc((void **)&scales, (size_t)count * 4) == hipSuccess &&
+        hipMalloc((void **)&consts, blob.size() * 4) == hipSuccess &&
+        hipMemcpy(consts, blob.data(), blob.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(data, data_host, bytes, hipMemcpyHostToDevice) == hipSuccess &&
+        aecm::LaunchFft128(data, scales, variant, kernel_variant != 0, count, consts, nullptr) == hipSuccess &&
+        hipDeviceSynchronize() == hipSuccess && hipMemcpy(data_host, data, bytes, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(scales_host, scales, (size_t)count * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = 0;
+    (void)hipFree(data);
+    (void)hipFree(scales);
+    (void)hipFree(consts);
+    return rc;
+}
+
 int32_t WebRtcAecmBatch_DeviceInfo(int32_t device_id, char *name, size_t name_len, int32_t *compute_units,
                                    int32_t *clock_khz) {
     hipDeviceProp_t prop;

@@ -67,6 +67,13 @@ hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *o
                             int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride, int16_t *out,
                             int n, const TickAssembleCodes &codes, int n_streams, hipStream_t stream);
 
+// Diagnostics: `count` independent 128-point transforms of the block kernel's fft128, one wavefront
+// each, on natural-order data (data[k] = re[128] then im[128] of transform k, in place).  variant:
+// 0 forward of real input, 1 forward complex, 2 inverse; scales[k] = the inverse's accumulated scale.
+// Outputs nobody consumes in the block path are returned as 0 (forward: im of bins >= 64; inverse: im).
+hipError_t LaunchFft128(int16_t *data_dev, int32_t *scales_dev, int variant, int fast, int count, const uint32_t *consts_dev,
+                        hipStream_t stream);
+
 // Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
 //  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,
 //  6 isqrt31 (exhaustive over [0, 2^31) when exhaustive != 0, else 2^24 samples), 7 table upload.

@@ -302,6 +302,13 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
                 hi = hi < 0 ? (hi == -32768 ? 32767 : -hi) : hi;
                 if (pk_abs_sat_i16(x) != ((lo & 0xffff) | (int)((unsigned)hi << 16))) bump(4);
                 if (pk_abs_sat_i16((int)0x80008000) != 0x7fff7fff) bump(4);
+                // v_mad_i32_i16 with and without op_sel, vector and scalar addend
+                const int uc = (int)Mix((unsigned)round * 2654435761u + blockIdx.x);   // wave-uniform
+                if (mad16_lo(x, y, c) != add(mul(sext16(x), sext16(y)), c)) bump(4);
+                if (mad16_hi(x, y, c) != add(mul(sar(x, 16), sext16(y)), c)) bump(4);
+                if (mad16_lo_uc(x, y, uc) != add(mul(sext16(x), sext16(y)), uc)) bump(4);
+                if (mad16_hi_uc(x, y, uc) != add(mul(sar(x, 16), sext16(y)), uc)) bump(4);
+                if (mad16_lo((int)0x80008000, -32768, 1) != 0x40000001 || mad16_hi((int)0x7fff0000, -32768, -32770) != (int)0xbffffffe) bump(4);
                 const int ml = imax(sext16(x), sext16(y)), mh = imax(sar(x, 16), sar(y, 16));
                 if (pk_max_i16(x, y) != ((ml & 0xffff) | (int)((unsigned)mh << 16))) bump(4);
             }
@@ -345,6 +352,38 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
             if (r * r > edges[k] || (r + 1) * (r + 1) <= edges[k]) bump(6);
         }
     }
+}
+
+template <bool kFast>
+__global__ __launch_bounds__(256) void aecm_fft128_kernel(int16_t *data, int32_t *scales, int variant, int count,
+                                                          const uint32_t *consts) {
+    FillLdsTables(consts);
+    using E = BlockEngine<Gfx950Wave<kFast>, false>;
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= count) return;
+    int16_t *re = data + (size_t)k * 256, *im = re + 128;
+    int a = (re[lane] & 0xffff) | (int)((unsigned)(variant == 0 ? 0 : im[lane]) << 16);
+    int b = (re[lane + 64] & 0xffff) | (int)((unsigned)(variant == 0 ? 0 : im[lane + 64]) << 16);
+    int scale = 0;
+    if (variant == 0) scale = E::template fft128<false, true>(a, b);
+    else if (variant == 1) scale = E::template fft128<false, false>(a, b);
+    else scale = E::template fft128<true, false>(a, b);
+    int r = 0;
+    for (int i = 0; i < 6; ++i) r |= ((lane >> i) & 1) << (5 - i);
+    re[r] = (int16_t)a;
+    re[r + 64] = (int16_t)b;
+    im[r] = variant == 2 ? (int16_t)0 : (int16_t)(a >> 16);
+    im[r + 64] = 0;
+    if (lane == 0) scales[k] = scale;
+}
+hipError_t LaunchFft128(int16_t *data_dev, int32_t *scales_dev, int variant, int fast, int count, const uint32_t *consts_dev,
+                        hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    const dim3 grid((count + 3) / 4), block(256);
+    if (fast) hipLaunchKernelGGL(aecm_fft128_kernel<true>, grid, block, sizeof(LdsTables), stream, data_dev, scales_dev, variant, count, consts_dev);
+    else hipLaunchKernelGGL(aecm_fft128_kernel<false>, grid, block, sizeof(LdsTables), stream, data_dev, scales_dev, variant, count, consts_dev);
+    return hipGetLastError();
 }
 
 hipError_t LaunchSelfTest(uint64_t *counters_dev, int exhaustive, const uint32_t *consts_dev, hipStream_t stream) {

@@ -40,7 +40,7 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
     "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
-    "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DeviceInfo",
+    "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo",
 ]
 SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_Create", "WebRtcAecmSessions_Free", "WebRtcAecmSessions_Init", "WebRtcAecmSessions_set_config",
@@ -119,6 +119,7 @@ def load():
     lib.WebRtcAecmSessions_Tick.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
     lib.WebRtcAecmSessions_TickHost.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
+    lib.WebRtcAecmBatch_DebugFft128.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DeviceInfo.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _lib = lib
     return lib
@@ -361,6 +362,20 @@ def self_test(device: int = 0, exhaustive: bool = False):
     if rc != 0:
         raise AecmError(rc, "WebRtcAecmBatch_SelfTest")
     return f
+
+
+def debug_fft128(re, im, variant: int, kernel_variant: int = KERNEL_FAST, device: int = 0):
+    """Run the block kernel's own 128-point transform on (count, 128) int16 arrays; returns (re, im, scales).
+    variant: 0 forward of real input, 1 forward complex, 2 inverse (see include/aecm_batch.h)."""
+    lib = load()
+    re = np.ascontiguousarray(re, dtype=np.int16).reshape(-1, 128)
+    im = np.ascontiguousarray(im, dtype=np.int16).reshape(-1, 128)
+    data = np.ascontiguousarray(np.concatenate([re, im], axis=1))
+    scales = np.zeros(re.shape[0], dtype=np.int32)
+    rc = lib.WebRtcAecmBatch_DebugFft128(device, data.ctypes.data, scales.ctypes.data, variant, kernel_variant, re.shape[0])
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_DebugFft128")
+    return data[:, :128].copy(), data[:, 128:].copy(), scales
 
 
 def device_info(device: int = 0):
