@@ -62,6 +62,7 @@ SIM_BIN(pk_max_i16, pk_max_i16(x, y))
 SIM_UN(operator~, ~x)
 SIM_UN(neg, neg(x))
 SIM_UN(sext16, sext16(x))
+SIM_UN(as_i16, as_i16(x))
 SIM_UN(zext16, zext16(x))
 SIM_UN(iabs, iabs(x))
 SIM_UN(clz32, clz32(x))

@@ -14,6 +14,10 @@ namespace aecm {
     fprintf(stderr, "aecm: mul24 precondition violated (%d * %d)\n", a, b);
     abort();
 }
+[[noreturn]] void aecm_i16_range_violation(int v) {
+    fprintf(stderr, "aecm: as_i16 precondition violated (%d)\n", v);
+    abort();
+}
 namespace {
 
 inline uint32_t Pack16(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | (((uint32_t)(uint16_t)hi) << 16); }

@@ -23,8 +23,12 @@ __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
     __syncthreads();
 }
 
+// Occupancy target: the kernel is bound by instruction issue with every wave strictly in order, so
+// resident waves are what hides one wave's latencies from the VALU port.  7 waves/SIMD = 72 VGPRs; the
+// fast variants need 68 / 71 (no spills).  Measured: 5 -> 6 -> 7 waves = 609 -> 657 -> 674 M frames/s;
+// 8 waves (64 VGPRs) spills and is slower.
 #ifndef AECM_WAVES_PER_EU
-#define AECM_WAVES_PER_EU 5
+#define AECM_WAVES_PER_EU 7
 #endif
 template <bool kFast, bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))

@@ -334,17 +334,16 @@ struct BlockEngine {
         // lane t holds X[bitrev6(t)] in a and X[bitrev6(t)+64] in b
         int x64 = W::readlane(b, 0);
         vi x = W::bpermute(a, r.brev);                      // bin t -> lane t
-        vi re = lo16(x);
-        vi im = sext16(neg(hi16(x)));                       // conjugate (:188-190), int16 wrap
-        im = sel(r.lane == 0, vi(0), im);                   // :296
-        sp.re = re;
-        sp.im = im;
+        x = sel(r.lane == 0, zext16(x), x);                 // bin 0: imaginary part forced to 0 (:296)
+        sp.re = lo16(x);
+        sp.im = sext16(neg(hi16(x)));                       // conjugate (:188-190), int16 wrap
         sp.re64 = sext16(x64);                              // bin 64: imag forced to 0 (:297)
         // magnitudes (:298-362, AECM_WITH_ABS_APPROX off).  The reference special-cases re == 0 /
         // im == 0 (|.| of the other part) and saturates re^2+im^2 at 2^31-1; both are subsumed by an
         // exact floor(sqrt) on the unsigned sum: floor(sqrt(x^2)) == |x|, and the only sum above
         // 2^31-1 is 2^31 (re = im = -32768), whose floor-sqrt 46340 equals that of 2^31-1.
-        vi sq = add(mul24(re, re), mul24(im, im));          // <= 2^31 as unsigned
+        // (-im)^2 == im^2 also for the wrapped -32768, so the packed bin squares itself.
+        vi sq = dot2_i16(x, x, vi(0));                      // <= 2^31 as unsigned
         sp.mag = W::isqrt31(sq);                            // <= 46340 < 2^16
         sp.mag64 = zext16(iabs(sp.re64));
         sp.q = q;
@@ -502,11 +501,11 @@ struct BlockEngine {
         I u1 = mul(sel(shift_ch_far >= 32, I(0), sar(s.ch_adapt32, shift_ch_far)), far);
         I zeros_num = norm_u32(u1);                                                           // :852-867
         I zeros_dfa = sel(dfa != 0, norm_u32(dfa), I(32));
-        I t16 = sext16(zeros_dfa - 2 + dfa_noisy_q - kResChannel32 - far_q + shift_ch_far);
+        I t16 = as_i16(zeros_dfa - 2 + dfa_noisy_q - kResChannel32 - far_q + shift_ch_far);   // |.| < 128: counts, Q values
         auto c1 = zeros_num > (t16 + 1);
-        I xfa_q = sel(c1, t16, sext16(zeros_num - 2));
-        I dfa_q = sel(c1, sext16(zeros_dfa - 2),
-                      sext16(I(kResChannel32 + far_q - dfa_noisy_q) - shift_ch_far + xfa_q));
+        I xfa_q = sel(c1, t16, as_i16(zeros_num - 2));
+        I dfa_q = sel(c1, as_i16(zeros_dfa - 2),
+                      as_i16(I(kResChannel32 + far_q - dfa_noisy_q) - shift_ch_far + xfa_q));
         u1 = shift_u(u1, xfa_q);                                                              // :869-872
         I u2 = shift_u(dfa, dfa_q);
         I t1 = sub(u2, u1);
@@ -518,7 +517,7 @@ struct BlockEngine {
         I t2 = mul(sar(sel(pos, t1, neg(t1)), shift_num), far);
         t2 = sel(pos, t2, neg(t2));
         t2 = div_by_magic(t2, div_magic_k, div_shift_k);                                      // :904  / (bin + 1)
-        I shift2res = sext16(shift_num + shift_ch_far - xfa_q - mu - shl(I(30) - zeros_far, 1));
+        I shift2res = as_i16(shift_num + shift_ch_far - xfa_q - mu - shl(I(30) - zeros_far, 1));
         t2 = sel(norm_w32(t2) < shift2res, I(0x7fffffff), shift_i(t2, shift2res));            // :906-912
         I n32 = add_sat32(s.ch_adapt32, t2);                                                  // :913-919
         n32 = sel(n32 < 0, I(0), n32);
@@ -615,7 +614,7 @@ struct BlockEngine {
         I t16 = I(17) - zeros32 - zeros16;
         int dq = clean_q - zeros_xbuf;
         I res_diff = sel(safe, I(14 - kResChannel16 - kResSupgain + dq),
-                         sext16(t16 + (14 - kResChannel16 - kResSupgain + dq)));
+                         as_i16(t16 + (14 - kResChannel16 - kResSupgain + dq)));
         // three regimes (:534,:544,:548), all "low 32 bits of a product": select the operands, multiply once
         auto shift_gain = zeros32 > t16;
         I lhs = sel(safe | shift_gain, s.echo_filt, sar(s.echo_filt, t16));
@@ -636,7 +635,7 @@ struct BlockEngine {
 
         I g2 = add(gained, sar(s.near_filt, 1));                                              // :582-611
         I t32 = shift_u(divu(g2, zext16(s.near_filt)), res_diff);
-        I h = sel(t32 > kOneQ14, I(0), sel(t32 < 0, I(kOneQ14), imax(I(kOneQ14) - sext16(t32), I(0))));
+        I h = sel(t32 > kOneQ14, I(0), sel(t32 < 0, I(kOneQ14), imax(I(kOneQ14) - t32, I(0))  /* only selected when 0 <= t32 <= 2^14: (int16_t) is the identity there */));
         return sel(gained == 0, I(kOneQ14), sel(s.near_filt == 0, I(0), h));
     }
 
@@ -667,10 +666,10 @@ struct BlockEngine {
         auto clamp = t32 > 32767;
         t32 = sel(clamp, I(32767), t32);
         s.noise_est = sel(clamp, shl(I(32767), shift_n), ne);
-        I n16 = sext16(sar(mul24(sext16(I(kOneQ14) - hnl), sext16(t32)), 14));
-        I idx = sext16(sar(mul24(I(359), rnd), 15));                                            // :150
-        u_re = sext16(sar(mul24(n16, sext16(W::cos360(idx))), 13));                                     // :153-156
-        u_im = sext16(sar(mul24(neg(n16), sext16(W::sin360(idx))), 13));
+        I n16 = as_i16(sar(mul24(as_i16(I(kOneQ14) - hnl), as_i16(t32)), 14));               // 0 <= hnl <= 2^14, 0 <= t32 <= 32767
+        I idx = as_i16(sar(mul24(I(359), rnd), 15));                                            // :150
+        u_re = as_i16(sar(mul24(n16, W::cos360(idx)), 13));     /* |cos|, |sin| <= 2^13 */                                     // :153-156
+        u_im = as_i16(sar(mul24(neg(n16), W::sin360(idx)), 13));
     }
 
     // ------------------------------------------------------------------------------------------
@@ -841,7 +840,7 @@ struct BlockEngine {
 
         AECM_PHASE_MARK(8, hnl, r.b.near_filt);
         if (u.mult == 2) {                                                            // :618-648
-            hnl = sext16(sar(mul24(hnl, hnl), 14));
+            hnl = as_i16(sar(mul24(hnl, hnl), 14));
             hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
             int avg = W::reduce_add(sel((r.lane >= 4) & (r.lane <= 24), hnl, vi(0)));
             avg = sext16(divi(avg, 21));
@@ -853,8 +852,8 @@ struct BlockEngine {
             hnl64 = hnl64 > kNlpCompHigh ? kOneQ14 : (hnl64 < kNlpCompLow ? 0 : hnl64);
             if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
         }
-        vi e_re = sext16(sar(mul24(clean.re, hnl) + 8192, 14));                         // :680-685
-        vi e_im = sext16(sar(mul24(clean.im, hnl) + 8192, 14));
+        vi e_re = as_i16(sar(mul24(clean.re, hnl) + 8192, 14));      // |re| <= 2^15, 0 <= hnl <= 2^14                         // :680-685
+        vi e_im = as_i16(sar(mul24(clean.im, hnl) + 8192, 14));
         int e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
         int e_im64 = 0;
 
@@ -866,7 +865,7 @@ struct BlockEngine {
             // LCG jump-ahead: lane t gets the t-th of this block's 64 draws
             vi st = add(mul(lane_const<LC_LCG_MUL>(r), vi(u.seed)), lane_const<LC_LCG_ADD>(r)) & 0x7fffffff;
             int s64 = add(mul(r.lcg_mul64, u.seed), r.lcg_add64) & 0x7fffffff;
-            vi rnd = sext16(lsr(st, 16));
+            vi rnd = as_i16(lsr(st, 16));                                           // st < 2^31
             int rnd64 = sext16(lsr(s64, 16));
             u.seed = s64;
             vi u_re, u_im;
@@ -894,7 +893,7 @@ struct BlockEngine {
         AECM_PHASE_MARK(11, a, b);
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
-        vi first = sext16(sar(mul24(lo16(a), lane_const<LC_HANN_SYN_LO>(r)) + 8192, 14));               // :219-221
+        vi first = as_i16(sar(mul24(lo16(a), lane_const<LC_HANN_SYN_LO>(r)) + 8192, 14));               // :219-221
         vi out = sat16(add(shift_i(first, sh), r.out_ovl));                           // :222-227
         vi second = sar(mul24(lo16(b), lane_const<LC_HANN_SYN_HI>(r)), 14);                             // :229-234
         r.out_ovl = sat16(shift_i(second, sh));
