@@ -60,20 +60,20 @@ int32_t WebRtcAecmBatch_ProcessBlocksHost(AecmBatch *b, const int16_t *far_host,
                                           int64_t block_stride, int32_t num_blocks);
 /* Whole recordings as sessions (batched form of the reference CLI's loop, main.cc:105-143): every
  * stream is treated as a freshly initialised WebRtcAecm_* session that receives num_calls pairs of
- * WebRtcAecm_BufferFarend(far, samples_per_call) + WebRtcAecm_Process(near, NULL, out,
- * samples_per_call, msInSndCardBuf).  The session wrapper and frame adapter of the reference
+ * WebRtcAecm_BufferFarend(far, samples_per_call) + WebRtcAecm_Process(near, near_clean, out,
+ * samples_per_call, msInSndCardBuf) (near_clean may be NULL, reference echo_control_mobile.h:135-140).  The session wrapper and frame adapter of the reference
  * (echo_control_mobile.cc:236-408, aecm_core.cc:501-572) only move samples, so they are run once on
  * the host in the index domain and applied to all streams as a device-side gather / scatter around
  * WebRtcAecmBatch_ProcessBlocks.  Call after WebRtcAecmBatch_Init (+ set_config) on fresh streams.
- * far/near/out: [S][stream_stride] with stream_stride >= num_calls * samples_per_call; samples beyond
+ * far/near/near_clean/out: [S][stream_stride] with stream_stride >= num_calls * samples_per_call; samples beyond
  * that are not touched.  Returns 0 or AECM_BAD_PARAMETER_WARNING exactly as each session would.
  * Synchronous. */
-int32_t WebRtcAecmBatch_ProcessRecordings(AecmBatch *b, const int16_t *far_dev, const int16_t *near_dev, int16_t *out_dev,
-                                          int64_t stream_stride, int32_t samples_per_call, int32_t num_calls,
-                                          int16_t msInSndCardBuf);
+int32_t WebRtcAecmBatch_ProcessRecordings(AecmBatch *b, const int16_t *far_dev, const int16_t *near_dev,
+                                          const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                          int32_t samples_per_call, int32_t num_calls, int16_t msInSndCardBuf);
 int32_t WebRtcAecmBatch_ProcessRecordingsHost(AecmBatch *b, const int16_t *far_host, const int16_t *near_host,
-                                              int16_t *out_host, int64_t stream_stride, int32_t samples_per_call,
-                                              int32_t num_calls, int16_t msInSndCardBuf);
+                                              const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                              int32_t samples_per_call, int32_t num_calls, int16_t msInSndCardBuf);
 int32_t WebRtcAecmBatch_Synchronize(AecmBatch *b);
 
 /* Duration of the most recent ProcessBlocks kernel, from HIP events recorded around the launch on
@@ -101,20 +101,24 @@ int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[
  * S independent WebRtcAecm_* sessions that share one call pattern (a media server's 10 ms clock):
  * every WebRtcAecmSessions_Tick is, for each stream s,
  *     WebRtcAecm_BufferFarend(inst_s, far[s], nrOfSamples);
- *     WebRtcAecm_Process(inst_s, near[s], NULL, out[s], nrOfSamples, msInSndCardBuf);
+ *     WebRtcAecm_Process(inst_s, near[s], near_clean ? near_clean[s] : NULL, out[s], nrOfSamples, msInSndCardBuf);
  * (reference echo_control_mobile.h:87,135) with identical results and return code.  Audio is held in
  * per-stream rings in HBM; the reference's jitter buffer / start-up gating / delay compensation /
  * 80->64 re-blocking run once on the host in the index domain (csrc/aecm_sessions.h).
- * far/near/out: [S][stream_stride] int16, device pointers (Tick) or host pointers (TickHost). */
+ * far/near/near_clean/out: [S][stream_stride] int16, device pointers (Tick) or host pointers (TickHost);
+ * near_clean may be NULL, but a batch must either always or never pass it (the clean ring is only kept
+ * up to date by ticks that carry it). */
 typedef struct AecmSessions AecmSessions;
 AecmSessions *WebRtcAecmSessions_Create(int32_t num_streams, int32_t device_id);
 void WebRtcAecmSessions_Free(AecmSessions *s);
 int32_t WebRtcAecmSessions_Init(AecmSessions *s, int32_t sampFreq);
 int32_t WebRtcAecmSessions_set_config(AecmSessions *s, AecmConfig config);
-int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev, int16_t *out_dev,
-                                int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf);
-int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host, int16_t *out_host,
-                                    int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf);
+int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
+                                const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples,
+                                int16_t msInSndCardBuf);
+int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
+                                    const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                    size_t nrOfSamples, int16_t msInSndCardBuf);
 
 /* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */
 int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);

@@ -111,38 +111,41 @@ bool BatchEngine::Digest(int stream, uint32_t d[kDigestWords]) {
 
 namespace aecm {
 // Same algorithm as BatchEngine::ProcessRecordings in aecm_engine.cpp, host loops instead of kernels.
-bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, int16_t *out, int64_t stride, int frame,
-                                    int n_calls, int16_t ms, bool, int32_t *rc) {
+bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride,
+                                    int frame, int n_calls, int16_t ms, bool, int32_t *rc) {
     const RecordingSchedule sch = BuildRecordingSchedule(fs_, frame, n_calls, ms);
     if (sch.first_error) { *rc = sch.first_error; return true; }
     *rc = sch.warned ? kWarnBadParameter : 0;
     const int64_t n_blk = (int64_t)sch.n_blocks * kBlock, n_in = (int64_t)n_calls * frame;
-    std::vector<int16_t> bfar(num_streams_ * n_blk), bnear(num_streams_ * n_blk), bout(num_streams_ * n_blk);
+    std::vector<int16_t> bfar(num_streams_ * n_blk), bnear(num_streams_ * n_blk), bclean(clean ? num_streams_ * n_blk : 0),
+        bout(num_streams_ * n_blk);
     for (int s = 0; s < num_streams_; ++s)
         for (int64_t j = 0; j < n_blk; ++j) {
             bfar[s * n_blk + j] = sch.far_map[j] >= 0 ? far[s * stride + sch.far_map[j]] : 0;
             bnear[s * n_blk + j] = sch.near_map[j] >= 0 ? near[s * stride + sch.near_map[j]] : 0;
+            if (clean) bclean[s * n_blk + j] = sch.near_map[j] >= 0 ? clean[s * stride + sch.near_map[j]] : 0;
         }
     if (sch.n_blocks > 0) {
-        IoView io{bfar.data(), bnear.data(), nullptr, bout.data(), n_blk, kBlock};
+        IoView io{bfar.data(), bnear.data(), clean ? bclean.data() : nullptr, bout.data(), n_blk, kBlock};
         ProcessBlocksHost(io, sch.n_blocks);
     }
+    const int16_t *pass = clean ? clean : near;      // pass-through source (echo_control_mobile.cc:285-291)
     for (int s = 0; s < num_streams_; ++s)
         for (int64_t j = 0; j < n_in; ++j) {
             const int32_t v = sch.out_map[j];
-            out[s * stride + j] = v >= 0 ? bout[s * n_blk + v] : (v == -1 ? (int16_t)0 : near[s * stride + (-(int64_t)v - 2)]);
+            out[s * stride + j] = v >= 0 ? bout[s * n_blk + v] : (v == -1 ? (int16_t)0 : pass[s * stride + (-(int64_t)v - 2)]);
         }
     return true;
 }
 }  // namespace aecm
 
 extern "C" int32_t sim_recordings(int n_streams, int n_samples, int fs, int frame, int cng, int echo_mode, int ms,
-                                  const int16_t *far, const int16_t *near, int16_t *out) {
+                                  const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out) {
     aecm::BatchEngine *e = aecm::BatchEngine::Create(n_streams, 0);
     e->Init(fs);
     e->SetConfig(cng, echo_mode, 0, n_streams);
     int32_t rc = -1;
-    e->ProcessRecordings(far, near, out, n_samples, frame, n_samples / frame, (int16_t)ms, true, &rc);
+    e->ProcessRecordings(far, near, clean, out, n_samples, frame, n_samples / frame, (int16_t)ms, true, &rc);
     delete e;
     return rc;
 }

@@ -45,7 +45,8 @@ def lib():
         l.sim_digest.argtypes = [C.c_void_p, _u32p]
         l.sim_fft128.argtypes = [_i16p, _i16p, C.c_int]
         l.sim_constants.argtypes = [_u32p, _u32p, _u32p]
-        l.sim_recordings.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.sim_recordings.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
         l.simsession_create.restype = C.c_void_p
         l.simsession_free.argtypes = [C.c_void_p]
         l.simsession_init.argtypes = [C.c_void_p, C.c_int32]
@@ -141,14 +142,18 @@ class SimSession:
             pass
 
 
-def sim_recordings(far, near, fs, frame, cng, echo_mode, ms):
+def sim_recordings(far, near, fs, frame, cng, echo_mode, ms, clean=None):
     """Schedule-based batched sessions on the simulator: returns (code, out) like
     AecmBatch.process_recordings_host."""
     far = np.ascontiguousarray(far, dtype=np.int16)
     near = np.ascontiguousarray(near, dtype=np.int16)
+    cptr = None
+    if clean is not None:
+        clean = np.ascontiguousarray(clean, dtype=np.int16)
+        cptr = clean.ctypes.data
     out = near.copy()
     rc = lib().sim_recordings(far.shape[0], far.shape[1], fs, frame, cng, echo_mode, ms, far.ctypes.data, near.ctypes.data,
-                              out.ctypes.data)
+                              cptr, out.ctypes.data)
     return rc, out
 
 

@@ -11,7 +11,7 @@ import webrtc_aecm_amd as aecm
 from helpers import (GOLDEN, describe_digest_diff, golden_files, oracle_batch, oracle_run, stream_config,
                      synth_streams)
 from oracle import pyoracle
-from webrtc_aecm_amd.synth import synth_pair
+from webrtc_aecm_amd.synth import synth_clean, synth_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -218,38 +218,45 @@ def test_state_snapshot_migrates_a_stream():
     assert np.array_equal(out_a[2], exp[T1 * 64:]) and np.array_equal(a.digest(2), dig)
 
 
-def _run_session(sess, far, near, frame, ms):
+def _run_session(sess, far, near, frame, ms, clean=None):
     out = near.copy()
     codes = set()
     for i in range(near.size // frame):
         sl = slice(i * frame, (i + 1) * frame)
         assert sess.buffer_farend(far[sl]) == 0
-        rc, o = sess.process(out[sl], None, ms)
+        rc, o = sess.process(out[sl], None if clean is None else clean[sl], ms)
         codes.add(rc)
         out[sl] = o
     return out, codes
 
 
+def _fixture_has_clean(g):
+    return "clean" in g.files and int(g["clean"]) != 0
+
+
 def test_session_abi_golden():
-    """The drop-in WebRtcAecm_* session ABI on the GPU against reference-generated fixtures."""
+    """The drop-in WebRtcAecm_* session ABI on the GPU against reference-generated fixtures
+    (including WebRtcAecm_Process with a nearendClean input)."""
     files = golden_files("session_")
-    assert files
+    assert files and any("_clean" in f.name for f in files)
     for f in files:
         g = np.load(f)
         fs, frame, ms = int(g["fs"]), int(g["frame"]), int(g["ms"])
         far, near = synth_pair(int(g["seed"]), int(g["n_blocks"]), fs, "mixed")
         n = (far.size // frame) * frame
+        clean = synth_clean(near)[:n] if _fixture_has_clean(g) else None
         s = aecm.Aecm()
         assert s.init(fs) == 0
         assert s.set_config(int(g["cng"]), int(g["echo_mode"])) == 0
-        out, codes = _run_session(s, far[:n], near[:n], frame, ms)
+        out, codes = _run_session(s, far[:n], near[:n], frame, ms, clean)
         assert sorted(codes) == g["codes"].tolist(), f.name
         assert np.array_equal(out, g["out"]), f.name
         s.close()
 
 
 def test_batched_recordings_equal_individual_sessions():
-    """WebRtcAecmBatch_ProcessRecordingsHost: S recordings as S sessions in one device batch."""
+    """WebRtcAecmBatch_ProcessRecordingsHost: S recordings as S sessions in one device batch (with and
+    without a nearendClean input)."""
     for f in golden_files("session_"):
         g = np.load(f)
         fs, frame, ms = int(g["fs"]), int(g["frame"]), int(g["ms"])
@@ -258,27 +265,31 @@ def test_batched_recordings_equal_individual_sessions():
         n = (pairs[0][0].size // frame) * frame
         far = np.stack([p[0][:n] for p in pairs])
         near = np.stack([p[1][:n] for p in pairs])
+        clean = synth_clean(near) if _fixture_has_clean(g) else None
         b = aecm.AecmBatch(S, fs, int(g["cng"]), int(g["echo_mode"]))
-        rc, out = b.process_recordings_host(far, near, frame, ms)
+        rc, out = b.process_recordings_host(far, near, frame, ms, clean)
         assert [rc] == g["codes"].tolist(), f.name
         assert np.array_equal(out[0], g["out"]), f.name                 # stream 0 is the golden recording
         for k in (1, S - 1):
             s = aecm.Aecm()
             assert s.init(fs) == 0 and s.set_config(int(g["cng"]), int(g["echo_mode"])) == 0
-            exp, _ = _run_session(s, far[k], near[k], frame, ms)
+            exp, _ = _run_session(s, far[k], near[k], frame, ms, None if clean is None else clean[k])
             assert np.array_equal(out[k], exp), (f.name, k)
             s.close()
 
 
 def test_streaming_session_batch_ticks_equal_individual_sessions():
-    """WebRtcAecmSessions_Tick: S sessions on a common 10 ms clock, including a jittering msInSndCardBuf."""
+    """WebRtcAecmSessions_Tick: S sessions on a common 10 ms clock, including a jittering msInSndCardBuf
+    and (last two cases) a nearendClean input."""
     rs = np.random.RandomState(9)
-    for fs, frame, cng, em in ((16000, 160, 1, 1), (8000, 80, 1, 3), (16000, 80, 0, 2), (8000, 160, 1, 4)):
+    for fs, frame, cng, em, with_clean in ((16000, 160, 1, 1, 0), (8000, 80, 1, 3, 0), (16000, 80, 0, 2, 0), (8000, 160, 1, 4, 0),
+                                           (16000, 160, 1, 3, 1), (8000, 80, 1, 1, 1)):
         S, secs = 4, 5
         pairs = [synth_pair(70 + k, secs * fs // 64, fs, "mixed") for k in range(S)]
         n_ticks = pairs[0][0].size // frame
         far = np.stack([p[0][:n_ticks * frame] for p in pairs])
         near = np.stack([p[1][:n_ticks * frame] for p in pairs])
+        clean = synth_clean(near) if with_clean else None
         ms_seq = [int(40 + rs.randint(-12, 13)) if i % 40 else int(rs.choice([-3, 0, 600, 90])) for i in range(n_ticks)]
         sb = aecm.AecmSessions(S, fs, cng, em)
         singles = []
@@ -288,10 +299,10 @@ def test_streaming_session_batch_ticks_equal_individual_sessions():
             singles.append(s)
         for i in range(n_ticks):
             sl = slice(i * frame, (i + 1) * frame)
-            rc, out = sb.tick_host(far[:, sl], near[:, sl], ms_seq[i])
+            rc, out = sb.tick_host(far[:, sl], near[:, sl], ms_seq[i], None if clean is None else clean[:, sl])
             for k in (0, S - 1):
                 assert singles[k].buffer_farend(far[k, sl]) == 0
-                rc1, o1 = singles[k].process(near[k, sl], None, ms_seq[i])
+                rc1, o1 = singles[k].process(near[k, sl], None if clean is None else clean[k, sl], ms_seq[i])
                 assert rc == rc1 and np.array_equal(out[k], o1), (fs, frame, i, k)
         for s in singles:
             s.close()

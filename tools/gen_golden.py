@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 from oracle import pyoracle  # noqa: E402
-from webrtc_aecm_amd.synth import synth_pair  # noqa: E402
+from webrtc_aecm_amd.synth import synth_clean, synth_pair  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 
@@ -27,11 +27,13 @@ BLOCK_CASES = [
     (3, 1200, 8000, 0, 0, None),
     (100, 4200, 16000, 1, 3, "silent"),
 ]
-# (seed, seconds, fs, frame, cng, echo_mode, ms)
+# (seed, seconds, fs, frame, cng, echo_mode, ms, with nearendClean = synth_clean(near))
 SESSION_CASES = [
-    (7, 10, 16000, 160, 1, 1, 40),     # the reference CLI's parameters (main.cc:102-105,163-164)
-    (8, 6, 8000, 80, 1, 3, 40),
-    (9, 4, 16000, 160, 0, 2, 700),     # ms out of range -> warning path, clamped
+    (7, 10, 16000, 160, 1, 1, 40, 0),     # the reference CLI's parameters (main.cc:102-105,163-164)
+    (8, 6, 8000, 80, 1, 3, 40, 0),
+    (9, 4, 16000, 160, 0, 2, 700, 0),     # ms out of range -> warning path, clamped
+    (10, 6, 16000, 160, 1, 3, 40, 1),     # noise suppressor upstream: WebRtcAecm_Process(noisy, clean, ...)
+    (11, 4, 8000, 160, 1, 1, 40, 1),
 ]
 
 
@@ -39,7 +41,10 @@ def main():
     pyoracle.build()
     assert pyoracle.have_reference(), "reference .so missing"
     GOLD.mkdir(parents=True, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""      # regenerate only the fixtures whose name contains this
     for seed, nb, fs, cng, em, prof in BLOCK_CASES:
+        if only and only not in f"block_s{seed}_":
+            continue
         far, near = synth_pair(seed, nb, fs, prof)
         r = pyoracle.RefCoreStream(fs, cng, em)
         digs = []
@@ -53,9 +58,13 @@ def main():
                             echo_mode=em, profile=prof or "", out=keep, digests=np.stack(digs),
                             sha256=hashlib.sha256(out.tobytes()).hexdigest())
         print("block", seed, fs, cng, em, prof, hashlib.sha256(out.tobytes()).hexdigest()[:16])
-    for seed, secs, fs, frame, cng, em, ms in SESSION_CASES:
+    for seed, secs, fs, frame, cng, em, ms, with_clean in SESSION_CASES:
+        name = f"session_s{seed}_fs{fs}_f{frame}_c{cng}_e{em}_ms{ms}" + ("_clean" if with_clean else "")
+        if only and only not in name:
+            continue
         nb = secs * fs // 64
         far, near = synth_pair(seed, nb, fs, "mixed")
+        clean = synth_clean(near) if with_clean else None
         n = (far.size // frame) * frame
         s = pyoracle.RefSession(fs, cng, em)
         lib = s.lib
@@ -65,13 +74,16 @@ def main():
         for i in range(n // frame):
             f = far[i * frame:(i + 1) * frame]
             d = out[i * frame:(i + 1) * frame]
+            c = clean[i * frame:(i + 1) * frame].ctypes.data if with_clean else None
             assert lib.WebRtcAecm_BufferFarend(s.h, f.ctypes.data, frame) == 0
-            codes.add(int(lib.WebRtcAecm_Process(s.h, d.ctypes.data, None, buf.ctypes.data, frame, ms)))
+            codes.add(int(lib.WebRtcAecm_Process(s.h, d.ctypes.data, c, buf.ctypes.data, frame, ms)))
             d[:] = buf
-        np.savez_compressed(GOLD / f"session_s{seed}_fs{fs}_f{frame}_c{cng}_e{em}_ms{ms}.npz", seed=seed, n_blocks=nb,
-                            fs=fs, frame=frame, cng=cng, echo_mode=em, ms=ms, out=out[:n], codes=np.array(sorted(codes)),
-                            sha256=hashlib.sha256(out[:n].tobytes()).hexdigest())
-        print("session", seed, fs, frame, cng, em, ms, sorted(codes))
+        np.savez_compressed(GOLD / f"{name}.npz", seed=seed, n_blocks=nb,
+                            fs=fs, frame=frame, cng=cng, echo_mode=em, ms=ms, clean=with_clean, out=out[:n],
+                            codes=np.array(sorted(codes)), sha256=hashlib.sha256(out[:n].tobytes()).hexdigest())
+        print("session", seed, fs, frame, cng, em, ms, with_clean, sorted(codes))
+    if only:
+        return
     # 60 s reference-CLI-shaped run: hash only
     far, near = synth_pair(60, 15000, 16000, "mixed")
     s = pyoracle.RefSession(16000, 1, 1)

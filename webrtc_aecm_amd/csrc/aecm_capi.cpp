@@ -139,28 +139,31 @@ int32_t WebRtcAecmBatch_ProcessBlocksHost(AecmBatch *b, const int16_t *far_host,
     return b->engine->ProcessBlocksHost(io, num_blocks) ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
-static int32_t ProcessRecordings(AecmBatch *b, const int16_t *far_p, const int16_t *near_p, int16_t *out_p,
-                                 int64_t stream_stride, int32_t samples_per_call, int32_t num_calls, int16_t ms, bool host) {
+static int32_t ProcessRecordings(AecmBatch *b, const int16_t *far_p, const int16_t *near_p, const int16_t *clean_p,
+                                 int16_t *out_p, int64_t stream_stride, int32_t samples_per_call, int32_t num_calls, int16_t ms,
+                                 bool host) {
     if (int32_t rc = CheckIo(b, far_p, near_p, out_p, num_calls)) return rc;
     if (samples_per_call != 80 && samples_per_call != 160) return AECM_BAD_PARAMETER_ERROR;
     if (stream_stride < (int64_t)samples_per_call * num_calls) return AECM_BAD_PARAMETER_ERROR;
     if (num_calls == 0) return 0;
     int32_t rc = 0;
-    if (!b->engine->ProcessRecordings(far_p, near_p, out_p, stream_stride, samples_per_call, num_calls, ms, host, &rc))
+    if (!b->engine->ProcessRecordings(far_p, near_p, clean_p, out_p, stream_stride, samples_per_call, num_calls, ms, host, &rc))
         return AECM_UNSPECIFIED_ERROR;
     return rc;
 }
 
-int32_t WebRtcAecmBatch_ProcessRecordings(AecmBatch *b, const int16_t *far_dev, const int16_t *near_dev, int16_t *out_dev,
-                                          int64_t stream_stride, int32_t samples_per_call, int32_t num_calls,
-                                          int16_t msInSndCardBuf) {
-    return ProcessRecordings(b, far_dev, near_dev, out_dev, stream_stride, samples_per_call, num_calls, msInSndCardBuf, false);
+int32_t WebRtcAecmBatch_ProcessRecordings(AecmBatch *b, const int16_t *far_dev, const int16_t *near_dev,
+                                          const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                          int32_t samples_per_call, int32_t num_calls, int16_t msInSndCardBuf) {
+    return ProcessRecordings(b, far_dev, near_dev, near_clean_dev, out_dev, stream_stride, samples_per_call, num_calls,
+                             msInSndCardBuf, false);
 }
 
 int32_t WebRtcAecmBatch_ProcessRecordingsHost(AecmBatch *b, const int16_t *far_host, const int16_t *near_host,
-                                              int16_t *out_host, int64_t stream_stride, int32_t samples_per_call,
-                                              int32_t num_calls, int16_t msInSndCardBuf) {
-    return ProcessRecordings(b, far_host, near_host, out_host, stream_stride, samples_per_call, num_calls, msInSndCardBuf, true);
+                                              const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                              int32_t samples_per_call, int32_t num_calls, int16_t msInSndCardBuf) {
+    return ProcessRecordings(b, far_host, near_host, near_clean_host, out_host, stream_stride, samples_per_call, num_calls,
+                             msInSndCardBuf, true);
 }
 
 int32_t WebRtcAecmBatch_Synchronize(AecmBatch *b) {
@@ -265,16 +268,18 @@ int32_t WebRtcAecmSessions_set_config(AecmSessions *s, AecmConfig config) {
     return s ? s->batch->SetConfig(config.cngMode, config.echoMode) : -1;
 }
 
-int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev, int16_t *out_dev,
-                                int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf) {
+int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
+                                const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples,
+                                int16_t msInSndCardBuf) {
     if (!s) return -1;
-    return s->batch->Tick(far_dev, near_dev, out_dev, stream_stride, (int)nrOfSamples, msInSndCardBuf, false);
+    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, (int)nrOfSamples, msInSndCardBuf, false);
 }
 
-int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host, int16_t *out_host,
-                                    int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf) {
+int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
+                                    const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                    size_t nrOfSamples, int16_t msInSndCardBuf) {
     if (!s) return -1;
-    return s->batch->Tick(far_host, near_host, out_host, stream_stride, (int)nrOfSamples, msInSndCardBuf, true);
+    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, (int)nrOfSamples, msInSndCardBuf, true);
 }
 
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]) {

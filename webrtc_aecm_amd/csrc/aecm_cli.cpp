@@ -173,7 +173,7 @@ int RunBatch(const char *list_path) {
         int32_t rc = WebRtcAecmBatch_Init(batch, (int32_t)rate);
         if (rc == 0) rc = WebRtcAecmBatch_set_config(batch, cfg, 0, -1);
         if (rc == 0)
-            rc = WebRtcAecmBatch_ProcessRecordingsHost(batch, far_all.data(), near_all.data(), out_all.data(), (int64_t)stride,
+            rc = WebRtcAecmBatch_ProcessRecordingsHost(batch, far_all.data(), near_all.data(), /*nearendClean*/ nullptr, out_all.data(), (int64_t)stride,
                                                        frame, (int32_t)max_calls, kMsInSndCardBuf);
         WebRtcAecmBatch_Free(batch);
         if (rc != 0) { fprintf(stderr, "batch at %u Hz failed: %d\n", rate, rc); return 1; }

@@ -182,48 +182,57 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
     return true;
 }
 
-bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, int16_t *out, int64_t stream_stride,
-                                    int frame, int n_calls, int16_t ms, bool host_pointers, int32_t *rc) {
+bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out,
+                                    int64_t stream_stride, int frame, int n_calls, int16_t ms, bool host_pointers, int32_t *rc) {
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
     const RecordingSchedule sch = BuildRecordingSchedule(fs_, frame, n_calls, ms);
     if (sch.first_error) { *rc = sch.first_error; return true; }
     *rc = sch.warned ? kWarnBadParameter : 0;
     const int64_t n_in = (int64_t)n_calls * frame, n_blk = (int64_t)sch.n_blocks * kBlock;
     const size_t S = (size_t)num_streams_;
-    // device scratch: [maps: far, near, out] + gathered far/near blocks + block outputs (+ staged I/O for host pointers)
+    const int n_near = clean ? 2 : 1;      // the clean near-end follows the near-end's schedule sample for sample
+    // device scratch: [maps: far, near, out] + gathered far/near(/clean) blocks + block outputs (+ staged I/O for host pointers)
     int32_t *maps = nullptr;
     int16_t *scratch = nullptr;
     const size_t map_elems = (size_t)(2 * n_blk + n_in);
-    const size_t io_elems = host_pointers ? 3 * S * (size_t)n_in : 0;
+    const size_t blk_elems = (size_t)(2 + n_near) * S * (size_t)n_blk;
+    const size_t io_elems = host_pointers ? (size_t)(2 + n_near) * S * (size_t)n_in : 0;
     bool ok = AECM_HIP_OK(hipMalloc((void **)&maps, std::max<size_t>(map_elems, 1) * sizeof(int32_t))) &&
-              AECM_HIP_OK(hipMalloc((void **)&scratch, std::max<size_t>(3 * S * (size_t)n_blk + io_elems, 1) * sizeof(int16_t)));
-    const int16_t *dfar = far, *dnear = near;
+              AECM_HIP_OK(hipMalloc((void **)&scratch, std::max<size_t>(blk_elems + io_elems, 1) * sizeof(int16_t)));
+    const int16_t *dfar = far, *dnear = near, *dclean = clean;
     int16_t *dout = out;
     int64_t dstride = stream_stride;
     if (ok && host_pointers) {
-        int16_t *io = scratch + 3 * S * (size_t)n_blk;
+        int16_t *io = scratch + blk_elems;
         dstride = n_in;
-        ok = AECM_HIP_OK(hipMemcpy2DAsync(io, n_in * 2, far, stream_stride * 2, n_in * 2, S, hipMemcpyHostToDevice, stream_)) &&
-             AECM_HIP_OK(hipMemcpy2DAsync(io + S * n_in, n_in * 2, near, stream_stride * 2, n_in * 2, S, hipMemcpyHostToDevice, stream_));
+        auto upload = [&](const int16_t *src, int16_t *dst) {
+            return AECM_HIP_OK(hipMemcpy2DAsync(dst, n_in * 2, src, stream_stride * 2, n_in * 2, S, hipMemcpyHostToDevice, stream_));
+        };
+        ok = upload(far, io) && upload(near, io + S * n_in) && (!clean || upload(clean, io + 3 * S * n_in));
         dfar = io;
         dnear = io + S * n_in;
         dout = io + 2 * S * n_in;
+        if (clean) dclean = io + 3 * S * n_in;
     }
     if (ok && n_blk > 0) {
         ok = AECM_HIP_OK(hipMemcpyAsync(maps, sch.far_map.data(), n_blk * sizeof(int32_t), hipMemcpyHostToDevice, stream_)) &&
              AECM_HIP_OK(hipMemcpyAsync(maps + n_blk, sch.near_map.data(), n_blk * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     }
     if (ok) ok = AECM_HIP_OK(hipMemcpyAsync(maps + 2 * n_blk, sch.out_map.data(), n_in * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    int16_t *bfar = scratch, *bnear = scratch + S * n_blk, *bout = scratch + 2 * S * n_blk;
+    int16_t *bfar = scratch, *bnear = scratch + S * n_blk, *bout = scratch + 2 * S * n_blk, *bclean = scratch + 3 * S * n_blk;
     if (ok && n_blk > 0) {
         ok = AECM_HIP_OK(LaunchGatherByMap(dfar, dstride, maps, n_blk, bfar, n_blk, num_streams_, stream_)) &&
-             AECM_HIP_OK(LaunchGatherByMap(dnear, dstride, maps + n_blk, n_blk, bnear, n_blk, num_streams_, stream_));
+             AECM_HIP_OK(LaunchGatherByMap(dnear, dstride, maps + n_blk, n_blk, bnear, n_blk, num_streams_, stream_)) &&
+             (!clean || AECM_HIP_OK(LaunchGatherByMap(dclean, dstride, maps + n_blk, n_blk, bclean, n_blk, num_streams_, stream_)));
         if (ok) {
-            IoView io{bfar, bnear, nullptr, bout, n_blk, kBlock};
+            IoView io{bfar, bnear, clean ? bclean : nullptr, bout, n_blk, kBlock};
             ok = ProcessBlocks(io, sch.n_blocks);
         }
     }
-    if (ok) ok = AECM_HIP_OK(LaunchAssembleOutput(bout, n_blk, dnear, dstride, maps + 2 * n_blk, n_in, dout, dstride, num_streams_, stream_));
+    // pass-through samples of the start-up phase come from the clean near-end when there is one
+    // (reference echo_control_mobile.cc:285-291)
+    if (ok) ok = AECM_HIP_OK(LaunchAssembleOutput(bout, n_blk, clean ? dclean : dnear, dstride, maps + 2 * n_blk, n_in, dout, dstride,
+                                                  num_streams_, stream_));
     if (ok && host_pointers)
         ok = AECM_HIP_OK(hipMemcpy2DAsync(out, stream_stride * 2, dout, n_in * 2, n_in * 2, S, hipMemcpyDeviceToHost, stream_));
     if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) ok = false;      // maps / scratch are freed below; sch goes out of scope

@@ -30,10 +30,11 @@ public:
     bool ProcessBlocksHost(const IoView &io_host, int num_blocks);     // sync
     // Whole recordings as sessions: every stream is driven like a fresh WebRtcAecm_* session by
     // n_calls x (BufferFarend, Process) of `frame` samples with a constant msInSndCardBuf
-    // (aecm_session_flow.h).  far/near/out: [S][>= n_calls*frame], device (or host) pointers.
+    // (aecm_session_flow.h).  far/near/clean/out: [S][>= n_calls*frame], device (or host) pointers; clean
+    // (WebRtcAecm_Process's nearendClean) may be null.
     // *rc receives the ABI return code a single session would have produced (0 or 12100).
-    bool ProcessRecordings(const int16_t *far, const int16_t *near, int16_t *out, int64_t stream_stride, int frame,
-                           int n_calls, int16_t ms, bool host_pointers, int32_t *rc);
+    bool ProcessRecordings(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride,
+                           int frame, int n_calls, int16_t ms, bool host_pointers, int32_t *rc);
     int fs() const { return fs_; }
     bool Synchronize();
     bool LastLaunchMs(float *ms);

@@ -55,12 +55,13 @@ enum TickSource : int32_t {
 };
 struct TickGatherCodes { int32_t far[kTickMaxBlockSamples], near[kTickMaxBlockSamples]; };
 struct TickAssembleCodes { int32_t out[kTickMaxSamples]; };
-// prepare: append the tick's n far/near samples to the rings (at far_pos / near_pos) and gather the
-// tick's nb blocks: bfar/bnear[s][j] for j in [0, nb*64).
-hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, int64_t in_stride, int n, int16_t *far_ring,
-                             int16_t *near_ring, int64_t ring_len, int64_t far_pos, int64_t near_pos, int16_t *bfar,
-                             int16_t *bnear, int n_block_samples, const TickGatherCodes &codes, int n_streams,
-                             hipStream_t stream);
+// prepare: append the tick's n far/near(/clean) samples to the rings (at far_pos / near_pos) and gather
+// the tick's nb blocks: bfar/bnear(/bclean)[s][j] for j in [0, nb*64).  clean_in == nullptr: no clean
+// near-end (clean_ring / bclean unused); the clean samples follow the near codes and positions.
+hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride, int n,
+                             int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
+                             int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int n_block_samples,
+                             const TickGatherCodes &codes, int n_streams, hipStream_t stream);
 // finish: append the nb*64 block outputs to the output ring (at out_pos) and assemble the tick's n
 // output samples.
 hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *out_ring, const int16_t *near_ring,

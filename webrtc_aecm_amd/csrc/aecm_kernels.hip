@@ -141,15 +141,17 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
 
 // ---- streaming-session sample rings --------------------------------------------------------------------
 
-__global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *near_in, int64_t in_stride, int n,
-                                         int16_t *far_ring, int16_t *near_ring, int64_t ring_len, int64_t far_pos,
-                                         int64_t near_pos, int16_t *bfar, int16_t *bnear, int nbs, int n_streams,
-                                         TickGatherCodes codes) {
+__global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
+                                         int n, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
+                                         int64_t far_pos, int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int nbs,
+                                         int n_streams, TickGatherCodes codes) {
     // one wavefront per stream (4 streams per workgroup), lanes stride over the samples
     const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
     if (s >= n_streams) return;
     const int16_t *fin = far_in + s * in_stride, *nin = near_in + s * in_stride;
+    const int16_t *cin = clean_in ? clean_in + s * in_stride : nullptr;
     int16_t *fr = far_ring + s * ring_len, *nr = near_ring + s * ring_len;
+    int16_t *cr = clean_in ? clean_ring + s * ring_len : nullptr;
     const int64_t mask = ring_len - 1;
     // reads of ring entries never alias this tick's appends: in-tick samples come from the input rows
     for (int j = threadIdx.x & 63; j < nbs; j += 64) {
@@ -157,20 +159,22 @@ __global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *n
         const int idf = cf & 0x0fffffff, idn = cn & 0x0fffffff;
         bfar[s * nbs + j] = cf < 0 ? (int16_t)0 : ((cf >> 28) == kTickFromInput ? fin[idf] : fr[idf]);
         bnear[s * nbs + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? nin[idn] : nr[idn]);
+        if (cin) bclean[s * nbs + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? cin[idn] : cr[idn]);
     }
     for (int j = threadIdx.x & 63; j < n; j += 64) {
         fr[(far_pos + j) & mask] = fin[j];
         nr[(near_pos + j) & mask] = nin[j];
+        if (cin) cr[(near_pos + j) & mask] = cin[j];
     }
 }
-hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, int64_t in_stride, int n, int16_t *far_ring,
-                             int16_t *near_ring, int64_t ring_len, int64_t far_pos, int64_t near_pos, int16_t *bfar,
-                             int16_t *bnear, int n_block_samples, const TickGatherCodes &codes, int n_streams,
-                             hipStream_t stream) {
+hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride, int n,
+                             int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
+                             int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int n_block_samples,
+                             const TickGatherCodes &codes, int n_streams, hipStream_t stream) {
     if (n_streams <= 0) return hipSuccess;
     hipLaunchKernelGGL(aecm_tick_prepare_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
-                       dim3(64 * kWavesPerWorkgroup), 0, stream, far_in, near_in, in_stride, n, far_ring, near_ring, ring_len,
-                       far_pos, near_pos, bfar, bnear, n_block_samples, n_streams, codes);
+                       dim3(64 * kWavesPerWorkgroup), 0, stream, far_in, near_in, clean_in, in_stride, n, far_ring, near_ring,
+                       clean_ring, ring_len, far_pos, near_pos, bfar, bnear, bclean, n_block_samples, n_streams, codes);
     return hipGetLastError();
 }
 

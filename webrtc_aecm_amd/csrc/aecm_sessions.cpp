@@ -18,8 +18,8 @@ SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
     bool ok = AECM_HIP_OK(hipMalloc((void **)&b->far_ring_, S * kRing * 2)) &&
               AECM_HIP_OK(hipMalloc((void **)&b->near_ring_, S * kRing * 2)) &&
               AECM_HIP_OK(hipMalloc((void **)&b->out_ring_, S * kRing * 2)) &&
-              AECM_HIP_OK(hipMalloc((void **)&b->blk_, 3 * S * 4 * kBlock * 2)) &&
-              AECM_HIP_OK(hipMalloc((void **)&b->io_dev_, 3 * S * 160 * 2));
+              AECM_HIP_OK(hipMalloc((void **)&b->blk_, 4 * S * 4 * kBlock * 2)) &&
+              AECM_HIP_OK(hipMalloc((void **)&b->io_dev_, 4 * S * 160 * 2));
     if (!ok) {
         delete b;
         return nullptr;
@@ -33,6 +33,7 @@ SessionBatch::~SessionBatch() {
     (void)hipFree(far_ring_);
     (void)hipFree(near_ring_);
     (void)hipFree(out_ring_);
+    (void)hipFree(clean_ring_);
     (void)hipFree(blk_);
     (void)hipFree(io_dev_);
 }
@@ -43,7 +44,8 @@ int32_t SessionBatch::Init(int32_t samp_freq) {
     const size_t bytes = (size_t)engine_->num_streams() * kRing * 2;
     if (!AECM_HIP_OK(hipMemsetAsync(far_ring_, 0, bytes, engine_->stream())) ||
         !AECM_HIP_OK(hipMemsetAsync(near_ring_, 0, bytes, engine_->stream())) ||
-        !AECM_HIP_OK(hipMemsetAsync(out_ring_, 0, bytes, engine_->stream())))
+        !AECM_HIP_OK(hipMemsetAsync(out_ring_, 0, bytes, engine_->stream())) ||
+        (clean_ring_ && !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, engine_->stream()))))
         return AECM_UNSPECIFIED_ERROR;
     far_pos_ = near_pos_ = blocks_done_ = 0;
     return flow_.Init(samp_freq);
@@ -59,26 +61,33 @@ int32_t SessionBatch::SetConfig(int16_t cng_mode, int16_t echo_mode) {
     return engine_->SetConfig(cng_mode, echo_mode, 0, -1) ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
-int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, int16_t *out, int64_t stride, int n, int16_t ms,
-                           bool host_pointers) {
+int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, int n,
+                           int16_t ms, bool host_pointers) {
     if (far == nullptr || near == nullptr || out == nullptr) return AECM_NULL_POINTER_ERROR;
     if (!flow_.initialized()) return AECM_UNINITIALIZED_ERROR;
     if (n != 80 && n != 160) return AECM_BAD_PARAMETER_ERROR;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
     hipStream_t st = engine_->stream();
-    const int16_t *dfar = far, *dnear = near;
+    if (clean && !clean_ring_) {
+        const size_t bytes = (size_t)S * kRing * 2;
+        if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st)))
+            return AECM_UNSPECIFIED_ERROR;
+    }
+    const int16_t *dfar = far, *dnear = near, *dclean = clean;
     int16_t *dout = out;
     int64_t dstride = stride;
     if (host_pointers) {
         dstride = 160;
-        int16_t *f = io_dev_, *d = io_dev_ + (size_t)S * 160;
+        int16_t *f = io_dev_, *d = io_dev_ + (size_t)S * 160, *c = io_dev_ + 3 * (size_t)S * 160;
         if (!AECM_HIP_OK(hipMemcpy2DAsync(f, 320, far, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
-            !AECM_HIP_OK(hipMemcpy2DAsync(d, 320, near, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)))
+            !AECM_HIP_OK(hipMemcpy2DAsync(d, 320, near, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
+            (clean && !AECM_HIP_OK(hipMemcpy2DAsync(c, 320, clean, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st))))
             return AECM_UNSPECIFIED_ERROR;
         dfar = f;
         dnear = d;
         dout = io_dev_ + 2 * (size_t)S * 160;
+        if (clean) dclean = c;
     }
     // 1. the session machinery in the index domain; a tag is the absolute sample count of a far / near
     //    sample, the tick's samples are [far_pos_, far_pos_ + n) and [near_pos_, near_pos_ + n)
@@ -90,7 +99,8 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, int16_t *out
     int n_blocks = 0;
     bool passthrough = false, stale = false;
     const int64_t out_base = blocks_done_ * kBlock;
-    rc = flow_.Process(near_tags, nullptr, out_tags, (size_t)n, ms,
+    // the clean near-end is positioned exactly like the noisy one: it shares the near tags
+    rc = flow_.Process(near_tags, clean ? near_tags : nullptr, out_tags, (size_t)n, ms,
                        [&](const int64_t *fb, const int64_t *nb, const int64_t *, int64_t *ob, int nblk) {
                            memcpy(blk_far, fb, sizeof(int64_t) * nblk * kBlock);
                            memcpy(blk_near, nb, sizeof(int64_t) * nblk * kBlock);
@@ -102,8 +112,8 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, int16_t *out
     if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) {
         // the far samples were consumed by BufferFarend: keep the rings in step with the flow
         TickGatherCodes none;
-        if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dstride, n, far_ring_, near_ring_, kRing, far_pos_, near_pos_,
-                                           blk_, blk_, 0, none, S, st)))
+        if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dclean, dstride, n, far_ring_, near_ring_, clean_ring_, kRing, far_pos_,
+                                           near_pos_, blk_, blk_, blk_, 0, none, S, st)))
             return AECM_UNSPECIFIED_ERROR;
         far_pos_ += n;
         near_pos_ += n;
@@ -135,18 +145,20 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, int16_t *out
     if (stale) return AECM_UNSPECIFIED_ERROR;
     // 3. device side of the tick: prepare -> blocks -> finish
     int16_t *bfar = blk_, *bnear = blk_ + (size_t)S * kTickMaxBlockSamples, *bout = blk_ + 2 * (size_t)S * kTickMaxBlockSamples;
-    if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dstride, n, far_ring_, near_ring_, kRing, far_pos_, near_pos_, bfar,
-                                       bnear, nbs, gather, S, st)))
+    int16_t *bclean = blk_ + 3 * (size_t)S * kTickMaxBlockSamples;
+    if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dclean, dstride, n, far_ring_, near_ring_, clean_ring_, kRing, far_pos_,
+                                       near_pos_, bfar, bnear, bclean, nbs, gather, S, st)))
         return AECM_UNSPECIFIED_ERROR;
     far_pos_ += n;
     near_pos_ += n;
     if (n_blocks > 0) {
-        IoView io{bfar, bnear, nullptr, bout, nbs, kBlock};
+        IoView io{bfar, bnear, clean ? bclean : nullptr, bout, nbs, kBlock};
         if (!engine_->ProcessBlocks(io, n_blocks)) return AECM_UNSPECIFIED_ERROR;
         blocks_done_ += n_blocks;
     }
-    if (!AECM_HIP_OK(LaunchTickFinish(bout, nbs, out_ring_, near_ring_, kRing, out_base, dnear, dstride, dout, n, assemble,
-                                      S, st)))
+    // pass-through samples come from the clean near-end when there is one (echo_control_mobile.cc:285-291)
+    if (!AECM_HIP_OK(LaunchTickFinish(bout, nbs, out_ring_, clean ? clean_ring_ : near_ring_, kRing, out_base,
+                                      clean ? dclean : dnear, dstride, dout, n, assemble, S, st)))
         return AECM_UNSPECIFIED_ERROR;
     if (host_pointers &&
         !AECM_HIP_OK(hipMemcpy2DAsync(out, stride * 2, dout, 320, (size_t)n * 2, S, hipMemcpyDeviceToHost, st)))

@@ -30,10 +30,11 @@ public:
 
     int32_t Init(int32_t samp_freq);
     int32_t SetConfig(int16_t cng_mode, int16_t echo_mode);
-    // One tick for every session; far/near/out are [S][>= n] with the given stream stride, device or
-    // host pointers.  Returns the code each session's WebRtcAecm_Process would return.
-    int32_t Tick(const int16_t *far, const int16_t *near, int16_t *out, int64_t stream_stride, int n, int16_t ms,
-                 bool host_pointers);
+    // One tick for every session; far/near/clean/out are [S][>= n] with the given stream stride, device
+    // or host pointers; clean (WebRtcAecm_Process's nearendClean) may be null.  Returns the code each
+    // session's WebRtcAecm_Process would return.
+    int32_t Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, int n,
+                 int16_t ms, bool host_pointers);
 
 private:
     SessionBatch() : flow_(-1) {}
@@ -42,8 +43,9 @@ private:
     SessionFlow<int64_t> flow_;
     int64_t far_pos_ = 0, near_pos_ = 0, blocks_done_ = 0;
     int16_t *far_ring_ = nullptr, *near_ring_ = nullptr, *out_ring_ = nullptr;   // [S][kRing]
-    int16_t *blk_ = nullptr;          // [3][S][4*64] gathered far / near blocks and block outputs of a tick
-    int16_t *io_dev_ = nullptr;       // [3][S][160] staging when the caller passes host pointers
+    int16_t *clean_ring_ = nullptr;   // [S][kRing], allocated by the first tick that carries a clean near-end
+    int16_t *blk_ = nullptr;          // [4][S][4*64] gathered far / near / clean blocks and block outputs of a tick
+    int16_t *io_dev_ = nullptr;       // [4][S][160] staging when the caller passes host pointers
     int device_ = 0;
 };
 

@@ -97,8 +97,8 @@ def load():
     lib.WebRtcAecmBatch_Control.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_ProcessBlocks.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32]
     lib.WebRtcAecmBatch_ProcessBlocksHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32]
-    lib.WebRtcAecmBatch_ProcessRecordings.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int16]
-    lib.WebRtcAecmBatch_ProcessRecordingsHost.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int16]
+    lib.WebRtcAecmBatch_ProcessRecordings.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int16]
+    lib.WebRtcAecmBatch_ProcessRecordingsHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int16]
     lib.WebRtcAecmBatch_Synchronize.argtypes = [vp]
     lib.WebRtcAecmBatch_GetLastLaunchMs.argtypes = [vp, C.POINTER(C.c_float)]
     lib.WebRtcAecmBatch_GetTimers.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -116,8 +116,8 @@ def load():
     lib.WebRtcAecmSessions_Free.restype = None
     lib.WebRtcAecmSessions_Init.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmSessions_set_config.argtypes = [vp, AecmConfig]
-    lib.WebRtcAecmSessions_Tick.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
-    lib.WebRtcAecmSessions_TickHost.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
+    lib.WebRtcAecmSessions_Tick.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
+    lib.WebRtcAecmSessions_TickHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
     lib.WebRtcAecmBatch_DebugFft128.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DeviceInfo.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -244,20 +244,27 @@ class AecmBatch:
                                                                out.ctypes.data, far.shape[1], BLOCK, t), "ProcessBlocksHost")
         return out
 
-    def process_recordings_host(self, far, near, frame: int, ms: int = 40):
-        """far/near: [S, N] int16 host arrays, each stream a whole recording driven like the reference CLI
-        (BufferFarend + Process per `frame` samples, constant msInSndCardBuf).  Returns (code, out)."""
+    def process_recordings_host(self, far, near, frame: int, ms: int = 40, clean=None):
+        """far/near(/clean): [S, N] int16 host arrays, each stream a whole recording driven like the reference
+        CLI (BufferFarend + Process per `frame` samples, constant msInSndCardBuf; clean = nearendClean).
+        Returns (code, out)."""
         far = np.ascontiguousarray(far, dtype=np.int16)
         near = np.ascontiguousarray(near, dtype=np.int16)
         assert far.shape == near.shape and far.shape[0] == self.num_streams
+        cptr = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            assert clean.shape == near.shape
+            cptr = clean.ctypes.data
         out = near.copy()
         n_calls = far.shape[1] // frame
-        rc = self.lib.WebRtcAecmBatch_ProcessRecordingsHost(self.h, far.ctypes.data, near.ctypes.data, out.ctypes.data,
+        rc = self.lib.WebRtcAecmBatch_ProcessRecordingsHost(self.h, far.ctypes.data, near.ctypes.data, cptr, out.ctypes.data,
                                                             far.shape[1], frame, n_calls, ms)
         return rc, out
 
-    def process_recordings_device(self, far_ptr, near_ptr, out_ptr, stream_stride, frame, n_calls, ms=40):
-        return self.lib.WebRtcAecmBatch_ProcessRecordings(self.h, far_ptr, near_ptr, out_ptr, stream_stride, frame, n_calls, ms)
+    def process_recordings_device(self, far_ptr, near_ptr, out_ptr, stream_stride, frame, n_calls, ms=40, clean_ptr=None):
+        return self.lib.WebRtcAecmBatch_ProcessRecordings(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, frame,
+                                                          n_calls, ms)
 
     def process_device(self, far_ptr, near_ptr, out_ptr, stream_stride, block_stride, num_blocks, clean_ptr=None):
         """Device pointers (e.g. torch .data_ptr()); asynchronous on the engine's stream."""
@@ -330,17 +337,21 @@ class AecmSessions:
         if rc != 0:
             raise AecmError(rc, "WebRtcAecmSessions_set_config")
 
-    def tick_host(self, far, near, ms: int = 40):
-        """far/near: [S, n] int16 (n = 80 or 160).  Returns (code, out)."""
+    def tick_host(self, far, near, ms: int = 40, clean=None):
+        """far/near(/clean): [S, n] int16 (n = 80 or 160).  Returns (code, out)."""
         far = np.ascontiguousarray(far, dtype=np.int16)
         near = np.ascontiguousarray(near, dtype=np.int16)
+        cptr = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            cptr = clean.ctypes.data
         out = np.empty_like(near)
-        rc = self.lib.WebRtcAecmSessions_TickHost(self.h, far.ctypes.data, near.ctypes.data, out.ctypes.data, far.shape[1],
+        rc = self.lib.WebRtcAecmSessions_TickHost(self.h, far.ctypes.data, near.ctypes.data, cptr, out.ctypes.data, far.shape[1],
                                                   far.shape[1], ms)
         return rc, out
 
-    def tick_device(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms=40):
-        return self.lib.WebRtcAecmSessions_Tick(self.h, far_ptr, near_ptr, out_ptr, stream_stride, n, ms)
+    def tick_device(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms=40, clean_ptr=None):
+        return self.lib.WebRtcAecmSessions_Tick(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n, ms)
 
     def close(self):
         if getattr(self, "h", None):

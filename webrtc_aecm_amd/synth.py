@@ -115,3 +115,9 @@ def synth_batch(base_seed: int, n_streams: int, n_blocks: int, fs: int = 16000):
     for s in range(n_streams):
         far[s], near[s] = synth_pair(base_seed + s, n_blocks, fs)
     return far, near
+
+
+def synth_clean(near):
+    """A deterministic "noise-suppressed" companion of a near-end signal (WebRtcAecm_Process's nearendClean)
+    for tests: 3/4 of the amplitude, floor division, integer only."""
+    return (np.asarray(near).astype(np.int32) * 3 // 4).astype(np.int16)
