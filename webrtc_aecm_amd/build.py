@@ -34,20 +34,35 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP/C++ source of the engine into one shared library for gfx950."""
+    """Compile every HIP/C++ source of the engine into one shared library for gfx950.
+
+    Safe to call from several processes at once (one rank per GPU under torch.distributed.run): the
+    build is serialised by a file lock and the library is moved into place atomically."""
     if not force and not is_stale():
         return LIB
+    import fcntl
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    cmd = [_hipcc(), *HIPCC_FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=str(CSRC))
-    # the command-line front end (reference main.cc equivalent + multi-file batch mode)
-    cli = ["g++", "-O2", "-std=c++17", str(CSRC / "aecm_cli.cpp"), "-o", str(CLI), f"-L{LIB_DIR}", "-laecm_mi355x",
-           "-Wl,-rpath,$ORIGIN"]
-    if verbose:
-        print(" ".join(cli))
-    subprocess.check_call(cli, cwd=str(CSRC))
+    with open(LIB_DIR / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():          # another process built it while we waited
+                return LIB
+            tmp = LIB_DIR / f".{LIB.name}.{os.getpid()}.tmp"
+            cmd = [_hipcc(), *HIPCC_FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(tmp)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=str(CSRC))
+            os.replace(tmp, LIB)
+            # the command-line front end (reference main.cc equivalent + multi-file batch mode)
+            tmp_cli = LIB_DIR / f".{CLI.name}.{os.getpid()}.tmp"
+            cli = ["g++", "-O2", "-std=c++17", str(CSRC / "aecm_cli.cpp"), "-o", str(tmp_cli), f"-L{LIB_DIR}", "-laecm_mi355x",
+                   "-Wl,-rpath,$ORIGIN"]
+            if verbose:
+                print(" ".join(cli))
+            subprocess.check_call(cli, cwd=str(CSRC))
+            os.replace(tmp_cli, CLI)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
