@@ -149,6 +149,7 @@ struct SimWave {
     static constexpr bool kLaneConstsInTable = false;
     template <int ROW> static vi table_lane_const(const vi &) { return vi(0); }   // never used (kLaneConstsInTable == false)
     static vi table_index_for_this_block() { return vi(0); }
+    static void begin_block(int, int) {}                                   // device: issue-priority rotation
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
     static bool is_first_lane() { return true; }

@@ -926,6 +926,7 @@ struct BlockEngine {
                 near_next = W::load_i16(io.near + off, r.lane);
                 if (kHasClean) clean_next = W::load_i16(io.near_clean + off, r.lane);
             }
+            W::begin_block(blk, n_blocks);
             vi out = process_block(r, hist, far_cur, near_cur, clean_cur);
             W::store_i16(io.out + base + (int64_t)blk * io.block_stride, r.brev, out);
         }

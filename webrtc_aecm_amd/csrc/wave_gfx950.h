@@ -35,6 +35,9 @@ struct LdsTables {
 static_assert(sizeof(LdsTables) == kConstBlobWords * 4, "LDS image layout (aecm_state.h) out of sync");
 extern __shared__ LdsTables g_lds[];   // one instance (dynamic LDS)
 
+#ifndef AECM_PRIORITY_ROTATION_MIN_BLOCKS
+#define AECM_PRIORITY_ROTATION_MIN_BLOCKS 8
+#endif
 #ifndef AECM_LANE_CONSTS_IN_LDS
 #define AECM_LANE_CONSTS_IN_LDS 1
 #endif
@@ -73,6 +76,21 @@ struct Gfx950Wave {
     template <int ROW>
     static __device__ __forceinline__ int table_lane_const(int index) { return g_lds[0].lane_rows[ROW][index]; }
 
+    // Called at the top of every block.  The SIMD's arbiter favours its oldest wave, so among waves that
+    // started together the oldest runs at solo speed and the youngest gets the leftovers: they finish
+    // far apart and the tail of a launch runs at low occupancy (a launch whose waves all fit on the chip
+    // at once lost 10-16 % to this).  Rotating the wave's issue priority every block, with a per-workgroup
+    // offset, shares the ports evenly over time; neutral for many-round launches.
+    static __device__ __forceinline__ void begin_block(int blk, int n_blocks) {
+        if (n_blocks < AECM_PRIORITY_ROTATION_MIN_BLOCKS) return;   // a 2-3 block tick launch is over before shares even out
+        const unsigned h = (blockIdx.x * 2654435761u) >> 16;
+        switch (((unsigned)blk + h) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
     static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool is_first_lane() { return lane_id() == 0; }
     static __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
