@@ -60,7 +60,6 @@ void sim_constants(uint32_t *blob_out, uint32_t *defined_lane_rows, uint32_t *de
     VecI wre, wim;
     uint32_t *o = defined_twiddles;
 #define SIM_TW(INV, S) SimWave::twiddles<S, INV>(wre, wim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)wre.v[t]; *o++ = (uint32_t)wim.v[t]; }
-    SIM_TW(false, 0) SIM_TW(false, 1) SIM_TW(false, 2) SIM_TW(false, 3) SIM_TW(false, 4) SIM_TW(false, 5) SIM_TW(false, 6)
     SIM_TW(true, 0) SIM_TW(true, 1) SIM_TW(true, 2) SIM_TW(true, 3) SIM_TW(true, 4) SIM_TW(true, 5) SIM_TW(true, 6)
 #undef SIM_TW
     VecI nwre, nwim, sre, cre, sim_, cim;

@@ -137,20 +137,18 @@ void BuildKernelConstants(std::vector<uint32_t> *blob) {
         lc[LC_HANN_SYN_LO * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[brev];
         lc[LC_HANN_SYN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - brev];
     }
-    // LDS image: packed twiddles (w_re = (wr, -wi), w_im = (wi, wr)) per [direction][stage][lane],
-    // wr = cos, wi = -sin (forward) / +sin (inverse) of entry m << k, m = position & (2^stage - 1)
-    // (reference complex_fft.c:296-303, 412-420); positions are bit-reversed lanes.
+    // LDS image: packed twiddles (w_re = (wr, -wi), w_im = (wi, wr)) of the inverse transform per
+    // [stage][lane]: wr = cos, wi = +sin of entry m << k, m = position & (2^stage - 1) (reference
+    // complex_fft.c:412-420; forward: wi = -sin, :296-303); positions are bit-reversed lanes.
     uint32_t *img = blob->data() + kLaneConstRows * kLanes;
-    for (int inverse = 0; inverse < 2; ++inverse)
-        for (int stage = 0; stage < 7; ++stage)
-            for (int t = 0; t < kLanes; ++t) {
-                const int idx = (BitRev6(t) & ((1 << stage) - 1)) << (6 - stage);
-                const int wr = kAecmTwiddleCosQ15[idx];
-                const int wi = inverse ? kAecmTwiddleSinQ15[idx] : -kAecmTwiddleSinQ15[idx];
-                uint32_t *e = img + ((inverse * 7 + stage) * kLanes + t) * 2;
-                e[0] = Pack16(wr, -wi);
-                e[1] = Pack16(wi, wr);
-            }
+    for (int stage = 0; stage < 7; ++stage)
+        for (int t = 0; t < kLanes; ++t) {
+            const int idx = (BitRev6(t) & ((1 << stage) - 1)) << (6 - stage);
+            const int wr = kAecmTwiddleCosQ15[idx], wi = kAecmTwiddleSinQ15[idx];
+            uint32_t *e = img + (stage * kLanes + t) * 2;
+            e[0] = Pack16(wr, -wi);
+            e[1] = Pack16(wi, wr);
+        }
     // Forward stages 1..6 in the multiply-add form of fft128 (aecm_wave.h): (w_re, w_im, -w_re, -w_im) per
     // lane, and for the even stages the accumulator offsets (s_re, 1 - s_re, s_im, 1 - s_im) with
     // s = sum of the two halves of the packed twiddle.

@@ -22,9 +22,9 @@ namespace aecm {
 // LDS tables, filled by the kernel prologue (aecm_kernels.hip).
 struct LdsTables {
     int lane_rows[kLaneConstRows][kLanes];   // LaneConstRow: per-lane constants (see lane_const() in aecm_wave.h)
-    // Packed FFT twiddles, one (w_re, w_im) pair per [direction][stage][lane]: a stage is one
+    // Packed twiddles of the inverse transform, one (w_re, w_im) pair per [stage][lane]: a stage is one
     // conflict-free ds_read_b64 at lane*8 + constant offset, no VALU address or packing work.
-    int2 twiddle[2][7][64];
+    int2 twiddle_inv[7][64];
     // Forward stages 1..6 in the multiply-add form of fft128: (w_re, w_im, -w_re, -w_im), one ds_read_b128;
     // stages 2, 4, 6 additionally (s_re, 1 - s_re, s_im, 1 - s_im).
     int4 fwd_twiddle[6][64];
@@ -100,9 +100,18 @@ struct Gfx950Wave {
     static __device__ __forceinline__ int hann(int i) { return g_lds[0].hann[i]; }
     template <int S, bool kInverse>
     static __device__ __forceinline__ void twiddles(int &w_re, int &w_im) {
-        const int2 w = g_lds[0].twiddle[kInverse ? 1 : 0][S][lane_id()];
-        w_re = w.x;
-        w_im = w.y;
+        if constexpr (kInverse) {
+            const int2 w = g_lds[0].twiddle_inv[S][lane_id()];
+            w_re = w.x;
+            w_im = w.y;
+        } else if constexpr (S == 0) {            // W^0 = (32767, 0)
+            w_re = 32767;
+            w_im = (int)(32767u << 16);
+        } else {                                  // forward stages live in the multiply-add table
+            const int4 w = g_lds[0].fwd_twiddle[S - 1][lane_id()];
+            w_re = w.x;
+            w_im = w.y;
+        }
     }
     template <int S>
     static __device__ __forceinline__ void fwd_twiddles(int &w_re, int &w_im, int &nw_re, int &nw_im) {
