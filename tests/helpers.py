@@ -49,3 +49,41 @@ def describe_digest_diff(a, b):
 
 def golden_files(prefix):
     return sorted(GOLDEN.glob(prefix + "*.npz"))
+
+
+def adversarial_cases(n_cases=24, n_blocks=1000, seed=7):
+    """Deterministic hostile inputs for the block path: full-scale noise, +-full-scale square waves,
+    constants (incl. -32768), sparse spikes, LSB dither, full-scale tones, and echo-like mixtures of
+    them; with a random configuration and (every other case) a random full-range echo path.
+    Yields dicts: far, near, fs, cng, echo_mode, path (int16[65] or None)."""
+    rs = np.random.RandomState(seed)
+
+    def nasty(n, kind):
+        if kind == 0:
+            return rs.randint(-32768, 32768, size=n).astype(np.int16)
+        if kind == 1:
+            return np.where(rs.randint(0, 2, size=n) == 1, 32767, -32768).astype(np.int16)
+        if kind == 2:
+            return np.full(n, rs.choice([-32768, 32767, 1, -1, 0, 16384]), dtype=np.int16)
+        if kind == 3:
+            x = np.zeros(n, dtype=np.int16)
+            idx = rs.randint(0, n, size=n // 50)
+            x[idx] = rs.randint(-32768, 32768, size=idx.size)
+            return x
+        if kind == 4:
+            return rs.randint(-3, 4, size=n).astype(np.int16)
+        t = np.arange(n)
+        return (32767 * np.sin(2 * np.pi * t * rs.randint(1, 60) / 128.0)).astype(np.int16)
+
+    for it in range(n_cases):
+        n = n_blocks * 64
+        far, near = nasty(n, rs.randint(0, 6)), nasty(n, rs.randint(0, 6))
+        if it % 3 == 0:
+            near = np.clip(np.roll(far.astype(np.int32), rs.randint(0, 2000)) // rs.choice([1, 2, 8, 64]) +
+                           near // rs.choice([1, 4, 64, 1024]), -32768, 32767).astype(np.int16)
+        path = None
+        if it % 2 == 1:
+            path = rs.randint(-32768, 32768, size=65).astype(np.int16) if it % 4 == 1 else \
+                rs.choice([0, 1, -1, 32767, -32768, 12000], size=65).astype(np.int16)
+        yield dict(far=far, near=near, fs=int(rs.choice([8000, 16000])), cng=int(rs.randint(0, 2)),
+                   echo_mode=int(rs.randint(0, 5)), path=path)

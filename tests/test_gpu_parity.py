@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import webrtc_aecm_amd as aecm
-from helpers import (GOLDEN, describe_digest_diff, golden_files, oracle_batch, oracle_run, stream_config,
+from helpers import (GOLDEN, adversarial_cases, describe_digest_diff, golden_files, oracle_batch, oracle_run, stream_config,
                      synth_streams)
 from oracle import pyoracle
 from webrtc_aecm_amd.synth import synth_clean, synth_pair
@@ -65,6 +65,29 @@ def test_block_parity_vs_oracle(fs, variant):
     for s in range(S):
         d = b.digest(s)
         assert np.array_equal(d, exp_dig[s]), f"state digest mismatch stream {s}: {describe_digest_diff(d, exp_dig[s])}"
+
+
+@pytest.mark.parametrize("variant", [aecm.KERNEL_FAST, aecm.KERNEL_SAFE])
+def test_adversarial_inputs_and_echo_paths(variant):
+    """Hostile signals (full-scale noise / square waves / -32768 constants / spikes / LSB dither / tones),
+    random configurations and random full-range echo paths, one case per stream of a batch, both
+    sampling rates: outputs and complete state against the oracle."""
+    cases = list(adversarial_cases())
+    for fs in (16000, 8000):
+        sel = [c for c in cases if c["fs"] == fs]
+        b = aecm.AecmBatch(len(sel), fs, variant=variant)
+        for k, c in enumerate(sel):
+            b.set_config(c["cng"], c["echo_mode"], k, 1)
+            if c["path"] is not None:
+                b.init_echo_path(k, c["path"])
+        out = b.process_host(np.stack([c["far"] for c in sel]), np.stack([c["near"] for c in sel]))
+        for k, c in enumerate(sel):
+            o = pyoracle.OracleStream(fs, c["cng"], c["echo_mode"])
+            if c["path"] is not None:
+                o.init_echo_path(c["path"])
+            assert np.array_equal(out[k], o.process(c["far"], c["near"])), (fs, k)
+            d = b.digest(k)
+            assert np.array_equal(d, o.digest()), (fs, k, describe_digest_diff(d, o.digest()))
 
 
 def test_chunked_launches_equal_one_launch():

@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from helpers import describe_digest_diff, golden_files
+from helpers import adversarial_cases, describe_digest_diff, golden_files
 from oracle import pyoracle
 from webrtc_aecm_amd.synth import PROFILES, synth_pair
 
@@ -149,31 +149,11 @@ def test_oracle_equals_reference_long_silence_control_and_clean():
 
 @needs_ref
 def test_oracle_equals_reference_on_adversarial_inputs():
-    rs = np.random.RandomState(7)
-
-    def nasty(n, kind):
-        if kind == 0:
-            return rs.randint(-32768, 32768, size=n).astype(np.int16)
-        if kind == 1:
-            return np.where(rs.randint(0, 2, size=n) == 1, 32767, -32768).astype(np.int16)
-        if kind == 2:
-            return np.full(n, rs.choice([-32768, 32767, 1, -1, 0, 16384]), dtype=np.int16)
-        if kind == 3:
-            x = np.zeros(n, dtype=np.int16)
-            idx = rs.randint(0, n, size=n // 50)
-            x[idx] = rs.randint(-32768, 32768, size=idx.size)
-            return x
-        if kind == 4:
-            return rs.randint(-3, 4, size=n).astype(np.int16)
-        t = np.arange(n)
-        return (32767 * np.sin(2 * np.pi * t * rs.randint(1, 60) / 128.0)).astype(np.int16)
-    for it in range(24):
-        n = 1000 * 64
-        far, near = nasty(n, rs.randint(0, 6)), nasty(n, rs.randint(0, 6))
-        if it % 3 == 0:
-            near = np.clip(np.roll(far.astype(np.int32), rs.randint(0, 2000)) // rs.choice([1, 2, 8, 64]) +
-                           near // rs.choice([1, 4, 64, 1024]), -32768, 32767).astype(np.int16)
-        fs, cng, em = int(rs.choice([8000, 16000])), int(rs.randint(0, 2)), int(rs.randint(0, 5))
-        o, r = pyoracle.OracleStream(fs, cng, em), pyoracle.RefCoreStream(fs, cng, em)
-        assert np.array_equal(o.process(far, near), r.process(far, near)), it
+    """Hostile signals, random configurations and random full-range echo paths (WebRtcAecm_InitEchoPath)."""
+    for it, c in enumerate(adversarial_cases()):
+        o, r = pyoracle.OracleStream(c["fs"], c["cng"], c["echo_mode"]), pyoracle.RefCoreStream(c["fs"], c["cng"], c["echo_mode"])
+        if c["path"] is not None:
+            o.init_echo_path(c["path"])
+            r.init_echo_path(c["path"])
+        assert np.array_equal(o.process(c["far"], c["near"]), r.process(c["far"], c["near"])), it
         assert np.array_equal(o.digest(), r.digest()), it

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import simlib
-from helpers import describe_digest_diff, golden_files
+from helpers import adversarial_cases, describe_digest_diff, golden_files
 from oracle import pyoracle
 from webrtc_aecm_amd.synth import synth_clean, synth_pair
 
@@ -85,6 +85,19 @@ def test_wave_dsp_full_scale_and_zero_inputs():
         o, s = pyoracle.OracleStream(16000, 1, 3), simlib.SimStream(16000, 1, 3)
         assert np.array_equal(o.process(far, near), s.process(far, near)), i
         assert np.array_equal(o.digest(), s.digest()), i
+
+
+def test_wave_dsp_adversarial_inputs_and_echo_paths():
+    """Hostile signals, random configurations and random full-range echo paths through the kernel source
+    on the lane simulator: bit-exact against the oracle, and none of the checked preconditions
+    (mul24 operand range, as_i16 narrowing) may fire."""
+    for it, c in enumerate(adversarial_cases()):
+        o, s = pyoracle.OracleStream(c["fs"], c["cng"], c["echo_mode"]), simlib.SimStream(c["fs"], c["cng"], c["echo_mode"])
+        if c["path"] is not None:
+            o.init_echo_path(c["path"])
+            s.init_echo_path(c["path"])
+        assert np.array_equal(o.process(c["far"], c["near"]), s.process(c["far"], c["near"])), it
+        assert np.array_equal(o.digest(), s.digest()), (it, describe_digest_diff(o.digest(), s.digest()))
 
 
 def test_echo_path_import_export():
