@@ -277,6 +277,22 @@ def test_session_abi_golden():
         s.close()
 
 
+def test_session_60s_cli_shaped_run_matches_reference_hash():
+    """one stream, 60 s at 16 kHz, through the session ABI exactly as the reference
+    CLI drives it (main.cc:102-145); the reference's output is pinned by its SHA-256.  Also as one
+    recording of a device batch."""
+    far, near = synth_pair(60, 15000, 16000, "mixed")
+    want = (GOLDEN / "session_60s_16k.sha256").read_text().strip()
+    s = aecm.Aecm()
+    assert s.init(16000) == 0 and s.set_config(1, 1) == 0
+    out, codes = _run_session(s, far, near, 160, 40)
+    s.close()
+    assert codes == {0} and hashlib.sha256(out.tobytes()).hexdigest() == want
+    b = aecm.AecmBatch(2, 16000, 1, 1)
+    rc, outs = b.process_recordings_host(np.stack([far, far]), np.stack([near, near]), 160, 40)
+    assert rc == 0 and hashlib.sha256(outs[1].tobytes()).hexdigest() == want
+
+
 def test_batched_recordings_equal_individual_sessions():
     """WebRtcAecmBatch_ProcessRecordingsHost: S recordings as S sessions in one device batch (with and
     without a nearendClean input)."""

@@ -139,6 +139,19 @@ def test_session_host_logic_matches_reference_fixtures():
         assert np.array_equal(out, g["out"]), f.name
 
 
+def test_session_60s_cli_shaped_run_matches_reference_hash():
+    """the reference CLI's procedure (main.cc: 160-sample calls, cng on, echoMode 1,
+    ms 40) on a 60 s 16 kHz pair; the reference's result is pinned by its SHA-256."""
+    import hashlib
+    from helpers import GOLDEN
+    far, near = synth_pair(60, 15000, 16000, "mixed")
+    s = simlib.SimSession()
+    assert s.init(16000) == 0 and s.set_config(1, 1) == 0
+    out, codes = _run(s, far, near, 160, 40)
+    assert codes == {0}
+    assert hashlib.sha256(out.tobytes()).hexdigest() == (GOLDEN / "session_60s_16k.sha256").read_text().strip()
+
+
 def test_session_error_codes_and_ownership_rules():
     s = simlib.SimSession()
     z = np.zeros(160, dtype=np.int16)
