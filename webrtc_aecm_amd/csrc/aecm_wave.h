@@ -496,8 +496,7 @@ struct BlockEngine {
                                  int mu) {
         I zeros_ch = norm_u32(s.ch_adapt32);
         I zeros_far = norm_u32(far);
-        auto safe = (zeros_ch + zeros_far) > 31;
-        I shift_ch_far = sel(safe, I(0), I(32) - zeros_ch - zeros_far);                       // :836-850
+        I shift_ch_far = imax(I(32) - zeros_ch - zeros_far, I(0));                            // :836-850: 0 when zeros_ch + zeros_far > 31
         I u1 = mul(sel(shift_ch_far >= 32, I(0), sar(s.ch_adapt32, shift_ch_far)), far);
         I zeros_num = norm_u32(u1);                                                           // :852-867
         I zeros_dfa = sel(dfa != 0, norm_u32(dfa), I(32));
@@ -511,8 +510,7 @@ struct BlockEngine {
         I t1 = sub(u2, u1);
         zeros_num = norm_w32(t1);
         auto update = (t1 != 0) & (far > shl(I(kChannelVad), far_q));                         // :873
-        auto safe2 = (zeros_num + zeros_far) > 31;                                            // :886-902
-        I shift_num = sel(safe2, I(0), I(32) - (zeros_num + zeros_far));
+        I shift_num = imax(I(32) - (zeros_num + zeros_far), I(0));                            // :886-902: 0 when the sum > 31
         auto pos = t1 > 0;
         I t2 = mul(sar(sel(pos, t1, neg(t1)), shift_num), far);
         t2 = sel(pos, t2, neg(t2));
