@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry point (WebRtcAecmBatch_ProcessBlocksHost): far/near in
+pageable host memory in, out in pageable host memory out.  Not the headline metric (bench.py keeps the
+audio resident in HBM); a row for DESIGN.md."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=65536)
+    ap.add_argument("--blocks", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    import webrtc_aecm_amd as aecm
+    S, T = a.streams, a.blocks
+    rs = np.random.RandomState(1)
+    far = (rs.standard_normal((S, T * 64)).astype(np.float32) * 3000).clip(-32768, 32767).astype(np.int16)
+    near = (np.roll(far, 37, axis=1) // 3).astype(np.int16)
+    b = aecm.AecmBatch(S, 16000, 1, 1)
+    b.process_host(far, near)                                   # warm-up (allocations, first touch)
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        b.process_host(far, near)
+    dt = (time.perf_counter() - t0) / a.reps
+    frames = S * T
+    print(json.dumps({"streams": S, "blocks": T, "s_per_call": dt, "frames_per_s": frames / dt,
+                      "GBps_over_the_boundary": frames * 384 / dt / 1e9}))
+
+
+if __name__ == "__main__":
+    main()
