@@ -90,6 +90,36 @@ def test_adversarial_inputs_and_echo_paths(variant):
             assert np.array_equal(d, o.digest()), (fs, k, describe_digest_diff(d, o.digest()))
 
 
+def test_host_buffer_pipeline_many_streams():
+    """WebRtcAecmBatch_ProcessBlocksHost with enough streams for the chunked upload / compute / download
+    pipeline (ragged last chunk), with and without the clean input: every stream against the oracle."""
+    S, T, K = 2 * 8192 + 260, 40, 16
+    pairs = [synth_pair(300 + k, T, 16000) for k in range(K)]
+    idx = np.arange(S) % K
+    far = np.stack([p[0] for p in pairs])[idx]
+    near = np.stack([p[1] for p in pairs])[idx]
+    for with_clean in (False, True):
+        clean = synth_clean(near) if with_clean else None
+        b = aecm.AecmBatch(S, 16000, 1, 3)
+        out = b.process_host(far, near, clean)
+        for k in range(K):
+            o = pyoracle.OracleStream(16000, 1, 3)
+            exp = o.process(pairs[k][0], pairs[k][1]) if not with_clean else np.concatenate(
+                [o.process_block_clean(pairs[k][0][j * 64:(j + 1) * 64], pairs[k][1][j * 64:(j + 1) * 64],
+                                       synth_clean(pairs[k][1])[j * 64:(j + 1) * 64]) for j in range(T)])
+            rows = out[idx == k]
+            assert np.array_equal(rows, np.broadcast_to(exp, rows.shape)), (with_clean, k)
+        for s in (0, 8191, 8192, S - 1):
+            o = pyoracle.OracleStream(16000, 1, 3)
+            if with_clean:
+                for j in range(T):
+                    o.process_block_clean(far[s][j * 64:(j + 1) * 64], near[s][j * 64:(j + 1) * 64], clean[s][j * 64:(j + 1) * 64])
+            else:
+                o.process(far[s], near[s])
+            assert np.array_equal(b.digest(s), o.digest()), (with_clean, s)
+        b.close()
+
+
 def test_chunked_launches_equal_one_launch():
     """State written back at the end of a launch and reloaded by the next must lose nothing."""
     S, T, fs = 16, 1300, 16000

@@ -2,9 +2,12 @@
 
 #include "aecm_session_flow.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace aecm {
@@ -55,6 +58,7 @@ BatchEngine::~BatchEngine() {
     (void)hipFree(patch_dev_);
     (void)hipFree(consts_dev_);
     (void)hipFree(stage_dev_);
+    if (download_stream_) (void)hipStreamDestroy(download_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -147,6 +151,8 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
         stage_elems_ = need;
     }
     const bool dense = io.block_stride == kBlock && io.stream_stride == (int64_t)num_blocks * kBlock;
+    static const bool pipeline = [] { const char *e = getenv("AECM_HOST_PIPELINE"); return !(e && e[0] == '0'); }();
+    if (pipeline && dense && num_streams_ >= 2 * kHostChunkStreams) return ProcessBlocksHostPipelined(io, num_blocks);
     std::vector<int16_t> tmp;
     auto upload = [&](const int16_t *src, int16_t *dst) -> bool {
         if (dense) return AECM_HIP_OK(hipMemcpyAsync(dst, src, per * sizeof(int16_t), hipMemcpyHostToDevice, stream_));
@@ -180,6 +186,65 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
             memcpy(io.out + s * io.stream_stride + b * io.block_stride, &tmp[((size_t)s * num_blocks + b) * kBlock],
                    kBlock * sizeof(int16_t));
     return true;
+}
+
+// Dense host buffers, many streams: the streams are cut into chunks; a helper thread downloads chunk k
+// (pageable-memory copies block their host thread) while this thread uploads and launches chunk k + 1,
+// so both directions of the link are busy.
+bool BatchEngine::ProcessBlocksHostPipelined(const IoView &io, int num_blocks) {
+    const size_t row = (size_t)num_blocks * kBlock;                       // samples per stream
+    const int n_in = io.near_clean ? 3 : 2;
+    const size_t per = (size_t)num_streams_ * row;
+    if (!download_stream_ && !AECM_HIP_OK(hipStreamCreateWithFlags(&download_stream_, hipStreamNonBlocking))) return false;
+    if (!FlushTimers()) return false;
+    const int n_chunks = (num_streams_ + kHostChunkStreams - 1) / kHostChunkStreams;
+    std::vector<hipEvent_t> done(n_chunks, nullptr);
+    bool ok = true;
+    for (auto &e : done) ok = ok && AECM_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int16_t *dfar = stage_dev_, *dnear = stage_dev_ + per, *dclean = stage_dev_ + 2 * per, *dout = stage_dev_ + (size_t)n_in * per;
+    std::atomic<int> launched{0};
+    std::atomic<bool> failed{!ok};
+    std::thread downloader([&] {
+        if (!AECM_HIP_OK(hipSetDevice(device_))) { failed = true; return; }
+        for (int k = 0; k < n_chunks; ++k) {
+            while (launched.load(std::memory_order_acquire) <= k) {
+                if (failed.load()) return;
+                std::this_thread::yield();
+            }
+            const size_t first = (size_t)k * kHostChunkStreams;
+            const size_t count = std::min<size_t>(kHostChunkStreams, num_streams_ - first);
+            if (!AECM_HIP_OK(hipEventSynchronize(done[k])) ||
+                !AECM_HIP_OK(hipMemcpyAsync(io.out + first * row, dout + first * row, count * row * sizeof(int16_t),
+                                            hipMemcpyDeviceToHost, download_stream_)) ||
+                !AECM_HIP_OK(hipStreamSynchronize(download_stream_))) {
+                failed = true;
+                return;
+            }
+        }
+    });
+    for (int k = 0; k < n_chunks && !failed.load(); ++k) {
+        const size_t first = (size_t)k * kHostChunkStreams;
+        const size_t count = std::min<size_t>(kHostChunkStreams, num_streams_ - first);
+        const size_t off = first * row, bytes = count * row * sizeof(int16_t);
+        bool up = AECM_HIP_OK(hipMemcpyAsync(dfar + off, io.far + off, bytes, hipMemcpyHostToDevice, stream_)) &&
+                  AECM_HIP_OK(hipMemcpyAsync(dnear + off, io.near + off, bytes, hipMemcpyHostToDevice, stream_)) &&
+                  (!io.near_clean || AECM_HIP_OK(hipMemcpyAsync(dclean + off, io.near_clean + off, bytes, hipMemcpyHostToDevice, stream_)));
+        StatePtrs st = st_;
+        st.vec += first * kVecWordsPerStream;
+        st.scal += first * kNumScal;
+        st.hist += first * kHistWordsPerStream;
+        IoView dev{dfar + off, dnear + off, io.near_clean ? dclean + off : nullptr, dout + off, (int64_t)row, kBlock};
+        up = up && AECM_HIP_OK(LaunchProcessBlocks(st, dev, (int)count, num_blocks, variant_, stream_)) &&
+             AECM_HIP_OK(hipEventRecord(done[k], stream_));
+        if (!up) failed = true;
+        launched.store(k + 1, std::memory_order_release);
+    }
+    if (failed.load()) launched.store(n_chunks, std::memory_order_release);      // let the helper fall out of its wait
+    downloader.join();
+    ok = !failed.load() && AECM_HIP_OK(hipStreamSynchronize(stream_));
+    for (auto e : done)
+        if (e) (void)hipEventDestroy(e);
+    return ok;
 }
 
 bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out,

@@ -72,6 +72,9 @@ private:
     // staging for ProcessBlocksHost
     int16_t *stage_dev_ = nullptr;
     size_t stage_elems_ = 0;
+    static constexpr int kHostChunkStreams = 8192;
+    bool ProcessBlocksHostPipelined(const IoView &io_host, int num_blocks);
+    hipStream_t download_stream_ = nullptr;    // ProcessBlocksHost: downloads overlap the next chunk's uploads
 };
 
 }  // namespace aecm

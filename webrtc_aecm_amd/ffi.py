@@ -229,12 +229,14 @@ class AecmBatch:
     def set_variant(self, variant):
         self._check(self.lib.WebRtcAecmBatch_SetKernelVariant(self.h, variant), "SetKernelVariant")
 
-    def process_host(self, far, near, clean=None):
-        """far/near: [S, T*64] int16 host arrays (stream-major).  Returns out [S, T*64]."""
+    def process_host(self, far, near, clean=None, out=None):
+        """far/near: [S, T*64] int16 host arrays (stream-major).  Returns out [S, T*64] (written into `out` if given)."""
         far = np.ascontiguousarray(far, dtype=np.int16)
         near = np.ascontiguousarray(near, dtype=np.int16)
         assert far.shape == near.shape and far.shape[0] == self.num_streams and far.shape[1] % BLOCK == 0
-        out = np.empty_like(near)
+        if out is None:
+            out = np.empty_like(near)
+        assert out.shape == near.shape and out.dtype == np.int16 and out.flags.c_contiguous
         cp = None
         if clean is not None:
             clean = np.ascontiguousarray(clean, dtype=np.int16)
