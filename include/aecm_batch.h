@@ -120,6 +120,21 @@ int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, co
                                     const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
                                     size_t nrOfSamples, int16_t msInSndCardBuf);
 
+/* The same with one msInSndCardBuf per session (host array, S entries): session s runs
+ *     WebRtcAecm_Process(inst_s, ..., msInSndCardBuf_host[s]).
+ * codes_host (S entries, may be NULL) receives each session's return code; the function returns 0 or the
+ * first non-zero code.  Sessions with identical msInSndCardBuf histories share one host-side session flow;
+ * at most 1024 distinct histories per object (AECM_UNSUPPORTED_FUNCTION_ERROR beyond that; sessions whose
+ * delay reports jitter independently belong in smaller objects).  Tick and TickPerSession may be mixed. */
+int32_t WebRtcAecmSessions_TickPerSession(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
+                                          const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                          size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host);
+int32_t WebRtcAecmSessions_TickPerSessionHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
+                                              const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                              size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host);
+/* Number of distinct msInSndCardBuf histories currently tracked (diagnostics). */
+int32_t WebRtcAecmSessions_num_flow_classes(AecmSessions *s);
+
 /* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */
 int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
 

@@ -82,7 +82,7 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
     }
     return true;
 }
-bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks) { return ProcessBlocksHost(io, num_blocks); }
+bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks, const int32_t *) { return ProcessBlocksHost(io, num_blocks); }
 bool BatchEngine::Synchronize() { return true; }
 bool BatchEngine::FlushTimers() { return true; }
 bool BatchEngine::LastLaunchMs(float *ms) { *ms = 0.f; return true; }

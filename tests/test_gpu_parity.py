@@ -369,10 +369,57 @@ def test_streaming_session_batch_ticks_equal_individual_sessions():
         for i in range(n_ticks):
             sl = slice(i * frame, (i + 1) * frame)
             rc, out = sb.tick_host(far[:, sl], near[:, sl], ms_seq[i], None if clean is None else clean[:, sl])
+            assert rc in (0, aecm.ffi.AECM_BAD_PARAMETER_WARNING), (fs, i, rc)
             for k in (0, S - 1):
                 assert singles[k].buffer_farend(far[k, sl]) == 0
                 rc1, o1 = singles[k].process(near[k, sl], None if clean is None else clean[k, sl], ms_seq[i])
                 assert rc == rc1 and np.array_equal(out[k], o1), (fs, frame, i, k)
+        for s in singles:
+            s.close()
+        sb.close()
+
+
+def test_streaming_ticks_with_per_session_sound_card_delay():
+    """WebRtcAecmSessions_TickPerSession: every session has its own msInSndCardBuf history (constant per
+    session, out-of-range values, a mid-run change, and a uniform Tick mixed in); each must equal an
+    individual WebRtcAecm_* session driven with the same values."""
+    rs = np.random.RandomState(21)
+    for fs, frame, with_clean in ((16000, 160, 0), (8000, 80, 1)):
+        S, secs = 12, 4
+        pairs = [synth_pair(90 + k, secs * fs // 64, fs, "mixed") for k in range(S)]
+        n_ticks = pairs[0][0].size // frame
+        far = np.stack([p[0][:n_ticks * frame] for p in pairs])
+        near = np.stack([p[1][:n_ticks * frame] for p in pairs])
+        clean = synth_clean(near) if with_clean else None
+        base_ms = np.array([40, 40, 100, 250, -5, 700, 0, 40, 130, 100, 60, 40], dtype=np.int16)
+        sb = aecm.AecmSessions(S, fs, 1, 3)
+        singles = []
+        for k in range(S):
+            s = aecm.Aecm()
+            assert s.init(fs) == 0 and s.set_config(1, 3) == 0
+            singles.append(s)
+        for i in range(n_ticks):
+            sl = slice(i * frame, (i + 1) * frame)
+            ms = base_ms.copy()
+            if i >= n_ticks // 2:
+                ms[1] = 90                                    # session 1 changes its delay report mid-run
+            if i % 50 == 49:
+                ms[7] = int(rs.randint(0, 400))               # session 7 jitters now and then
+            c = None if clean is None else clean[:, sl]
+            if i % 97 == 96:                                  # a uniform tick in between
+                ms[:] = 55
+                rc, out = sb.tick_host(far[:, sl], near[:, sl], 55, c)
+                codes = np.full(S, rc)
+            else:
+                rc, out, codes = sb.tick_host_per_session(far[:, sl], near[:, sl], ms, c)
+            assert rc in (0, aecm.ffi.AECM_BAD_PARAMETER_WARNING), (fs, i, rc)
+            for k in range(S):
+                assert singles[k].buffer_farend(far[k, sl]) == 0
+                rc1, o1 = singles[k].process(near[k, sl], None if clean is None else clean[k, sl], int(ms[k]))
+                if i % 97 != 96:
+                    assert codes[k] == rc1, (fs, i, k)
+                assert np.array_equal(out[k], o1), (fs, frame, i, k)
+        assert 6 <= sb.num_flow_classes() <= aecm.AecmSessions.MAX_FLOW_CLASSES
         for s in singles:
             s.close()
         sb.close()

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--streams", type=int, default=65536)
     ap.add_argument("--fs", type=int, default=16000)
     ap.add_argument("--ticks", type=int, default=300)
+    ap.add_argument("--classes", type=int, default=1,
+                    help="distinct msInSndCardBuf values among the sessions (> 1: WebRtcAecmSessions_TickPerSession)")
     args = ap.parse_args()
     import torch
 
@@ -29,9 +31,15 @@ def main():
     sess = aecm.AecmSessions(S, fs, 1, 1)
     torch.cuda.synchronize()
 
+    import numpy as np
+    ms = (40 + (np.arange(S) % args.classes)).astype(np.int16)          # distinct values in [40, 40 + classes)
+
     def tick(i):
         off = (i % 8) * n * 2
-        rc = sess.tick_device(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, 40)
+        if args.classes > 1:
+            rc = sess.tick_device_per_session(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, ms)
+        else:
+            rc = sess.tick_device(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, 40)
         assert rc == 0, rc
     for i in range(40):                               # through the start-up phase
         tick(i)
@@ -42,7 +50,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.ticks
     blocks_per_tick = n / 64.0
-    print(json.dumps({"streams": S, "fs": fs, "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
+    print(json.dumps({"streams": S, "fs": fs, "flow_classes": sess.num_flow_classes(), "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
                       "realtime_streams_per_gpu": int(S * 0.010 / dt)}))
 
 

@@ -272,15 +272,37 @@ int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const i
                                 const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples,
                                 int16_t msInSndCardBuf) {
     if (!s) return -1;
-    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, (int)nrOfSamples, msInSndCardBuf, false);
+    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, (int)nrOfSamples, msInSndCardBuf, nullptr,
+                          nullptr, false);
 }
 
 int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
                                     const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
                                     size_t nrOfSamples, int16_t msInSndCardBuf) {
     if (!s) return -1;
-    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, (int)nrOfSamples, msInSndCardBuf, true);
+    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, (int)nrOfSamples, msInSndCardBuf,
+                          nullptr, nullptr, true);
 }
+
+int32_t WebRtcAecmSessions_TickPerSession(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
+                                          const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                          size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host) {
+    if (!s) return -1;
+    if (!msInSndCardBuf_host) return AECM_NULL_POINTER_ERROR;
+    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, (int)nrOfSamples, 0, msInSndCardBuf_host,
+                          codes_host, false);
+}
+
+int32_t WebRtcAecmSessions_TickPerSessionHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
+                                              const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                              size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host) {
+    if (!s) return -1;
+    if (!msInSndCardBuf_host) return AECM_NULL_POINTER_ERROR;
+    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, (int)nrOfSamples, 0,
+                          msInSndCardBuf_host, codes_host, true);
+}
+
+int32_t WebRtcAecmSessions_num_flow_classes(AecmSessions *s) { return s ? s->batch->num_flow_classes() : -1; }
 
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]) {
     if (!failures) return AECM_NULL_POINTER_ERROR;

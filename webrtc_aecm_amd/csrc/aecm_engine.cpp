@@ -127,11 +127,11 @@ bool BatchEngine::FlushTimers() {
     return true;
 }
 
-bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks) {
+bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks, const int32_t *blocks_per_stream_dev) {
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
     if (!FlushTimers()) return false;            // the event pair is reused: harvest the previous launch first
     if (!AECM_HIP_OK(hipEventRecord(ev_start_, stream_))) return false;
-    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, io, num_streams_, num_blocks, variant_, stream_))) return false;
+    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, io, num_streams_, num_blocks, variant_, stream_, blocks_per_stream_dev))) return false;
     if (!AECM_HIP_OK(hipEventRecord(ev_stop_, stream_))) return false;
     timed_pending_ = true;
     return true;

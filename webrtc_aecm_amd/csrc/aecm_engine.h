@@ -26,7 +26,8 @@ public:
     bool SetConfig(int cng_mode, int echo_mode, int first, int count);
     bool SetCngMode(int cng_mode, int first, int count);
     bool Control(int fixed_delay, int nlp_flag, int first, int count);
-    bool ProcessBlocks(const IoView &io_dev, int num_blocks);          // async
+    // async; blocks_per_stream_dev (may be null): per-stream block counts <= num_blocks
+    bool ProcessBlocks(const IoView &io_dev, int num_blocks, const int32_t *blocks_per_stream_dev = nullptr);
     bool ProcessBlocksHost(const IoView &io_host, int num_blocks);     // sync
     // Whole recordings as sessions: every stream is driven like a fresh WebRtcAecm_* session by
     // n_calls x (BufferFarend, Process) of `frame` samples with a constant msInSndCardBuf

@@ -20,8 +20,10 @@ enum KernelVariant : int {
 };
 
 // Process n_blocks consecutive blocks of streams [0, n_streams) -- one wavefront per stream.
+// blocks_per_stream (device, may be null): stream s processes blocks_per_stream[s] <= n_blocks blocks
+// instead (streaming sessions whose flow classes are out of phase).
 hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
-                               hipStream_t stream);
+                               hipStream_t stream, const int32_t *blocks_per_stream = nullptr);
 
 // Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into
 // streams [first, first + count) and clear their far-spectrum history.
@@ -55,11 +57,13 @@ enum TickSource : int32_t {
 };
 struct TickGatherCodes { int32_t far[kTickMaxBlockSamples], near[kTickMaxBlockSamples]; };
 struct TickAssembleCodes { int32_t out[kTickMaxSamples]; };
-// prepare: append the tick's n far/near(/clean) samples to the rings (at far_pos / near_pos) and gather
-// the tick's nb blocks: bfar/bnear(/bclean)[s][j] for j in [0, nb*64).  clean_in == nullptr: no clean
-// near-end (clean_ring / bclean unused); the clean samples follow the near codes and positions.
+// prepare: append the tick's first n_far far and all n near(/clean) samples to the rings (at far_pos /
+// near_pos) and gather the tick's nb blocks: bfar/bnear(/bclean)[s][j] for j in [0, nb*64).  The far ring
+// only takes what the session's jitter buffer accepted (a saturated one drops the rest), so a far tag is
+// the count of ACCEPTED samples and never outlives the ring.  clean_in == nullptr: no clean near-end
+// (clean_ring / bclean unused); the clean samples follow the near codes and positions.
 hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride, int n,
-                             int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
+                             int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
                              int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int n_block_samples,
                              const TickGatherCodes &codes, int n_streams, hipStream_t stream);
 // finish: append the nb*64 block outputs to the output ring (at out_pos) and assemble the tick's n
@@ -67,6 +71,27 @@ hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, cons
 hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *out_ring, const int16_t *near_ring,
                             int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride, int16_t *out,
                             int n, const TickAssembleCodes &codes, int n_streams, hipStream_t stream);
+
+// Sessions whose msInSndCardBuf histories differ live in different flow classes (aecm_sessions.h): the
+// per-sample source codes then come from a device table indexed by the stream's class, and the block
+// buffers use a fixed row stride of kTickMaxBlockSamples.
+struct TickClassEntry {
+    int32_t n_block_samples;     // blocks of this tick * 64
+    int32_t n_far;               // how many of the tick's far samples the jitter buffer accepted (the first n_far)
+    int64_t far_pos;             // where they go in the far ring
+    int64_t out_pos;             // where this class's block outputs go in the output ring
+    TickGatherCodes gather;
+    TickAssembleCodes assemble;
+};
+hipError_t LaunchTickPrepareClasses(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
+                                    int n, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
+                                    int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean,
+                                    const int32_t *class_of_stream, const TickClassEntry *table, int32_t *blocks_per_stream,
+                                    int n_streams, hipStream_t stream);
+hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
+                                   const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
+                                   const int32_t *class_of_stream, const TickClassEntry *table, int n_streams,
+                                   hipStream_t stream);
 
 // Diagnostics: `count` independent 128-point transforms of the block kernel's fft128, one wavefront
 // each, on natural-order data (data[k] = re[128] then im[128] of transform k, in place).  variant:

@@ -32,28 +32,31 @@ __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
 #endif
 template <bool kFast, bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
-void aecm_process_kernel(StatePtrs st, IoView io, int n_streams,
-                                                                              int n_blocks) {
+void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, const int32_t *blocks_per_stream) {
     FillLdsTables(st.consts);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t stream = (int64_t)blockIdx.x * kWavesPerWorkgroup + wave;
     if (stream >= n_streams) return;
+    if (blocks_per_stream) {
+        n_blocks = __builtin_amdgcn_readfirstlane(blocks_per_stream[stream]);
+        if (n_blocks <= 0) return;
+    }
     BlockEngine<Gfx950Wave<kFast>, kHasClean>::run_stream(st, io, stream, n_blocks);
 }
 
 hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
-                               hipStream_t stream) {
+                               hipStream_t stream, const int32_t *blocks_per_stream) {
     if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
     const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup);
     const dim3 block(64 * kWavesPerWorkgroup);
     const size_t lds = sizeof(LdsTables);
     const bool clean = io.near_clean != nullptr;
     if (variant == kVariantFast) {
-        if (clean) hipLaunchKernelGGL((aecm_process_kernel<true, true>), grid, block, lds, stream, st, io, n_streams, n_blocks);
-        else hipLaunchKernelGGL((aecm_process_kernel<true, false>), grid, block, lds, stream, st, io, n_streams, n_blocks);
+        if (clean) hipLaunchKernelGGL((aecm_process_kernel<true, true>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
+        else hipLaunchKernelGGL((aecm_process_kernel<true, false>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
     } else {
-        if (clean) hipLaunchKernelGGL((aecm_process_kernel<false, true>), grid, block, lds, stream, st, io, n_streams, n_blocks);
-        else hipLaunchKernelGGL((aecm_process_kernel<false, false>), grid, block, lds, stream, st, io, n_streams, n_blocks);
+        if (clean) hipLaunchKernelGGL((aecm_process_kernel<false, true>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
+        else hipLaunchKernelGGL((aecm_process_kernel<false, false>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
     }
     return hipGetLastError();
 }
@@ -142,7 +145,7 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
 // ---- streaming-session sample rings --------------------------------------------------------------------
 
 __global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
-                                         int n, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
+                                         int n, int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
                                          int64_t far_pos, int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int nbs,
                                          int n_streams, TickGatherCodes codes) {
     // one wavefront per stream (4 streams per workgroup), lanes stride over the samples
@@ -162,18 +165,18 @@ __global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *n
         if (cin) bclean[s * nbs + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? cin[idn] : cr[idn]);
     }
     for (int j = threadIdx.x & 63; j < n; j += 64) {
-        fr[(far_pos + j) & mask] = fin[j];
+        if (j < n_far) fr[(far_pos + j) & mask] = fin[j];
         nr[(near_pos + j) & mask] = nin[j];
         if (cin) cr[(near_pos + j) & mask] = cin[j];
     }
 }
 hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride, int n,
-                             int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
+                             int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
                              int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int n_block_samples,
                              const TickGatherCodes &codes, int n_streams, hipStream_t stream) {
     if (n_streams <= 0) return hipSuccess;
     hipLaunchKernelGGL(aecm_tick_prepare_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
-                       dim3(64 * kWavesPerWorkgroup), 0, stream, far_in, near_in, clean_in, in_stride, n, far_ring, near_ring,
+                       dim3(64 * kWavesPerWorkgroup), 0, stream, far_in, near_in, clean_in, in_stride, n, n_far, far_ring, near_ring,
                        clean_ring, ring_len, far_pos, near_pos, bfar, bnear, bclean, n_block_samples, n_streams, codes);
     return hipGetLastError();
 }
@@ -210,6 +213,86 @@ hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *o
     hipLaunchKernelGGL(aecm_tick_finish_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
                        dim3(64 * kWavesPerWorkgroup), 0, stream, bout, n_block_samples, out_ring, near_ring, ring_len, out_pos,
                        near_in, io_stride, out, n, n_streams, codes);
+    return hipGetLastError();
+}
+
+__global__ void aecm_tick_prepare_classes_kernel(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in,
+                                                 int64_t in_stride, int n, int16_t *far_ring, int16_t *near_ring,
+                                                 int16_t *clean_ring, int64_t ring_len, int64_t near_pos,
+                                                 int16_t *bfar, int16_t *bnear, int16_t *bclean, const int32_t *class_of_stream,
+                                                 const TickClassEntry *table, int32_t *blocks_per_stream, int n_streams) {
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
+    if (s >= n_streams) return;
+    const TickClassEntry *e = table + class_of_stream[s];
+    const int nbs = e->n_block_samples, n_far = e->n_far;
+    const int64_t far_pos = e->far_pos;
+    const int16_t *fin = far_in + s * in_stride, *nin = near_in + s * in_stride;
+    const int16_t *cin = clean_in ? clean_in + s * in_stride : nullptr;
+    int16_t *fr = far_ring + s * ring_len, *nr = near_ring + s * ring_len;
+    int16_t *cr = clean_in ? clean_ring + s * ring_len : nullptr;
+    const int64_t mask = ring_len - 1, row = s * kTickMaxBlockSamples;
+    for (int j = threadIdx.x & 63; j < nbs; j += 64) {
+        const int cf = e->gather.far[j], cn = e->gather.near[j];
+        const int idf = cf & 0x0fffffff, idn = cn & 0x0fffffff;
+        bfar[row + j] = cf < 0 ? (int16_t)0 : ((cf >> 28) == kTickFromInput ? fin[idf] : fr[idf]);
+        bnear[row + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? nin[idn] : nr[idn]);
+        if (cin) bclean[row + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? cin[idn] : cr[idn]);
+    }
+    for (int j = threadIdx.x & 63; j < n; j += 64) {
+        if (j < n_far) fr[(far_pos + j) & mask] = fin[j];
+        nr[(near_pos + j) & mask] = nin[j];
+        if (cin) cr[(near_pos + j) & mask] = cin[j];
+    }
+    if ((threadIdx.x & 63) == 0) blocks_per_stream[s] = nbs / kBlock;
+}
+hipError_t LaunchTickPrepareClasses(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
+                                    int n, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
+                                    int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean,
+                                    const int32_t *class_of_stream, const TickClassEntry *table, int32_t *blocks_per_stream,
+                                    int n_streams, hipStream_t stream) {
+    if (n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_tick_prepare_classes_kernel,
+                       dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)), dim3(64 * kWavesPerWorkgroup), 0,
+                       stream, far_in, near_in, clean_in, in_stride, n, far_ring, near_ring, clean_ring, ring_len, near_pos,
+                       bfar, bnear, bclean, class_of_stream, table, blocks_per_stream, n_streams);
+    return hipGetLastError();
+}
+
+__global__ void aecm_tick_finish_classes_kernel(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
+                                                const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
+                                                const int32_t *class_of_stream, const TickClassEntry *table, int n_streams) {
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
+    if (s >= n_streams) return;
+    const TickClassEntry *e = table + class_of_stream[s];
+    const int nbs = e->n_block_samples;
+    const int64_t out_pos = e->out_pos;
+    const int16_t *bo = bout + s * kTickMaxBlockSamples;
+    int16_t *ring = out_ring + s * ring_len;
+    const int64_t mask = ring_len - 1;
+    for (int j = threadIdx.x & 63; j < n; j += 64) {
+        const int c = e->assemble.out[j];
+        const int idx = c & 0x0fffffff;
+        int16_t r = 0;
+        if (c >= 0) {
+            switch (c >> 28) {
+                case kTickFromInput: r = bo[idx]; break;
+                case kTickFromRing: r = ring[idx]; break;
+                case kTickNearInput: r = pass_in[s * io_stride + idx]; break;
+                default: r = pass_ring[s * ring_len + idx]; break;
+            }
+        }
+        out[s * io_stride + j] = r;
+    }
+    for (int j = threadIdx.x & 63; j < nbs; j += 64) ring[(out_pos + j) & mask] = bo[j];
+}
+hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
+                                   const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
+                                   const int32_t *class_of_stream, const TickClassEntry *table, int n_streams,
+                                   hipStream_t stream) {
+    if (n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_tick_finish_classes_kernel,
+                       dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)), dim3(64 * kWavesPerWorkgroup), 0,
+                       stream, bout, out_ring, pass_ring, ring_len, pass_in, io_stride, out, n, class_of_stream, table, n_streams);
     return hipGetLastError();
 }
 

@@ -123,9 +123,11 @@ public:
         const int32_t err = BufferFarendError(farend, n);
         if (err != 0) return err;
         if (!ec_startup_) DelayComp();
-        farend_buf_.Write(farend, n);
+        far_accepted_ = farend_buf_.Write(farend, n);      // a full jitter buffer drops what does not fit (ring_buffer.c:142-150)
         return 0;
     }
+    // How many samples of the last BufferFarend call entered the jitter buffer.
+    size_t last_far_accepted() const { return far_accepted_; }
 
     // WebRtcAecm_Process (:236-408).  run_blocks(far, near, clean_or_null, out, n_blocks) must fill
     // out[0 .. n_blocks*64) with the WebRtcAecm_ProcessBlock results of the n_blocks consecutive
@@ -286,6 +288,7 @@ private:
     SampleRing<T> farend_buf_;   // 50 frames of 80 samples (:31-36,98)
     // --- frame adapter rings (aecm_core.cc:183-205): FRAME_LEN + PART_LEN = 144 samples each ---
     SampleRing<T> far_frames_, near_frames_, clean_frames_, out_frames_;
+    size_t far_accepted_ = 0;
 };
 
 // Gather / scatter schedule of a whole recording processed as n_calls x (BufferFarend, Process) of

@@ -2,6 +2,9 @@
 
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "../../include/echo_control_mobile.h"
 
 namespace aecm {
@@ -18,8 +21,12 @@ SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
     bool ok = AECM_HIP_OK(hipMalloc((void **)&b->far_ring_, S * kRing * 2)) &&
               AECM_HIP_OK(hipMalloc((void **)&b->near_ring_, S * kRing * 2)) &&
               AECM_HIP_OK(hipMalloc((void **)&b->out_ring_, S * kRing * 2)) &&
-              AECM_HIP_OK(hipMalloc((void **)&b->blk_, 4 * S * 4 * kBlock * 2)) &&
-              AECM_HIP_OK(hipMalloc((void **)&b->io_dev_, 4 * S * 160 * 2));
+              AECM_HIP_OK(hipMalloc((void **)&b->blk_, 4 * S * kTickMaxBlockSamples * 2)) &&
+              AECM_HIP_OK(hipMalloc((void **)&b->io_dev_, 4 * S * 160 * 2)) &&
+              AECM_HIP_OK(hipMalloc((void **)&b->class_of_dev_, S * sizeof(int32_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&b->blocks_per_stream_dev_, S * sizeof(int32_t))) &&
+              AECM_HIP_OK(hipMalloc((void **)&b->table_dev_, kMaxFlowClasses * sizeof(TickClassEntry))) &&
+              AECM_HIP_OK(hipHostMalloc((void **)&b->table_host_, kMaxFlowClasses * sizeof(TickClassEntry), hipHostMallocDefault));
     if (!ok) {
         delete b;
         return nullptr;
@@ -36,23 +43,34 @@ SessionBatch::~SessionBatch() {
     (void)hipFree(clean_ring_);
     (void)hipFree(blk_);
     (void)hipFree(io_dev_);
+    (void)hipFree(class_of_dev_);
+    (void)hipFree(blocks_per_stream_dev_);
+    (void)hipFree(table_dev_);
+    if (table_host_) (void)hipHostFree(table_host_);
 }
 
 int32_t SessionBatch::Init(int32_t samp_freq) {
     if (samp_freq != 8000 && samp_freq != 16000) return AECM_BAD_PARAMETER_ERROR;
     if (!engine_->Init(samp_freq)) return AECM_UNSPECIFIED_ERROR;
-    const size_t bytes = (size_t)engine_->num_streams() * kRing * 2;
+    const int S = engine_->num_streams();
+    const size_t bytes = (size_t)S * kRing * 2;
     if (!AECM_HIP_OK(hipMemsetAsync(far_ring_, 0, bytes, engine_->stream())) ||
         !AECM_HIP_OK(hipMemsetAsync(near_ring_, 0, bytes, engine_->stream())) ||
         !AECM_HIP_OK(hipMemsetAsync(out_ring_, 0, bytes, engine_->stream())) ||
         (clean_ring_ && !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, engine_->stream()))))
         return AECM_UNSPECIFIED_ERROR;
-    far_pos_ = near_pos_ = blocks_done_ = 0;
-    return flow_.Init(samp_freq);
+    near_pos_ = 0;
+    classes_.clear();
+    classes_.emplace_back();                      // every session starts in one class
+    classes_[0].members = S;
+    class_of_.assign((size_t)S, 0);
+    last_ms_.clear();
+    class_of_dirty_ = true;
+    return classes_[0].flow.Init(samp_freq);
 }
 
 int32_t SessionBatch::SetConfig(int16_t cng_mode, int16_t echo_mode) {
-    if (!flow_.initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (classes_.empty() || !classes_[0].flow.initialized()) return AECM_UNINITIALIZED_ERROR;
     if (cng_mode != AecmFalse && cng_mode != AecmTrue) return AECM_BAD_PARAMETER_ERROR;
     if (echo_mode < 0 || echo_mode > 4) {
         if (!engine_->SetCngMode(cng_mode, 0, -1)) return AECM_UNSPECIFIED_ERROR;
@@ -61,10 +79,100 @@ int32_t SessionBatch::SetConfig(int16_t cng_mode, int16_t echo_mode) {
     return engine_->SetConfig(cng_mode, echo_mode, 0, -1) ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
+// Give every session the class that matches (its previous class, its msInSndCardBuf of this tick).
+int32_t SessionBatch::Regroup(const int16_t *ms_per_session) {
+    const size_t S = class_of_.size();
+    if (last_ms_.size() == S && memcmp(last_ms_.data(), ms_per_session, S * sizeof(int16_t)) == 0) return 0;   // same grouping as last tick
+    struct Child { int16_t ms; int32_t id; };
+    std::vector<std::vector<Child>> children(classes_.size());
+    std::vector<FlowClass> next;
+    std::vector<int32_t> next_class_of(S);
+    for (size_t s = 0; s < S; ++s) {
+        const int32_t old = class_of_[s];
+        const int16_t ms = ms_per_session[s];
+        int32_t id = -1;
+        for (const Child &c : children[old])
+            if (c.ms == ms) { id = c.id; break; }
+        if (id < 0) {
+            if ((int)next.size() >= kMaxFlowClasses) return AECM_UNSUPPORTED_FUNCTION_ERROR;
+            id = (int32_t)next.size();
+            next.push_back(classes_[old]);           // the flow state before this tick
+            next.back().ms = ms;
+            next.back().members = 0;
+            children[old].push_back({ms, id});
+        }
+        next[id].members++;
+        next_class_of[s] = id;
+    }
+    classes_.swap(next);
+    class_of_.swap(next_class_of);
+    last_ms_.assign(ms_per_session, ms_per_session + S);
+    class_of_dirty_ = true;
+    return 0;
+}
+
+// One tick of one class's session machinery in the index domain: where every block sample and every
+// output sample comes from, as source codes (aecm_kernels.h).  A near tag is the absolute sample count;
+// a far tag counts the samples the class's jitter buffer has ACCEPTED (a saturated buffer drops what does
+// not fit, and may then re-read arbitrarily old content for ever: in accepted-sample time that content
+// is never more than the buffer's 4000 samples away, so it always sits inside the device ring).
+int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, bool *stale) {
+    int64_t far_tags[kTickMaxSamples], near_tags[kTickMaxSamples], out_tags[kTickMaxSamples];
+    for (int i = 0; i < n; ++i) { far_tags[i] = c.far_count + i; near_tags[i] = near_pos_ + i; }
+    entry->n_block_samples = 0;
+    entry->n_far = 0;
+    entry->far_pos = c.far_count;
+    entry->out_pos = c.blocks_done * kBlock;
+    for (int i = 0; i < n; ++i) entry->assemble.out[i] = -1;
+    int32_t rc = c.flow.BufferFarend(far_tags, (size_t)n);
+    if (rc != 0) return rc;
+    const int64_t far_first = c.far_count;
+    entry->n_far = (int32_t)c.flow.last_far_accepted();
+    c.far_count += entry->n_far;
+    int64_t blk_far[kTickMaxBlockSamples], blk_near[kTickMaxBlockSamples];
+    int n_blocks = 0;
+    bool passthrough = false;
+    const int64_t out_base = c.blocks_done * kBlock;
+    // the clean near-end is positioned exactly like the noisy one: it shares the near tags
+    rc = c.flow.Process(near_tags, has_clean ? near_tags : nullptr, out_tags, (size_t)n, c.ms,
+                        [&](const int64_t *fb, const int64_t *nb, const int64_t *, int64_t *ob, int nblk) {
+                            memcpy(blk_far, fb, sizeof(int64_t) * nblk * kBlock);
+                            memcpy(blk_near, nb, sizeof(int64_t) * nblk * kBlock);
+                            for (int k = 0; k < nblk * kBlock; ++k) ob[k] = out_base + k;
+                            n_blocks = nblk;
+                            return true;
+                        },
+                        &passthrough);
+    if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) return rc;      // nothing processed; the rings still take the samples
+    if (passthrough)
+        for (int i = 0; i < n; ++i) out_tags[i] = -(out_tags[i] + 2);
+    const int nbs = n_blocks * kBlock;
+    const int64_t far_end = c.far_count, near_end = near_pos_ + n, out_end = out_base + nbs;
+    auto code = [&](int64_t tag, int64_t first_of_tick, int64_t end, int kind_now, int kind_ring) -> int32_t {
+        if (tag < 0) return -1;
+        if (end - tag > kRing) *stale = true;           // every tag must still be inside its ring
+        if (tag >= first_of_tick) return (int32_t)((kind_now << 28) | (int32_t)(tag - first_of_tick));
+        return (int32_t)((kind_ring << 28) | (int32_t)(tag & (kRing - 1)));
+    };
+    for (int k = 0; k < nbs; ++k) {
+        entry->gather.far[k] = code(blk_far[k], far_first, far_end, kTickFromInput, kTickFromRing);
+        entry->gather.near[k] = code(blk_near[k], near_pos_, near_end, kTickFromInput, kTickFromRing);
+    }
+    for (int i = 0; i < n; ++i) {
+        const int64_t v = out_tags[i];
+        entry->assemble.out[i] = v >= 0    ? code(v, out_base, out_end, kTickFromInput, kTickFromRing)
+                                 : v <= -2 ? code(-v - 2, near_pos_, near_end, kTickNearInput, kTickNearRing)
+                                           : -1;
+    }
+    entry->n_block_samples = nbs;
+    c.blocks_done += n_blocks;
+    return rc;
+}
+
 int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, int n,
-                           int16_t ms, bool host_pointers) {
+                           int16_t ms, const int16_t *ms_per_session, int32_t *codes, bool host_pointers) {
     if (far == nullptr || near == nullptr || out == nullptr) return AECM_NULL_POINTER_ERROR;
-    if (!flow_.initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (classes_.empty() || !classes_[0].flow.initialized()) return AECM_UNINITIALIZED_ERROR;
     if (n != 80 && n != 160) return AECM_BAD_PARAMETER_ERROR;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
@@ -74,6 +182,28 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st)))
             return AECM_UNSPECIFIED_ERROR;
     }
+    // 1. which class every session is in for this tick
+    if (ms_per_session) {
+        if (int32_t rc = Regroup(ms_per_session)) return rc;
+    } else {
+        for (FlowClass &c : classes_) c.ms = ms;
+        last_ms_.clear();
+    }
+    const int n_classes = (int)classes_.size();
+    // 2. the session machinery of every class in the index domain (the table is read by the previous tick's
+    //    kernels until they finish: every tick ends with a stream synchronisation)
+    bool stale = false;
+    std::vector<int32_t> class_rc((size_t)n_classes, 0);
+    int32_t first_rc = 0, max_nbs = 0;
+    for (int k = 0; k < n_classes; ++k) {
+        class_rc[k] = AdvanceClass(classes_[k], n, clean != nullptr, &table_host_[k], &stale);
+        if (class_rc[k] != 0 && first_rc == 0) first_rc = class_rc[k];
+        max_nbs = std::max(max_nbs, table_host_[k].n_block_samples);
+    }
+    if (stale) return AECM_UNSPECIFIED_ERROR;
+    if (codes)
+        for (int s = 0; s < S; ++s) codes[s] = class_rc[class_of_[s]];
+    // 3. device side of the tick: prepare -> blocks -> finish
     const int16_t *dfar = far, *dnear = near, *dclean = clean;
     int16_t *dout = out;
     int64_t dstride = stride;
@@ -89,82 +219,48 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         dout = io_dev_ + 2 * (size_t)S * 160;
         if (clean) dclean = c;
     }
-    // 1. the session machinery in the index domain; a tag is the absolute sample count of a far / near
-    //    sample, the tick's samples are [far_pos_, far_pos_ + n) and [near_pos_, near_pos_ + n)
-    int64_t far_tags[kTickMaxSamples], near_tags[kTickMaxSamples], out_tags[kTickMaxSamples];
-    for (int i = 0; i < n; ++i) { far_tags[i] = far_pos_ + i; near_tags[i] = near_pos_ + i; }
-    int32_t rc = flow_.BufferFarend(far_tags, (size_t)n);
-    if (rc != 0) return rc;
-    int64_t blk_far[kTickMaxBlockSamples], blk_near[kTickMaxBlockSamples];
-    int n_blocks = 0;
-    bool passthrough = false, stale = false;
-    const int64_t out_base = blocks_done_ * kBlock;
-    // the clean near-end is positioned exactly like the noisy one: it shares the near tags
-    rc = flow_.Process(near_tags, clean ? near_tags : nullptr, out_tags, (size_t)n, ms,
-                       [&](const int64_t *fb, const int64_t *nb, const int64_t *, int64_t *ob, int nblk) {
-                           memcpy(blk_far, fb, sizeof(int64_t) * nblk * kBlock);
-                           memcpy(blk_near, nb, sizeof(int64_t) * nblk * kBlock);
-                           for (int k = 0; k < nblk * kBlock; ++k) ob[k] = out_base + k;
-                           n_blocks = nblk;
-                           return true;
-                       },
-                       &passthrough);
-    if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) {
-        // the far samples were consumed by BufferFarend: keep the rings in step with the flow
-        TickGatherCodes none;
-        if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dclean, dstride, n, far_ring_, near_ring_, clean_ring_, kRing, far_pos_,
-                                           near_pos_, blk_, blk_, blk_, 0, none, S, st)))
-            return AECM_UNSPECIFIED_ERROR;
-        far_pos_ += n;
-        near_pos_ += n;
-        return rc;
-    }
-    if (passthrough)
-        for (int i = 0; i < n; ++i) out_tags[i] = -(out_tags[i] + 2);
-    // 2. every sample's source as a code the kernels understand; every tag must still be inside its ring
-    const int nbs = n_blocks * kBlock;
-    const int64_t far_end = far_pos_ + n, near_end = near_pos_ + n, out_end = out_base + nbs;
-    auto code = [&](int64_t tag, int64_t first_of_tick, int64_t end, int kind_now, int kind_ring) -> int32_t {
-        if (tag < 0) return -1;
-        if (end - tag > kRing) stale = true;
-        if (tag >= first_of_tick) return (int32_t)((kind_now << 28) | (int32_t)(tag - first_of_tick));
-        return (int32_t)((kind_ring << 28) | (int32_t)(tag & (kRing - 1)));
-    };
-    TickGatherCodes gather;
-    for (int k = 0; k < nbs; ++k) {
-        gather.far[k] = code(blk_far[k], far_pos_, far_end, kTickFromInput, kTickFromRing);
-        gather.near[k] = code(blk_near[k], near_pos_, near_end, kTickFromInput, kTickFromRing);
-    }
-    TickAssembleCodes assemble;
-    for (int i = 0; i < n; ++i) {
-        const int64_t v = out_tags[i];
-        assemble.out[i] = v >= 0    ? code(v, out_base, out_end, kTickFromInput, kTickFromRing)
-                          : v <= -2 ? code(-v - 2, near_pos_, near_end, kTickNearInput, kTickNearRing)
-                                    : -1;
-    }
-    if (stale) return AECM_UNSPECIFIED_ERROR;
-    // 3. device side of the tick: prepare -> blocks -> finish
     int16_t *bfar = blk_, *bnear = blk_ + (size_t)S * kTickMaxBlockSamples, *bout = blk_ + 2 * (size_t)S * kTickMaxBlockSamples;
     int16_t *bclean = blk_ + 3 * (size_t)S * kTickMaxBlockSamples;
-    if (!AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dclean, dstride, n, far_ring_, near_ring_, clean_ring_, kRing, far_pos_,
-                                       near_pos_, bfar, bnear, bclean, nbs, gather, S, st)))
-        return AECM_UNSPECIFIED_ERROR;
-    far_pos_ += n;
-    near_pos_ += n;
-    if (n_blocks > 0) {
-        IoView io{bfar, bnear, clean ? bclean : nullptr, bout, nbs, kBlock};
-        if (!engine_->ProcessBlocks(io, n_blocks)) return AECM_UNSPECIFIED_ERROR;
-        blocks_done_ += n_blocks;
-    }
     // pass-through samples come from the clean near-end when there is one (echo_control_mobile.cc:285-291)
-    if (!AECM_HIP_OK(LaunchTickFinish(bout, nbs, out_ring_, clean ? clean_ring_ : near_ring_, kRing, out_base,
-                                      clean ? dclean : dnear, dstride, dout, n, assemble, S, st)))
-        return AECM_UNSPECIFIED_ERROR;
+    const int16_t *pass_ring = clean ? clean_ring_ : near_ring_, *pass_in = clean ? dclean : dnear;
+    bool ok = true;
+    if (n_classes == 1) {
+        // one class: the source codes travel as kernel arguments, dense block rows
+        const TickClassEntry &e = table_host_[0];
+        const int nbs = e.n_block_samples;
+        ok = AECM_HIP_OK(LaunchTickPrepare(dfar, dnear, dclean, dstride, n, e.n_far, far_ring_, near_ring_, clean_ring_, kRing,
+                                           e.far_pos, near_pos_, bfar, bnear, bclean, nbs, e.gather, S, st));
+        if (ok && nbs > 0) {
+            IoView io{bfar, bnear, clean ? bclean : nullptr, bout, nbs, kBlock};
+            ok = engine_->ProcessBlocks(io, nbs / kBlock);
+        }
+        ok = ok && AECM_HIP_OK(LaunchTickFinish(bout, nbs, out_ring_, pass_ring, kRing, e.out_pos, pass_in, dstride, dout, n,
+                                                e.assemble, S, st));
+    } else {
+        // several classes: codes from a device table indexed by the session's class, fixed block row stride
+        if (class_of_dirty_) {
+            ok = AECM_HIP_OK(hipMemcpyAsync(class_of_dev_, class_of_.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            class_of_dirty_ = !ok;
+        }
+        ok = ok && AECM_HIP_OK(hipMemcpyAsync(table_dev_, table_host_, (size_t)n_classes * sizeof(TickClassEntry),
+                                              hipMemcpyHostToDevice, st)) &&
+             AECM_HIP_OK(LaunchTickPrepareClasses(dfar, dnear, dclean, dstride, n, far_ring_, near_ring_, clean_ring_, kRing,
+                                                  near_pos_, bfar, bnear, bclean, class_of_dev_, table_dev_,
+                                                  blocks_per_stream_dev_, S, st));
+        if (ok && max_nbs > 0) {
+            IoView io{bfar, bnear, clean ? bclean : nullptr, bout, kTickMaxBlockSamples, kBlock};
+            ok = engine_->ProcessBlocks(io, max_nbs / kBlock, blocks_per_stream_dev_);
+        }
+        ok = ok && AECM_HIP_OK(LaunchTickFinishClasses(bout, out_ring_, pass_ring, kRing, pass_in, dstride, dout, n, class_of_dev_,
+                                                       table_dev_, S, st));
+    }
+    near_pos_ += n;
+    if (!ok) return AECM_UNSPECIFIED_ERROR;
     if (host_pointers &&
         !AECM_HIP_OK(hipMemcpy2DAsync(out, stride * 2, dout, 320, (size_t)n * 2, S, hipMemcpyDeviceToHost, st)))
         return AECM_UNSPECIFIED_ERROR;
     if (!AECM_HIP_OK(hipStreamSynchronize(st))) return AECM_UNSPECIFIED_ERROR;
-    return rc;
+    return first_rc;
 }
 
 }  // namespace aecm

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "aecm_engine.h"
+#include "aecm_kernels.h"
 #include "aecm_session_flow.h"
 
 namespace aecm {
@@ -31,21 +32,45 @@ public:
     int32_t Init(int32_t samp_freq);
     int32_t SetConfig(int16_t cng_mode, int16_t echo_mode);
     // One tick for every session; far/near/clean/out are [S][>= n] with the given stream stride, device
-    // or host pointers; clean (WebRtcAecm_Process's nearendClean) may be null.  Returns the code each
-    // session's WebRtcAecm_Process would return.
+    // or host pointers; clean (WebRtcAecm_Process's nearendClean) may be null.
+    //   ms_per_session == nullptr: every session gets `ms`; the return value is the code each session's
+    //     WebRtcAecm_Process would return.
+    //   ms_per_session != nullptr (host array, S entries): session s gets ms_per_session[s]; codes (host,
+    //     S entries, may be null) receives each session's code, the return value is 0 or the first
+    //     non-zero code.
     int32_t Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, int n,
-                 int16_t ms, bool host_pointers);
+                 int16_t ms, const int16_t *ms_per_session, int32_t *codes, bool host_pointers);
+    int num_flow_classes() const { return (int)classes_.size(); }
+
+    static constexpr int kMaxFlowClasses = 1024;
 
 private:
-    SessionBatch() : flow_(-1) {}
+    // Sessions whose msInSndCardBuf history is identical share one SessionFlow (run in the index domain on
+    // the host).  A class splits when its members present different values in a tick; classes never merge.
+    struct FlowClass {
+        SessionFlow<int64_t> flow;
+        int64_t blocks_done = 0;
+        int64_t far_count = 0;   // far samples its jitter buffer has accepted so far = the next far tag
+        int16_t ms = 0;          // this tick's msInSndCardBuf
+        int32_t members = 0;
+        FlowClass() : flow(-1) {}
+    };
+    SessionBatch() {}
+    int32_t Regroup(const int16_t *ms_per_session);
+    int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, bool *stale);
     static constexpr int64_t kRing = 8192;     // >= 4000 (jitter buffer) + 160 + 144 + stale re-reads; power of two
     std::unique_ptr<BatchEngine> engine_;
-    SessionFlow<int64_t> flow_;
-    int64_t far_pos_ = 0, near_pos_ = 0, blocks_done_ = 0;
+    std::vector<FlowClass> classes_;
+    std::vector<int32_t> class_of_;            // host copy, [S]
+    std::vector<int16_t> last_ms_;             // per-session values of the previous per-session tick
+    bool class_of_dirty_ = false;
+    int64_t near_pos_ = 0;
     int16_t *far_ring_ = nullptr, *near_ring_ = nullptr, *out_ring_ = nullptr;   // [S][kRing]
     int16_t *clean_ring_ = nullptr;   // [S][kRing], allocated by the first tick that carries a clean near-end
     int16_t *blk_ = nullptr;          // [4][S][4*64] gathered far / near / clean blocks and block outputs of a tick
     int16_t *io_dev_ = nullptr;       // [4][S][160] staging when the caller passes host pointers
+    int32_t *class_of_dev_ = nullptr, *blocks_per_stream_dev_ = nullptr;          // [S] each
+    TickClassEntry *table_dev_ = nullptr, *table_host_ = nullptr;                 // [kMaxFlowClasses], host copy pinned
     int device_ = 0;
 };
 

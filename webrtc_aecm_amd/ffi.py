@@ -44,7 +44,8 @@ BATCH_SYMBOLS = [
 ]
 SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_Create", "WebRtcAecmSessions_Free", "WebRtcAecmSessions_Init", "WebRtcAecmSessions_set_config",
-    "WebRtcAecmSessions_Tick", "WebRtcAecmSessions_TickHost",
+    "WebRtcAecmSessions_Tick", "WebRtcAecmSessions_TickHost", "WebRtcAecmSessions_TickPerSession",
+    "WebRtcAecmSessions_TickPerSessionHost", "WebRtcAecmSessions_num_flow_classes",
 ]
 
 
@@ -118,6 +119,9 @@ def load():
     lib.WebRtcAecmSessions_set_config.argtypes = [vp, AecmConfig]
     lib.WebRtcAecmSessions_Tick.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
     lib.WebRtcAecmSessions_TickHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
+    lib.WebRtcAecmSessions_TickPerSession.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, vp, vp]
+    lib.WebRtcAecmSessions_TickPerSessionHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, vp, vp]
+    lib.WebRtcAecmSessions_num_flow_classes.argtypes = [vp]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
     lib.WebRtcAecmBatch_DebugFft128.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DeviceInfo.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -324,7 +328,9 @@ class AecmBatch:
 
 
 class AecmSessions:
-    """S streaming sessions with a common call pattern (include/aecm_batch.h, WebRtcAecmSessions_*)."""
+    """S streaming sessions with a common call cadence (include/aecm_batch.h, WebRtcAecmSessions_*)."""
+
+    MAX_FLOW_CLASSES = 1024      # distinct msInSndCardBuf histories per object (csrc/aecm_sessions.h)
 
     def __init__(self, num_streams: int, fs: int = 16000, cng_mode: int = 1, echo_mode: int = 3, device: int = 0):
         self.lib = load()
@@ -354,6 +360,30 @@ class AecmSessions:
 
     def tick_device(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms=40, clean_ptr=None):
         return self.lib.WebRtcAecmSessions_Tick(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n, ms)
+
+    def tick_host_per_session(self, far, near, ms_per_session, clean=None):
+        """far/near(/clean): [S, n] int16; ms_per_session: S msInSndCardBuf values.  Returns (code, out, codes[S])."""
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        ms = np.ascontiguousarray(ms_per_session, dtype=np.int16)
+        assert ms.shape == (far.shape[0],)
+        cptr = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            cptr = clean.ctypes.data
+        out = np.empty_like(near)
+        codes = np.zeros(far.shape[0], dtype=np.int32)
+        rc = self.lib.WebRtcAecmSessions_TickPerSessionHost(self.h, far.ctypes.data, near.ctypes.data, cptr, out.ctypes.data,
+                                                            far.shape[1], far.shape[1], ms.ctypes.data, codes.ctypes.data)
+        return rc, out, codes
+
+    def tick_device_per_session(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms_per_session, clean_ptr=None):
+        ms = np.ascontiguousarray(ms_per_session, dtype=np.int16)
+        return self.lib.WebRtcAecmSessions_TickPerSession(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n,
+                                                          ms.ctypes.data, None)
+
+    def num_flow_classes(self) -> int:
+        return self.lib.WebRtcAecmSessions_num_flow_classes(self.h)
 
     def close(self):
         if getattr(self, "h", None):
