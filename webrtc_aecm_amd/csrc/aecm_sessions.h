@@ -1,13 +1,15 @@
-// Streaming batch of sessions: S independent WebRtcAecm_* sessions that all see the same call
-// pattern (one BufferFarend + one Process of n samples per tick, same msInSndCardBuf) -- the shape of
-// a media server mixing many calls on a 10 ms clock.
+// Streaming batch of sessions: S independent WebRtcAecm_* sessions on a common call cadence (one
+// BufferFarend + one Process of n samples per tick) -- the shape of a media server mixing many calls on a
+// 10 ms clock.  msInSndCardBuf is per tick for everybody or per session.
 //
-// The session wrapper and the frame adapter only move samples (aecm_session_flow.h), so ONE
-// SessionFlow runs on the host in the index domain (64-bit absolute sample tags) and its decisions are
-// applied to all streams on the device: the audio lives in per-stream rings in HBM, each tick is
+// The session wrapper and the frame adapter only move samples (aecm_session_flow.h), so sessions with
+// the same msInSndCardBuf history share ONE SessionFlow that runs on the host in the index domain (sample
+// tags instead of samples; a "flow class") and whose decisions are applied to all its members on the
+// device: the audio lives in per-stream rings in HBM, each tick is
 //   prepare (append far/near to the rings + gather the tick's blocks) -> WebRtcAecm_ProcessBlock x nb
-//   -> finish (block outputs into the output ring + assemble the tick's output): three launches, the
-//   per-sample source decisions travel as kernel arguments.
+//   -> finish (block outputs into the output ring + assemble the tick's output): three launches.  With
+//   one class the per-sample source decisions travel as kernel arguments, with several they sit in a
+//   device table indexed by the session's class.
 #ifndef AECM_AMD_SESSIONS_H_
 #define AECM_AMD_SESSIONS_H_
 
