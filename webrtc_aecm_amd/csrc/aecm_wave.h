@@ -178,128 +178,153 @@ struct BlockEngine {
     // and T is one v_dot2_i32_i16 on the packed operand with packed twiddles (wr,-wi) / (wi,wr).
     // kRealInput: the imaginary parts of a and b are known to be zero on entry (forward transform of
     // a real signal, real_fft.c:59-65), which lets stage 0 (twiddle = (32767, 0)) skip half its work.
+    //
+    // Stage S pairs positions differing in bit S; the operands of stage S > 0 are brought together by
+    // exchanging on lane bit (6 - S).
+
+    // Forward stage 0 of a real signal: twiddle (32767, 0), imaginary inputs 0, so T_im = 1 and the
+    // imaginary outputs are 0.  sh = 15: base = (x_a << 15) + 2^15 is even, so
+    // Y+ = base + ((T >> 1) << 1) = (base + T) & ~1 and only the upper half of Y is kept: the product
+    // accumulates straight onto base + 1 and bit 0 never matters for Y+.  For Y- = 2*base - Y+ the
+    // upper half equals that of Z = 2*base + 1 - acc (acc = base + T): Y- = Z - [acc even], and Z can
+    // only be a multiple of 2^16 when acc is odd.
+    static AECM_HD void fft_stage0_real(vi &a, vi &b) {
+        vi acc = add(mul24(vi(32767), lo16(b)), shl_add(lo16(a), 15, 32769));
+        b = lsr(sub(shl_add(a, 16, 65537), acc), 16);
+        a = lsr(acc, 16);
+    }
+
+    // Forward stages 1..6 as 4 multiply-adds + 4 dot products + 2 byte permutes.  With K = -32768,
+    // x_a * K + c = c - (x_a << 15) is one v_mad_i32_i16 taking either half of the packed operand, so the
+    // base B = (x_a << 15) + 2^15 is formed NEGATED; since ~v = -v - 1 and the output is the upper half
+    // of a word, computing the complement of the word gives the complement of the output for free:
+    //   odd stages (true in, complemented out):
+    //     ~(B + 1 + T) = (-32770 - (x_a << 15)) - T,      ~(B - T) = (-32769 - (x_a << 15)) + T
+    //   even stages (complemented in a' = ~a, b' = ~b, true out): x = -x' - 1, so B = -(x_a' << 15) and
+    //     T = -T' - s with T' the dot product on b' and s the sum of the twiddle's halves:
+    //     B + 1 + T = ((1 - s) - (x_a' << 15)) - T',      B - T = (s - (x_a' << 15)) + T'.
+    // All exact modulo 2^32.  Six stages: the last one (even) ends in true values.
+    template <int S, int N>
+    static AECM_HD void fft_stage_forward(vi (&aa)[N], vi (&bb)[N]) {
+        static_assert(S >= 1 && S <= 6, "forward stages 1..6");
+        constexpr bool kTrueIn = (S & 1) != 0;
+        constexpr bool kNeedImB = S != 6;       // bins 65..127: only the real part of bin 64 is used (aecm_core_c.cc:297)
+        vi w_re, w_im, nw_re, nw_im;
+        W::template fwd_twiddles<S>(w_re, w_im, nw_re, nw_im);
+        vi s_re = vi(0), c_re = vi(0), s_im = vi(0), c_im = vi(0);
+        if constexpr (!kTrueIn) W::template fwd_offsets<kTrueIn ? 2 : S>(s_re, c_re, s_im, c_im);
+        const vi k = vi(-32768);
+        for (int n = 0; n < N; ++n) {
+            vi &a = aa[n], &b = bb[n];
+            W::template exchange<6 - S>(a, b);
+            vi p_re, p_im, m_re, m_im = vi(0);
+            if constexpr (kTrueIn) {
+                p_re = dot2_i16(b, nw_re, mad16_lo_uc(a, k, -32770));
+                m_re = dot2_i16(b, w_re, mad16_lo_uc(a, k, -32769));
+                p_im = dot2_i16(b, nw_im, mad16_hi_uc(a, k, -32770));
+                m_im = dot2_i16(b, w_im, mad16_hi_uc(a, k, -32769));
+            } else {
+                p_re = dot2_i16(b, nw_re, mad16_lo(a, k, c_re));
+                m_re = dot2_i16(b, w_re, mad16_lo(a, k, s_re));
+                p_im = dot2_i16(b, nw_im, mad16_hi(a, k, c_im));
+                if (kNeedImB) m_im = dot2_i16(b, w_im, mad16_hi(a, k, s_im));
+            }
+            a = pack_hi16(p_re, p_im);
+            b = kNeedImB ? pack_hi16(m_re, m_im) : lsr(m_re, 16);
+        }
+    }
+
+    // The generic stage: every inverse stage (data-dependent scaling, complex_fft.c:382-396) and forward
+    // stage 0 of a complex signal.  Returns the sum of the shifts applied (inverse only).
+    template <bool kInverse, int S, int N>
+    static AECM_HD int fft_stage_generic(vi (&aa)[N], vi (&bb)[N]) {
+        int scale = 0;
+        vi w_re, w_im;
+        W::template twiddles<S, kInverse>(w_re, w_im);       // (wr,-wi) and (wi,wr), packed
+        // Last stage: the caller only consumes the real parts (inverse: real_fft.c:97-99) resp. bins
+        // 0..63 complex and the real part of bin 64 (forward: aecm_core_c.cc:297)
+        constexpr bool kNeedImA = !(S == 6 && kInverse), kNeedImB = S != 6;
+        for (int n = 0; n < N; ++n) {
+            vi &a = aa[n], &b = bb[n];
+            if constexpr (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);
+            int shift = 1;
+            if (kInverse) {
+                // only "max|x| > 13573" and "> 27146" matter: two ballots instead of a wave max-reduction
+                // (|-32768| saturates to 32767, the reference clamps it the same)
+                vi m = max_halves_i16(pk_max_i16(pk_abs_sat_i16(a), pk_abs_sat_i16(b)));
+                shift = (W::ballot(m > 13573) != 0 ? 1 : 0) + (W::ballot(m > 27146) != 0 ? 1 : 0);
+                scale += shift;
+            }
+            if (AECM_UNLIKELY(shift == 1)) {
+                // sh = 15: as in fft_stage0_real, with a complex twiddle
+                vi acc_re = dot2_i16(b, w_re, shl_add(lo16(a), 15, 32769));      // base + T_re
+                vi z_re = sub(shl_add(a, 16, 65537), acc_re);                    // Z = 2*base + 1 - acc
+                vi acc_im = vi(0), z_im = vi(0);
+                if (kNeedImA) acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));
+                if (kNeedImB) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);
+                a = kNeedImA ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);
+                b = kNeedImB ? pack_hi16(z_re, z_im) : lsr(z_re, 16);
+            } else if (AECM_LIKELY(shift == 0)) {
+                // sh = 14 (the usual case of the inverse transform: the suppressed output is small).
+                // base = (x_a << 16) + 2^15 has 15 zero low bits and (T >> 1) << 2 is 2T with bit 1
+                // cleared, so V = base + 2T equals Y+ except possibly in bit 1, and Z = 2*base + 2 - V
+                // equals Y- or Y- + 2 with Y- a multiple of 4: the upper halves are those of Y+ and Y-.
+                vi v_re = shl_add(dot2_i16(b, w_re, vi(1)), 1, shl_add(a, 16, 32768));
+                vi z_re = sub(shl_add(a, 17, 65538), v_re);
+                if (kNeedImA) {
+                    vi base_im = (a & (int)0xffff0000) | 32768;
+                    vi v_im = shl_add(dot2_i16(b, w_im, vi(1)), 1, base_im);
+                    vi z_im = sub(shl_add(base_im, 1, 2), v_im);
+                    a = pack_hi16(v_re, v_im);
+                    b = pack_hi16(z_re, z_im);
+                } else {
+                    a = lsr(v_re, 16);
+                    b = lsr(z_re, 16);
+                }
+            } else {
+                // shift == 2, sh = 16 (rare): Y = (x_a << 14) +- (T >> 1) + 2^15
+                vi t_re = sar(dot2_i16(b, w_re, vi(1)), 1);
+                vi base_re = shl(lo16(a), 14) + 32768;
+                if (kNeedImA) {
+                    vi t_im = sar(dot2_i16(b, w_im, vi(1)), 1);
+                    vi base_im = shl(hi16(a), 14) + 32768;
+                    a = pack_hi16(add(base_re, t_re), add(base_im, t_im));
+                    b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));
+                } else {
+                    a = lsr(add(base_re, t_re), 16);
+                    b = lsr(sub(base_re, t_re), 16);
+                }
+            }
+        }
+        return scale;
+    }
+
+    template <bool kInverse, bool kRealInput, int N, int S>
+    static AECM_HD int fft_stage(vi (&aa)[N], vi (&bb)[N]) {
+        if constexpr (S == 0 && kRealInput && !kInverse) {
+            for (int n = 0; n < N; ++n) fft_stage0_real(aa[n], bb[n]);
+            return 0;
+        } else if constexpr (S > 0 && !kInverse) {
+            fft_stage_forward<S, N>(aa, bb);
+            return 0;
+        } else {
+            return fft_stage_generic<kInverse, S, N>(aa, bb);
+        }
+    }
+
     // N independent transforms advance in lockstep (the far-end, near-end and optional clean
     // near-end windows of a block): each stage's twiddles are fetched once and are dead again before
     // the next stage, which keeps the register footprint of the tables at one stage's worth.
     template <bool kInverse, bool kRealInput, int N>
     static AECM_HD int fft128(vi (&aa)[N], vi (&bb)[N]) {
         int scale = 0;
-        // stage s pairs positions differing in bit s; the operands of stage s>0 are brought
-        // together by exchanging on lane bit (6 - s).
-        //
-        // sh = 15 (forward stage 0; inverse stages with shift 1): base = (x_a << 15) + 2^15 is
-        // even, so Y+ = base + ((T >> 1) << 1) = (base + T) & ~1, and only the upper half of Y is
-        // kept: the dot product accumulates straight onto base + 1 and bit 0 never matters for Y+.
-        // For Y- = 2*base - Y+ the upper half equals that of Z = 2*base + 1 - acc (acc = base + T):
-        // Y- = Z - [acc even], and Z can only be a multiple of 2^16 when acc is odd.
-#define AECM_FFT_STAGE(S)                                                                          \
-        if (S == 0 && kRealInput && !kInverse) {                                                   \
-            /* twiddle (32767, 0), imaginary inputs 0: T_im = 1 -> imaginary outputs are 0 */      \
-            for (int n = 0; n < N; ++n) {                                                          \
-                vi &a = aa[n], &b = bb[n];                                                         \
-                vi acc = add(mul24(vi(32767), lo16(b)), shl_add(lo16(a), 15, 32769));              \
-                b = lsr(sub(shl_add(a, 16, 65537), acc), 16);                                      \
-                a = lsr(acc, 16);                                                                  \
-            }                                                                                      \
-        } else if (S > 0 && !kInverse) {                                                           \
-            /* Forward stages 1..6 as 4 multiply-adds + 4 dot products + 2 byte permutes.          \
-               With K = -32768, x_a * K + c = c - (x_a << 15) is one v_mad_i32_i16 taking either   \
-               half of the packed operand, so the base B = (x_a << 15) + 2^15 is formed NEGATED;   \
-               since ~v = -v - 1 and the output is the upper half of a word, computing the         \
-               complement of the word gives the complement of the output for free:                 \
-                 odd stages (true in, complemented out):                                           \
-                   ~(B + 1 + T) = (-32770 - (x_a << 15)) - T,   ~(B - T) = (-32769 - (x_a << 15)) + T \
-                 even stages (complemented in a' = ~a, b' = ~b, true out): x = -x' - 1, so         \
-                   B = -(x_a' << 15) and T = -T' - s with T' the dot product on b' and s the sum   \
-                   of the twiddle's halves:                                                        \
-                   B + 1 + T = ((1 - s) - (x_a' << 15)) - T',   B - T = (s - (x_a' << 15)) + T'.  \
-               All exact modulo 2^32.  Six stages: the last one (even) ends in true values. */    \
-            const bool need_im_b = !(S == 6);   /* bins 65..127: only the real part of bin 64 is used */ \
-            vi w_re, w_im, nw_re, nw_im;                                                           \
-            W::template fwd_twiddles<(S > 0 ? S : 1)>(w_re, w_im, nw_re, nw_im);                   \
-            vi s_re = vi(0), c_re = vi(0), s_im = vi(0), c_im = vi(0);                             \
-            if (!(S & 1)) W::template fwd_offsets<(S > 0 && !(S & 1) ? S : 2)>(s_re, c_re, s_im, c_im); \
-            const vi k = vi(-32768);                                                               \
-            for (int n = 0; n < N; ++n) {                                                          \
-                vi &a = aa[n], &b = bb[n];                                                         \
-                W::template exchange<6 - (S > 0 ? S : 1)>(a, b);                                   \
-                vi p_re, p_im, m_re, m_im = vi(0);                                                 \
-                if (S & 1) {                                                                       \
-                    p_re = dot2_i16(b, nw_re, mad16_lo_uc(a, k, -32770));                          \
-                    m_re = dot2_i16(b, w_re, mad16_lo_uc(a, k, -32769));                           \
-                    p_im = dot2_i16(b, nw_im, mad16_hi_uc(a, k, -32770));                          \
-                    m_im = dot2_i16(b, w_im, mad16_hi_uc(a, k, -32769));                           \
-                } else {                                                                           \
-                    p_re = dot2_i16(b, nw_re, mad16_lo(a, k, c_re));                               \
-                    m_re = dot2_i16(b, w_re, mad16_lo(a, k, s_re));                                \
-                    p_im = dot2_i16(b, nw_im, mad16_hi(a, k, c_im));                               \
-                    if (need_im_b) m_im = dot2_i16(b, w_im, mad16_hi(a, k, s_im));                 \
-                }                                                                                  \
-                a = pack_hi16(p_re, p_im);                                                         \
-                b = need_im_b ? pack_hi16(m_re, m_im) : lsr(m_re, 16);                             \
-            }                                                                                      \
-        } else {                                                                                   \
-            vi w_re, w_im;                                                                         \
-            W::template twiddles<S, kInverse>(w_re, w_im);   /* (wr,-wi) and (wi,wr), packed */    \
-            /* Last stage: the caller only consumes the real parts (inverse: real_fft.c:97-99)    \
-               resp. bins 0..63 complex and the real part of bin 64 (forward: aecm_core_c.cc:297) */\
-            const bool need_im_a = !(S == 6 && kInverse), need_im_b = !(S == 6);                  \
-            for (int n = 0; n < N; ++n) {                                                          \
-                vi &a = aa[n], &b = bb[n];                                                         \
-                if (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);                        \
-                int shift = 1;                                                                     \
-                if (kInverse) { /* complex_fft.c:382-396: data-dependent scaling per stage */      \
-                    /* only "max|x| > 13573" and "> 27146" matter: two ballots instead of a wave  \
-                       max-reduction (|-32768| saturates to 32767, the reference clamps it the same) */ \
-                    vi m = max_halves_i16(pk_max_i16(pk_abs_sat_i16(a), pk_abs_sat_i16(b)));       \
-                    shift = (W::ballot(m > 13573) != 0 ? 1 : 0) + (W::ballot(m > 27146) != 0 ? 1 : 0); \
-                    scale += shift;                                                                \
-                }                                                                                  \
-                if (AECM_UNLIKELY(shift == 1)) {                                               \
-                    vi acc_re = dot2_i16(b, w_re, shl_add(lo16(a), 15, 32769));  /* base + T_re */ \
-                    vi z_re = sub(shl_add(a, 16, 65537), acc_re);  /* Z = 2*base + 1 - acc */      \
-                    vi acc_im = vi(0), z_im = vi(0);                                               \
-                    if (need_im_a) acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));        \
-                    if (need_im_b) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);              \
-                    a = need_im_a ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);                   \
-                    b = need_im_b ? pack_hi16(z_re, z_im) : lsr(z_re, 16);                         \
-                } else if (AECM_LIKELY(shift == 0)) {                                       \
-                    /* sh = 14 (the usual case of the inverse transform: the suppressed output is  \
-                       small).  base = (x_a << 16) + 2^15 has 15 zero low bits and (T >> 1) << 2   \
-                       is 2T with bit 1 cleared, so V = base + 2T equals Y+ except possibly in bit \
-                       1, and Z = 2*base + 2 - V equals Y- or Y- + 2 with Y- a multiple of 4: the  \
-                       upper halves are those of Y+ and Y-. */                                     \
-                    vi v_re = shl_add(dot2_i16(b, w_re, vi(1)), 1, shl_add(a, 16, 32768));         \
-                    vi z_re = sub(shl_add(a, 17, 65538), v_re);                                    \
-                    if (need_im_a) {                                                               \
-                        vi base_im = (a & (int)0xffff0000) | 32768;                                \
-                        vi v_im = shl_add(dot2_i16(b, w_im, vi(1)), 1, base_im);                   \
-                        vi z_im = sub(shl_add(base_im, 1, 2), v_im);                               \
-                        a = pack_hi16(v_re, v_im);                                                 \
-                        b = pack_hi16(z_re, z_im);                                                 \
-                    } else {                                                                       \
-                        a = lsr(v_re, 16);                                                         \
-                        b = lsr(z_re, 16);                                                         \
-                    }                                                                              \
-                } else {                                                                           \
-                    /* shift == 2, sh = 16 (rare): Y = (x_a << 14) +- (T >> 1) + 2^15 */           \
-                    vi t_re = sar(dot2_i16(b, w_re, vi(1)), 1);                                    \
-                    vi base_re = shl(lo16(a), 14) + 32768;                                         \
-                    if (need_im_a) {                                                               \
-                        vi t_im = sar(dot2_i16(b, w_im, vi(1)), 1);                                \
-                        vi base_im = shl(hi16(a), 14) + 32768;                                     \
-                        a = pack_hi16(add(base_re, t_re), add(base_im, t_im));                     \
-                        b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));                     \
-                    } else {                                                                       \
-                        a = lsr(add(base_re, t_re), 16);                                           \
-                        b = lsr(sub(base_re, t_re), 16);                                           \
-                    }                                                                              \
-                }                                                                                  \
-            }                                                                                      \
-        }
-        AECM_FFT_STAGE(0) AECM_FFT_STAGE(1) AECM_FFT_STAGE(2) AECM_FFT_STAGE(3)
-        AECM_FFT_STAGE(4) AECM_FFT_STAGE(5) AECM_FFT_STAGE(6)
-#undef AECM_FFT_STAGE
+        scale += fft_stage<kInverse, kRealInput, N, 0>(aa, bb);
+        scale += fft_stage<kInverse, kRealInput, N, 1>(aa, bb);
+        scale += fft_stage<kInverse, kRealInput, N, 2>(aa, bb);
+        scale += fft_stage<kInverse, kRealInput, N, 3>(aa, bb);
+        scale += fft_stage<kInverse, kRealInput, N, 4>(aa, bb);
+        scale += fft_stage<kInverse, kRealInput, N, 5>(aa, bb);
+        scale += fft_stage<kInverse, kRealInput, N, 6>(aa, bb);
         return scale;
     }
     template <bool kInverse, bool kRealInput>
