@@ -379,6 +379,34 @@ def test_streaming_session_batch_ticks_equal_individual_sessions():
         sb.close()
 
 
+def test_streaming_ticks_device_pointers_unaligned_rows():
+    """WebRtcAecmSessions_Tick on device pointers whose rows are NOT 8-byte aligned (odd stride, odd offset):
+    the tick kernels must fall back from their 4-sample accesses; results equal the host-pointer path."""
+    import torch
+    fs, frame, S, n_ticks = 16000, 160, 6, 60
+    pairs = [synth_pair(120 + k, n_ticks * frame // 64 + 1, fs, "mixed") for k in range(S)]
+    far = np.stack([p[0][:n_ticks * frame] for p in pairs])
+    near = np.stack([p[1][:n_ticks * frame] for p in pairs])
+    ref = aecm.AecmSessions(S, fs, 1, 1)
+    dev = aecm.AecmSessions(S, fs, 1, 1)
+    stride = frame + 3                                             # odd row stride
+    buf = torch.zeros((3, S * stride + 8), dtype=torch.int16, device="cuda")
+    for i in range(n_ticks):
+        sl = slice(i * frame, (i + 1) * frame)
+        rc0, want = ref.tick_host(far[:, sl], near[:, sl], 40)
+        off = 1 + (i % 2)                                          # odd / even element offsets
+        for k, src in enumerate((far, near)):
+            rows = torch.from_numpy(np.ascontiguousarray(src[:, sl])).cuda()
+            buf[k, off:off + S * stride].view(S, stride)[:, :frame] = rows
+        base = buf.data_ptr() + 2 * off
+        row_bytes = buf.stride(0) * 2
+        rc1 = dev.tick_device(base, base + row_bytes, base + 2 * row_bytes, stride, frame, 40)
+        got = buf[2, off:off + S * stride].view(S, stride)[:, :frame].cpu().numpy()
+        assert rc0 == rc1 and np.array_equal(got, want), i
+    ref.close()
+    dev.close()
+
+
 def test_streaming_ticks_with_per_session_sound_card_delay():
     """WebRtcAecmSessions_TickPerSession: every session has its own msInSndCardBuf history (constant per
     session, out-of-range values, a mid-run change, and a uniform Tick mixed in); each must equal an

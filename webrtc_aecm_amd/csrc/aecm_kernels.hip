@@ -10,6 +10,8 @@
 #define AECM_TABLE_ATTR __device__
 #include "aecm_kernels.h"
 
+#include <initializer_list>
+
 #include "aecm_tables.h"
 #include "aecm_wave.h"
 #include "wave_gfx950.h"
@@ -144,31 +146,81 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
 
 // ---- streaming-session sample rings --------------------------------------------------------------------
 
-__global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
-                                         int n, int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
-                                         int64_t far_pos, int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int nbs,
-                                         int n_streams, TickGatherCodes codes) {
-    // one wavefront per stream (4 streams per workgroup), lanes stride over the samples
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
-    if (s >= n_streams) return;
+// The tick kernels move 16-bit samples selected by per-sample source codes.  Runs are long in practice
+// (a block is a contiguous piece of a ring or of the tick's input), so a lane handles a group of four
+// samples: one 8-byte access when the four codes are consecutive, 4-aligned and the rows are 8-byte
+// aligned, four 2-byte accesses otherwise.  Fetch(kind, idx) returns the address of sample idx of a source.
+template <class Fetch>
+__device__ __forceinline__ void CopyGroup4(const int32_t *codes4, int16_t *dst4, bool rows_aligned, Fetch fetch) {
+    const int4 c = *reinterpret_cast<const int4 *>(codes4);
+    if (rows_aligned && c.x >= 0 && (c.x & 3) == 0 && c.y == c.x + 1 && c.z == c.x + 2 && c.w == c.x + 3) {
+        *reinterpret_cast<int2 *>(dst4) = *reinterpret_cast<const int2 *>(fetch(c.x >> 28, c.x & 0x0fffffff));
+        return;
+    }
+    const int cc[4] = {c.x, c.y, c.z, c.w};
+    for (int k = 0; k < 4; ++k) dst4[k] = cc[k] < 0 ? (int16_t)0 : *fetch(cc[k] >> 28, cc[k] & 0x0fffffff);
+}
+// ring[(pos + j) & mask] = src[j] for j in [0, n), four samples per lane where alignment allows
+__device__ __forceinline__ void AppendRing(int16_t *ring, int64_t mask, int64_t pos, const int16_t *src, int n, bool rows_aligned) {
+    const int lane = threadIdx.x & 63;
+    if (rows_aligned && (pos & 3) == 0 && (n & 3) == 0) {
+        for (int g = lane; g < n / 4; g += 64)
+            *reinterpret_cast<int2 *>(ring + ((pos + 4 * g) & mask)) = *reinterpret_cast<const int2 *>(src + 4 * g);
+    } else {
+        for (int j = lane; j < n; j += 64) ring[(pos + j) & mask] = src[j];
+    }
+}
+
+// Body shared by the one-class (codes as kernel arguments) and many-class (codes in a device table) forms.
+__device__ __forceinline__ void TickPrepareStream(int64_t s, const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in,
+                                                  int64_t in_stride, int n, int n_far, int16_t *far_ring, int16_t *near_ring,
+                                                  int16_t *clean_ring, int64_t ring_len, int64_t far_pos, int64_t near_pos,
+                                                  int16_t *bfar, int16_t *bnear, int16_t *bclean, int nbs,
+                                                  const TickGatherCodes *codes, bool rows_aligned) {
     const int16_t *fin = far_in + s * in_stride, *nin = near_in + s * in_stride;
     const int16_t *cin = clean_in ? clean_in + s * in_stride : nullptr;
     int16_t *fr = far_ring + s * ring_len, *nr = near_ring + s * ring_len;
     int16_t *cr = clean_in ? clean_ring + s * ring_len : nullptr;
     const int64_t mask = ring_len - 1;
     // reads of ring entries never alias this tick's appends: in-tick samples come from the input rows
-    for (int j = threadIdx.x & 63; j < nbs; j += 64) {
-        const int cf = codes.far[j], cn = codes.near[j];
-        const int idf = cf & 0x0fffffff, idn = cn & 0x0fffffff;
-        bfar[s * nbs + j] = cf < 0 ? (int16_t)0 : ((cf >> 28) == kTickFromInput ? fin[idf] : fr[idf]);
-        bnear[s * nbs + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? nin[idn] : nr[idn]);
-        if (cin) bclean[s * nbs + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? cin[idn] : cr[idn]);
+    for (int g = threadIdx.x & 63; g < nbs / 4; g += 64) {
+        CopyGroup4(codes->far + 4 * g, bfar + 4 * g, rows_aligned, [&](int kind, int idx) { return (kind == kTickFromInput ? fin : fr) + idx; });
+        CopyGroup4(codes->near + 4 * g, bnear + 4 * g, rows_aligned, [&](int kind, int idx) { return (kind == kTickFromInput ? nin : nr) + idx; });
+        if (cin)
+            CopyGroup4(codes->near + 4 * g, bclean + 4 * g, rows_aligned, [&](int kind, int idx) { return (kind == kTickFromInput ? cin : cr) + idx; });
     }
-    for (int j = threadIdx.x & 63; j < n; j += 64) {
-        if (j < n_far) fr[(far_pos + j) & mask] = fin[j];
-        nr[(near_pos + j) & mask] = nin[j];
-        if (cin) cr[(near_pos + j) & mask] = cin[j];
-    }
+    AppendRing(fr, mask, far_pos, fin, n_far, rows_aligned);
+    AppendRing(nr, mask, near_pos, nin, n, rows_aligned);
+    if (cin) AppendRing(cr, mask, near_pos, cin, n, rows_aligned);
+}
+
+__device__ __forceinline__ void TickFinishStream(int64_t s, const int16_t *bo, int nbs, int16_t *out_ring, const int16_t *pass_ring,
+                                                 int64_t ring_len, int64_t out_pos, const int16_t *pass_in, int64_t io_stride,
+                                                 int16_t *out, int n, const TickAssembleCodes *codes, bool rows_aligned) {
+    int16_t *ring = out_ring + s * ring_len;
+    const int16_t *pr = pass_ring + s * ring_len, *pi = pass_in + s * io_stride;
+    // in-tick block outputs are read from bo, so the ring reads never alias the appends below
+    for (int g = threadIdx.x & 63; g < n / 4; g += 64)
+        CopyGroup4(codes->out + 4 * g, out + s * io_stride + 4 * g, rows_aligned, [&](int kind, int idx) {
+            return (kind == kTickFromInput ? bo : kind == kTickFromRing ? (const int16_t *)ring : kind == kTickNearInput ? pi : pr) + idx;
+        });
+    AppendRing(ring, ring_len - 1, out_pos, bo, nbs, true);
+}
+
+__global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
+                                         int n, int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
+                                         int64_t far_pos, int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int nbs,
+                                         int n_streams, bool rows_aligned, TickGatherCodes codes) {
+    // one wavefront per stream (4 streams per workgroup)
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
+    if (s >= n_streams) return;
+    TickPrepareStream(s, far_in, near_in, clean_in, in_stride, n, n_far, far_ring, near_ring, clean_ring, ring_len, far_pos, near_pos,
+                      bfar + s * nbs, bnear + s * nbs, bclean + s * nbs, nbs, &codes, rows_aligned);
+}
+static bool RowsAligned(int64_t stride, std::initializer_list<const void *> ptrs) {
+    bool ok = (stride & 3) == 0;
+    for (const void *p : ptrs) ok = ok && (reinterpret_cast<uintptr_t>(p) & 7u) == 0;
+    return ok;
 }
 hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride, int n,
                              int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
@@ -177,34 +229,17 @@ hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, cons
     if (n_streams <= 0) return hipSuccess;
     hipLaunchKernelGGL(aecm_tick_prepare_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
                        dim3(64 * kWavesPerWorkgroup), 0, stream, far_in, near_in, clean_in, in_stride, n, n_far, far_ring, near_ring,
-                       clean_ring, ring_len, far_pos, near_pos, bfar, bnear, bclean, n_block_samples, n_streams, codes);
+                       clean_ring, ring_len, far_pos, near_pos, bfar, bnear, bclean, n_block_samples, n_streams,
+                       RowsAligned(in_stride, {far_in, near_in, clean_in}), codes);
     return hipGetLastError();
 }
 
 __global__ void aecm_tick_finish_kernel(const int16_t *bout, int nbs, int16_t *out_ring, const int16_t *near_ring,
                                         int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride,
-                                        int16_t *out, int n, int n_streams, TickAssembleCodes codes) {
+                                        int16_t *out, int n, int n_streams, bool rows_aligned, TickAssembleCodes codes) {
     const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
     if (s >= n_streams) return;
-    const int16_t *bo = bout + s * nbs;
-    int16_t *ring = out_ring + s * ring_len;
-    const int64_t mask = ring_len - 1;
-    // in-tick block outputs are read from bout, so the ring reads never alias the appends below
-    for (int j = threadIdx.x & 63; j < n; j += 64) {
-        const int c = codes.out[j];
-        const int idx = c & 0x0fffffff;
-        int16_t r = 0;
-        if (c >= 0) {
-            switch (c >> 28) {
-                case kTickFromInput: r = bo[idx]; break;
-                case kTickFromRing: r = ring[idx]; break;
-                case kTickNearInput: r = near_in[s * io_stride + idx]; break;
-                default: r = near_ring[s * ring_len + idx]; break;
-            }
-        }
-        out[s * io_stride + j] = r;
-    }
-    for (int j = threadIdx.x & 63; j < nbs; j += 64) ring[(out_pos + j) & mask] = bo[j];
+    TickFinishStream(s, bout + s * nbs, nbs, out_ring, near_ring, ring_len, out_pos, near_in, io_stride, out, n, &codes, rows_aligned);
 }
 hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *out_ring, const int16_t *near_ring,
                             int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride, int16_t *out,
@@ -212,7 +247,7 @@ hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *o
     if (n_streams <= 0) return hipSuccess;
     hipLaunchKernelGGL(aecm_tick_finish_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
                        dim3(64 * kWavesPerWorkgroup), 0, stream, bout, n_block_samples, out_ring, near_ring, ring_len, out_pos,
-                       near_in, io_stride, out, n, n_streams, codes);
+                       near_in, io_stride, out, n, n_streams, RowsAligned(io_stride, {near_in, out}), codes);
     return hipGetLastError();
 }
 
@@ -220,30 +255,15 @@ __global__ void aecm_tick_prepare_classes_kernel(const int16_t *far_in, const in
                                                  int64_t in_stride, int n, int16_t *far_ring, int16_t *near_ring,
                                                  int16_t *clean_ring, int64_t ring_len, int64_t near_pos,
                                                  int16_t *bfar, int16_t *bnear, int16_t *bclean, const int32_t *class_of_stream,
-                                                 const TickClassEntry *table, int32_t *blocks_per_stream, int n_streams) {
+                                                 const TickClassEntry *table, int32_t *blocks_per_stream, int n_streams,
+                                                 bool rows_aligned) {
     const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
     if (s >= n_streams) return;
     const TickClassEntry *e = table + class_of_stream[s];
-    const int nbs = e->n_block_samples, n_far = e->n_far;
-    const int64_t far_pos = e->far_pos;
-    const int16_t *fin = far_in + s * in_stride, *nin = near_in + s * in_stride;
-    const int16_t *cin = clean_in ? clean_in + s * in_stride : nullptr;
-    int16_t *fr = far_ring + s * ring_len, *nr = near_ring + s * ring_len;
-    int16_t *cr = clean_in ? clean_ring + s * ring_len : nullptr;
-    const int64_t mask = ring_len - 1, row = s * kTickMaxBlockSamples;
-    for (int j = threadIdx.x & 63; j < nbs; j += 64) {
-        const int cf = e->gather.far[j], cn = e->gather.near[j];
-        const int idf = cf & 0x0fffffff, idn = cn & 0x0fffffff;
-        bfar[row + j] = cf < 0 ? (int16_t)0 : ((cf >> 28) == kTickFromInput ? fin[idf] : fr[idf]);
-        bnear[row + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? nin[idn] : nr[idn]);
-        if (cin) bclean[row + j] = cn < 0 ? (int16_t)0 : ((cn >> 28) == kTickFromInput ? cin[idn] : cr[idn]);
-    }
-    for (int j = threadIdx.x & 63; j < n; j += 64) {
-        if (j < n_far) fr[(far_pos + j) & mask] = fin[j];
-        nr[(near_pos + j) & mask] = nin[j];
-        if (cin) cr[(near_pos + j) & mask] = cin[j];
-    }
-    if ((threadIdx.x & 63) == 0) blocks_per_stream[s] = nbs / kBlock;
+    const int64_t row = s * kTickMaxBlockSamples;
+    TickPrepareStream(s, far_in, near_in, clean_in, in_stride, n, e->n_far, far_ring, near_ring, clean_ring, ring_len, e->far_pos,
+                      near_pos, bfar + row, bnear + row, bclean + row, e->n_block_samples, &e->gather, rows_aligned);
+    if ((threadIdx.x & 63) == 0) blocks_per_stream[s] = e->n_block_samples / kBlock;
 }
 hipError_t LaunchTickPrepareClasses(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
                                     int n, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
@@ -254,36 +274,20 @@ hipError_t LaunchTickPrepareClasses(const int16_t *far_in, const int16_t *near_i
     hipLaunchKernelGGL(aecm_tick_prepare_classes_kernel,
                        dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)), dim3(64 * kWavesPerWorkgroup), 0,
                        stream, far_in, near_in, clean_in, in_stride, n, far_ring, near_ring, clean_ring, ring_len, near_pos,
-                       bfar, bnear, bclean, class_of_stream, table, blocks_per_stream, n_streams);
+                       bfar, bnear, bclean, class_of_stream, table, blocks_per_stream, n_streams,
+                       RowsAligned(in_stride, {far_in, near_in, clean_in}));
     return hipGetLastError();
 }
 
 __global__ void aecm_tick_finish_classes_kernel(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
                                                 const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
-                                                const int32_t *class_of_stream, const TickClassEntry *table, int n_streams) {
+                                                const int32_t *class_of_stream, const TickClassEntry *table, int n_streams,
+                                                bool rows_aligned) {
     const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
     if (s >= n_streams) return;
     const TickClassEntry *e = table + class_of_stream[s];
-    const int nbs = e->n_block_samples;
-    const int64_t out_pos = e->out_pos;
-    const int16_t *bo = bout + s * kTickMaxBlockSamples;
-    int16_t *ring = out_ring + s * ring_len;
-    const int64_t mask = ring_len - 1;
-    for (int j = threadIdx.x & 63; j < n; j += 64) {
-        const int c = e->assemble.out[j];
-        const int idx = c & 0x0fffffff;
-        int16_t r = 0;
-        if (c >= 0) {
-            switch (c >> 28) {
-                case kTickFromInput: r = bo[idx]; break;
-                case kTickFromRing: r = ring[idx]; break;
-                case kTickNearInput: r = pass_in[s * io_stride + idx]; break;
-                default: r = pass_ring[s * ring_len + idx]; break;
-            }
-        }
-        out[s * io_stride + j] = r;
-    }
-    for (int j = threadIdx.x & 63; j < nbs; j += 64) ring[(out_pos + j) & mask] = bo[j];
+    TickFinishStream(s, bout + s * kTickMaxBlockSamples, e->n_block_samples, out_ring, pass_ring, ring_len, e->out_pos, pass_in,
+                     io_stride, out, n, &e->assemble, rows_aligned);
 }
 hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
                                    const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
@@ -292,7 +296,8 @@ hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const
     if (n_streams <= 0) return hipSuccess;
     hipLaunchKernelGGL(aecm_tick_finish_classes_kernel,
                        dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)), dim3(64 * kWavesPerWorkgroup), 0,
-                       stream, bout, out_ring, pass_ring, ring_len, pass_in, io_stride, out, n, class_of_stream, table, n_streams);
+                       stream, bout, out_ring, pass_ring, ring_len, pass_in, io_stride, out, n, class_of_stream, table, n_streams,
+                       RowsAligned(io_stride, {pass_in, out}));
     return hipGetLastError();
 }
 
