@@ -11,6 +11,13 @@ for p in (str(ROOT), str(ROOT / "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # Build the checkers before collection: the oracle always (gcc), the unmodified reference when
+    # /root/reference is mounted (build container) -- the "needs reference" skips are decided at import time.
+    try:
+        from oracle import pyoracle
+        pyoracle.build()
+    except Exception as e:                       # a missing toolchain must not hide the real test errors
+        print(f"conftest: building oracle/ failed: {e}", file=sys.stderr)
 
 
 def _gpu_present() -> bool:
