@@ -156,6 +156,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (BASELINE config 3: 65536)")
     ap.add_argument("--blocks", type=int, default=128, help="blocks per stream per step (one launch)")
+    ap.add_argument("--total-streams", type=int, default=0,
+                    help="strong scaling: this many streams in total, split evenly over the GPUs (overrides --streams)")
+    ap.add_argument("--clean", action="store_true",
+                    help="also feed a clean near-end input (WebRtcAecm_ProcessBlock's nearendClean: third transform per block)")
     ap.add_argument("--fs", type=int, default=16000)
     ap.add_argument("--variant", choices=["fast", "safe"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,8 +188,11 @@ def main():
     device = torch.device("cuda", local_rank)
 
     S, T, K, W = args.streams, args.blocks, args.steps, args.warmup
+    if args.total_streams:
+        _, S = adist.shard_range(args.total_streams, rank, world)
     segs = 2
     far, near = synth_on_device(torch, S, segs * T * 64, 1234 + rank, device)
+    clean = (near.to(torch.int32) * 3 // 4).to(torch.int16) if args.clean else None
     batch = aecm.AecmBatch(S, args.fs, cng_mode=1, echo_mode=1, device=local_rank,
                            variant=aecm.KERNEL_FAST if args.variant == "fast" else aecm.KERNEL_SAFE)
     if args.fixed_delay >= 0:
@@ -196,7 +203,8 @@ def main():
 
     def step(i):                            # one C-ABI call = one launch = S*T frames
         off = (i % segs) * T * 64 * 2       # byte offset of this step's input segment
-        batch.process_device(far.data_ptr() + off, near.data_ptr() + off, out_full.data_ptr() + off, stride, 64, T)
+        batch.process_device(far.data_ptr() + off, near.data_ptr() + off, out_full.data_ptr() + off, stride, 64, T,
+                             clean.data_ptr() + off if clean is not None else None)
 
     torch.cuda.synchronize()
     for i in range(W):
@@ -220,21 +228,22 @@ def main():
     if rank == 0:
         value = frames / wall_max
         kern_avg_s = kernel_ms_total / launches / 1e3
-        achieved = ALGO_BYTES_PER_FRAME * S * T / kern_avg_s / 1e9
+        algo_bytes = ALGO_BYTES_PER_FRAME + (128 if args.clean else 0)
+        achieved = algo_bytes * S * T / kern_avg_s / 1e9
         workload_key = f"S{S}_T{T}_fs{args.fs}"
         res = {
             "metric": "AECM frames/sec (64-sample @16kHz) per GPU; bit-exact vs aecm_core_c.cc",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (Q-format fixed point)", "data": "synthetic",
             "config": {"workload": f"{S} streams/GPU x {T} blocks/step, {args.fs} Hz (BASELINE.json configs[2]; "
-                                   f"configs[1] = --streams 4096), cng on, echoMode 1, inputs resident in HBM",
+                                   f"configs[1] = --streams 4096), cng on, echoMode 1{', clean near-end input' if args.clean else ''}, inputs resident in HBM",
                        "streams_per_gpu": S, "blocks_per_step": T, "fs": args.fs, "kernel_variant": args.variant,
                        "sharding": f"static, {world} x {S} independent streams, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(workload_key),
-                         "kernel": "aecm_process_kernel<fast,noclean>", "kernel_avg_ms": kern_avg_s * 1e3,
-                         "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME,
+                         "kernel": f"aecm_process_kernel<{args.variant},{'clean' if args.clean else 'noclean'}>",
+                         "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_frame": algo_bytes,
                          "note": "instruction-issue-bound integer kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "
                                  "see issue_bound for the binding resource",
                          "issue_bound": load_issue_note()},
