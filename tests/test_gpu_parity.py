@@ -453,6 +453,20 @@ def test_streaming_ticks_with_per_session_sound_card_delay():
         sb.close()
 
 
+def test_streaming_ticks_three_launch_path():
+    """The streaming tests above run the fused one-launch tick (small batches).  Large batches use the
+    three-launch form (prepare / blocks / finish); run the same tests with that path forced."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("AECM_TICK_FUSED") is not None:
+        pytest.skip("already running with a forced tick path")
+    env = dict(os.environ, AECM_TICK_FUSED="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", "streaming_"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _write_wav(path, rate, samples):
     import wave
     with wave.open(str(path), "wb") as w:

@@ -48,6 +48,8 @@ public:
     bool ExportState(int stream, void *buf);
     bool ImportState(int stream, const void *buf);
     void set_variant(int v) { variant_ = v; }
+    int variant() const { return variant_; }
+    const StatePtrs &state_ptrs() const { return st_; }      // for kernels launched by the session batch on stream()
 
 private:
     BatchEngine() = default;

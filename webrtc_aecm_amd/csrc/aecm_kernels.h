@@ -93,6 +93,22 @@ hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const
                                    const int32_t *class_of_stream, const TickClassEntry *table, int n_streams,
                                    hipStream_t stream);
 
+// One tick of S streaming sessions as ONE launch, one wavefront per session: append the tick's far / near
+// (/ clean) samples to the rings, run the session's blocks with their inputs fetched through the source
+// codes (no intermediate block buffers), write the block outputs to the output ring and assemble the
+// tick's n output samples (this tick's block outputs are kept in LDS for that).
+//   class_of_stream / table == nullptr: every session uses `single`; else session s uses table[class_of_stream[s]].
+struct TickIo {
+    const int16_t *far_in, *near_in, *clean_in;   // [S][io_stride]; clean_in may be null
+    int16_t *out;                                 // [S][io_stride]
+    int64_t io_stride;
+    int32_t n;                                    // samples of this tick (80 or 160)
+    int16_t *far_ring, *near_ring, *clean_ring, *out_ring;   // [S][ring_len]
+    int64_t ring_len, near_pos;
+};
+hipError_t LaunchTick(const StatePtrs &st, const TickIo &io, int n_streams, int variant, const int32_t *class_of_stream,
+                      const TickClassEntry *table, const TickClassEntry *single, hipStream_t stream);
+
 // Diagnostics: `count` independent 128-point transforms of the block kernel's fft128, one wavefront
 // each, on natural-order data (data[k] = re[128] then im[128] of transform k, in place).  variant:
 // 0 forward of real input, 1 forward complex, 2 inverse; scales[k] = the inverse's accumulated scale.

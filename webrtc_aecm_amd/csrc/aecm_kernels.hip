@@ -301,6 +301,100 @@ hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const
     return hipGetLastError();
 }
 
+// ---- fused tick -------------------------------------------------------------------------------------
+#ifndef AECM_TICK_WAVES_PER_EU
+#define AECM_TICK_WAVES_PER_EU 6      // the coded I/O needs a few more registers than the strided one: 7 waves would spill
+#endif
+template <bool kFast, bool kHasClean>
+struct TickCodedIo {
+    using E = BlockEngine<Gfx950Wave<kFast>, kHasClean>;
+    using Regs = typename E::Regs;
+    const TickClassEntry *e;
+    const int16_t *fin, *nin, *cin, *fr, *nr, *cr;    // this session's input rows and rings
+    int16_t *out_ring_row, *lds_out;
+    int64_t mask;
+    static __device__ __forceinline__ int fetch(const int32_t *codes, int j, const int16_t *in_row, const int16_t *ring_row) {
+        const int c = codes[j], idx = c & 0x0fffffff;
+        return c < 0 ? 0 : (int)((c >> 28) == kTickFromInput ? in_row[idx] : ring_row[idx]);
+    }
+    __device__ __forceinline__ int far(const Regs &r, int b) const { return fetch(e->gather.far, b * kBlock + r.lane, fin, fr); }
+    __device__ __forceinline__ int near(const Regs &r, int b) const { return fetch(e->gather.near, b * kBlock + r.lane, nin, nr); }
+    __device__ __forceinline__ int clean(const Regs &r, int b) const { return fetch(e->gather.near, b * kBlock + r.lane, cin, cr); }
+    __device__ __forceinline__ void out(const Regs &r, int b, int v) const {
+        const int j = b * kBlock + r.brev;
+        lds_out[j] = (int16_t)v;
+        out_ring_row[(e->out_pos + j) & mask] = (int16_t)v;
+    }
+};
+
+template <bool kFast, bool kHasClean>
+__device__ __forceinline__ void TickSession(const StatePtrs &st, const TickIo &io, int64_t s, const TickClassEntry *e) {
+    using Io = TickCodedIo<kFast, kHasClean>;
+    const bool rows_aligned = (io.io_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(io.far_in) | reinterpret_cast<uintptr_t>(io.near_in) |
+                                                            reinterpret_cast<uintptr_t>(io.clean_in) | reinterpret_cast<uintptr_t>(io.out)) & 7u) == 0;
+    const int16_t *fin = io.far_in + s * io.io_stride, *nin = io.near_in + s * io.io_stride;
+    const int16_t *cin = kHasClean ? io.clean_in + s * io.io_stride : nullptr;
+    int16_t *fr = io.far_ring + s * io.ring_len, *nr = io.near_ring + s * io.ring_len;
+    int16_t *cr = kHasClean ? io.clean_ring + s * io.ring_len : nullptr;
+    int16_t *ring = io.out_ring + s * io.ring_len;
+    const int64_t mask = io.ring_len - 1;
+    int16_t *lds_out = reinterpret_cast<int16_t *>(&g_lds[1]) + (threadIdx.x >> 6) * kTickMaxBlockSamples;
+    // in-tick samples are always fetched from the input rows, so the appends never feed this tick's reads
+    AppendRing(fr, mask, e->far_pos, fin, e->n_far, rows_aligned);
+    AppendRing(nr, mask, io.near_pos, nin, io.n, rows_aligned);
+    if (kHasClean) AppendRing(cr, mask, io.near_pos, cin, io.n, rows_aligned);
+    const int nbs = e->n_block_samples;
+    if (nbs > 0) {
+        Io cio{e, fin, nin, cin, fr, nr, cr, ring, lds_out, mask};
+        Io::E::run_stream_io(st, cio, s, nbs / kBlock);
+    }
+    // the tick's output: this tick's block outputs from LDS, older ones from the ring, pass-through from
+    // the (clean) near-end (reference echo_control_mobile.cc:285-291)
+    const int16_t *pi = kHasClean ? cin : nin, *pr = kHasClean ? cr : nr;
+    for (int g = threadIdx.x & 63; g < io.n / 4; g += 64)
+        CopyGroup4(e->assemble.out + 4 * g, io.out + s * io.io_stride + 4 * g, rows_aligned, [&](int kind, int idx) {
+            return (kind == kTickFromInput ? (const int16_t *)lds_out : kind == kTickFromRing ? (const int16_t *)ring
+                    : kind == kTickNearInput ? pi : pr) + idx;
+        });
+}
+
+template <bool kFast, bool kHasClean>
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_TICK_WAVES_PER_EU, 8)))
+void aecm_tick_kernel(StatePtrs st, TickIo io, int n_streams, TickClassEntry single) {
+    FillLdsTables(st.consts);
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (s >= n_streams) return;
+    TickSession<kFast, kHasClean>(st, io, s, &single);
+}
+template <bool kFast, bool kHasClean>
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_TICK_WAVES_PER_EU, 8)))
+void aecm_tick_classes_kernel(StatePtrs st, TickIo io, int n_streams, const int32_t *class_of_stream, const TickClassEntry *table) {
+    FillLdsTables(st.consts);
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (s >= n_streams) return;
+    TickSession<kFast, kHasClean>(st, io, s, table + __builtin_amdgcn_readfirstlane(class_of_stream[s]));
+}
+
+hipError_t LaunchTick(const StatePtrs &st, const TickIo &io, int n_streams, int variant, const int32_t *class_of_stream,
+                      const TickClassEntry *table, const TickClassEntry *single, hipStream_t stream) {
+    if (n_streams <= 0) return hipSuccess;
+    const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup), block(64 * kWavesPerWorkgroup);
+    const size_t lds = sizeof(LdsTables) + kWavesPerWorkgroup * kTickMaxBlockSamples * sizeof(int16_t);
+    const bool fast = variant == kVariantFast, clean = io.clean_in != nullptr;
+#define AECM_LAUNCH_TICK(F, C)                                                                                          \
+    do {                                                                                                                \
+        if (table) hipLaunchKernelGGL((aecm_tick_classes_kernel<F, C>), grid, block, lds, stream, st, io, n_streams,   \
+                                      class_of_stream, table);                                                         \
+        else hipLaunchKernelGGL((aecm_tick_kernel<F, C>), grid, block, lds, stream, st, io, n_streams, *single);       \
+    } while (0)
+    if (fast && clean) AECM_LAUNCH_TICK(true, true);
+    else if (fast) AECM_LAUNCH_TICK(true, false);
+    else if (clean) AECM_LAUNCH_TICK(false, true);
+    else AECM_LAUNCH_TICK(false, false);
+#undef AECM_LAUNCH_TICK
+    return hipGetLastError();
+}
+
 // ---- self test of the wave primitives ------------------------------------------------------------
 
 __device__ __forceinline__ unsigned Mix(unsigned x) {

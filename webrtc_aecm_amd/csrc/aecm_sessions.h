@@ -58,6 +58,7 @@ private:
         FlowClass() : flow(-1) {}
     };
     SessionBatch() {}
+    static bool FusedTick(int num_streams);
     int32_t Regroup(const int16_t *ms_per_session);
     int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, bool *stale);
     static constexpr int64_t kRing = 8192;     // >= 4000 (jitter buffer) + 160 + 144 + stale re-reads; power of two

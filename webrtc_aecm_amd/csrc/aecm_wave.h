@@ -928,32 +928,48 @@ struct BlockEngine {
     }
 
     // ------------------------------------------------------------------------------------------
-    // A launch: n_blocks consecutive blocks of one stream, state in registers throughout.
+    // A launch: n_blocks consecutive blocks of one stream, state in registers throughout.  Io says where
+    // block b's 64 new samples come from and where its 64 output samples go:
+    //   vi far(const Regs &, int b), near(...), clean(...)   lane t -> sample t of block b
+    //   void out(const Regs &, int b, vi v)                  lane t holds output sample bitrev6(t) (= r.brev)
     // ------------------------------------------------------------------------------------------
-    static AECM_HD void run_stream(const StatePtrs &st, const IoView &io, int64_t stream, int n_blocks) {
+    template <class Io>
+    static AECM_HD void run_stream_io(const StatePtrs &st, Io &io, int64_t stream, int n_blocks) {
         Regs r;
         init_lane_constants(r, st.consts);
         uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
         int32_t *scal = st.scal + stream * (int64_t)kNumScal;
         uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
         load_state(r, vec, scal);
-        const int64_t base = stream * io.stream_stride;
-        vi far_next = W::load_i16(io.far + base, r.lane);
-        vi near_next = W::load_i16(io.near + base, r.lane);
-        vi clean_next = kHasClean ? W::load_i16(io.near_clean + base, r.lane) : vi(0);
+        vi far_next = io.far(r, 0);
+        vi near_next = io.near(r, 0);
+        vi clean_next = kHasClean ? io.clean(r, 0) : vi(0);
         for (int blk = 0; blk < n_blocks; ++blk) {
             vi far_cur = far_next, near_cur = near_next, clean_cur = clean_next;
             if (blk + 1 < n_blocks) {             // prefetch the next block's 3 x 128 bytes
-                const int64_t off = base + (int64_t)(blk + 1) * io.block_stride;
-                far_next = W::load_i16(io.far + off, r.lane);
-                near_next = W::load_i16(io.near + off, r.lane);
-                if (kHasClean) clean_next = W::load_i16(io.near_clean + off, r.lane);
+                far_next = io.far(r, blk + 1);
+                near_next = io.near(r, blk + 1);
+                if (kHasClean) clean_next = io.clean(r, blk + 1);
             }
             W::begin_block(blk, n_blocks);
             vi out = process_block(r, hist, far_cur, near_cur, clean_cur);
-            W::store_i16(io.out + base + (int64_t)blk * io.block_stride, r.brev, out);
+            io.out(r, blk, out);
         }
         store_state(r, vec, scal);
+    }
+
+    // The strided audio view of the batch interface (aecm_state.h: IoView).
+    struct StridedIo {
+        const IoView &v;
+        int64_t base;
+        AECM_HD vi far(const Regs &r, int b) const { return W::load_i16(v.far + base + (int64_t)b * v.block_stride, r.lane); }
+        AECM_HD vi near(const Regs &r, int b) const { return W::load_i16(v.near + base + (int64_t)b * v.block_stride, r.lane); }
+        AECM_HD vi clean(const Regs &r, int b) const { return W::load_i16(v.near_clean + base + (int64_t)b * v.block_stride, r.lane); }
+        AECM_HD void out(const Regs &r, int b, vi val) const { W::store_i16(v.out + base + (int64_t)b * v.block_stride, r.brev, val); }
+    };
+    static AECM_HD void run_stream(const StatePtrs &st, const IoView &io, int64_t stream, int n_blocks) {
+        StridedIo sio{io, stream * io.stream_stride};
+        run_stream_io(st, sio, stream, n_blocks);
     }
 };
 
