@@ -7,9 +7,10 @@
 // tags instead of samples; a "flow class") and whose decisions are applied to all its members on the
 // device: the audio lives in per-stream rings in HBM, each tick is
 //   prepare (append far/near to the rings + gather the tick's blocks) -> WebRtcAecm_ProcessBlock x nb
-//   -> finish (block outputs into the output ring + assemble the tick's output): three launches.  With
-//   one class the per-sample source decisions travel as kernel arguments, with several they sit in a
-//   device table indexed by the session's class.
+//   -> finish (block outputs into the output ring + assemble the tick's output)
+// as three launches for large batches, or fused into one launch (one wavefront per session does all of
+// it) for batches that do not fill the GPU.  With one class the per-sample source decisions travel as
+// kernel arguments, with several they sit in a device table indexed by the session's class.
 #ifndef AECM_AMD_SESSIONS_H_
 #define AECM_AMD_SESSIONS_H_
 
