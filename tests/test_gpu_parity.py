@@ -453,6 +453,29 @@ def test_streaming_ticks_with_per_session_sound_card_delay():
         sb.close()
 
 
+def test_streaming_ticks_too_many_delay_histories_is_an_error_not_a_crash():
+    """More distinct msInSndCardBuf histories than flow classes: the tick is refused with
+    AECM_UNSUPPORTED_FUNCTION_ERROR, nothing is consumed, and the object keeps working."""
+    S, frame, fs = aecm.AecmSessions.MAX_FLOW_CLASSES + 6, 160, 16000
+    far, near = synth_pair(33, 40, fs, "mixed")
+    far = np.tile(far[:10 * frame], (S, 1))
+    near = np.tile(near[:10 * frame], (S, 1))
+    sb = aecm.AecmSessions(S, fs, 1, 1)
+    one = aecm.Aecm()
+    assert one.init(fs) == 0 and one.set_config(1, 1) == 0
+    for i in range(10):
+        sl = slice(i * frame, (i + 1) * frame)
+        if i == 4:
+            rc, _, _ = sb.tick_host_per_session(far[:, sl], near[:, sl], np.arange(S, dtype=np.int16))      # S distinct values
+            assert rc == aecm.ffi.AECM_UNSUPPORTED_FUNCTION_ERROR and sb.num_flow_classes() == 1
+        rc, out = sb.tick_host(far[:, sl], near[:, sl], 40)
+        assert one.buffer_farend(far[0, sl]) == 0
+        rc1, o1 = one.process(near[0, sl], None, 40)
+        assert rc == rc1 == 0 and np.array_equal(out[0], o1) and np.array_equal(out[S - 1], o1), i
+    one.close()
+    sb.close()
+
+
 def test_streaming_ticks_three_launch_path():
     """The streaming tests above run the fused one-launch tick (small batches).  Large batches use the
     three-launch form (prepare / blocks / finish); run the same tests with that path forced."""
