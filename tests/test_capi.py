@@ -60,3 +60,24 @@ def test_product_does_not_use_the_oracle():
         txt = p.read_text()
         for b in banned:
             assert b not in txt, f"{p} mentions {b}"
+
+
+def test_block_kernel_register_budget(tmp_path):
+    """The headline kernels are built for 7 waves per SIMD (72 VGPRs): the fast variants must fit without
+    spilling to scratch, or the occupancy the measurements rely on is silently gone."""
+    import re
+    import subprocess
+    from webrtc_aecm_amd import build
+    out = tmp_path / "kernels.s"
+    flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([build._hipcc(), *flags, "-S", "--cuda-device-only", f"-I{build.CSRC}", str(build.CSRC / "aecm_kernels.hip"),
+                           "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    for has_clean in ("0", "1"):
+        m = re.search(r"^_ZN4aecm19aecm_process_kernelILb1ELb%sEEE\w*:.*\n" % has_clean, text, re.M)
+        assert m, "fast block kernel not found in the device assembly"
+        body = text[m.end():]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = len(re.findall(r"^\s*scratch_(load|store)", body, re.M))
+        assert vgprs <= 72 and scratch == 0, (has_clean, vgprs, scratch)
