@@ -167,6 +167,29 @@ def test_session_error_codes_and_ownership_rules():
 
 
 @pytest.mark.skipif(not pyoracle.have_reference(), reason="oracle/_ref/libaecm_ref.so not built")
+@pytest.mark.skipif(not pyoracle.have_reference(), reason="oracle/_ref/libaecm_ref.so not built")
+def test_session_host_logic_matches_reference_abi_persistent_delays_and_clean_input():
+    # Sound-card delays held for the whole session, including the ones that saturate the 4000-sample
+    # jitter buffer (250 / 500 ms: the reference then drops new far-end data and keeps re-reading old
+    # content), with and without a nearendClean input.
+    for fs, frame, ms, with_clean in ((16000, 160, 250, 0), (16000, 160, 500, 1), (8000, 80, 500, 0), (8000, 160, 0, 1),
+                                      (16000, 80, 130, 1)):
+        far, near = synth_pair(41, 1200, fs, "mixed")
+        clean = synth_clean(near) if with_clean else None
+        r = pyoracle.RefSession(fs, 1, 2)
+        s = simlib.SimSession()
+        assert s.init(fs) == 0 and s.set_config(1, 2) == 0
+        ob = np.empty(frame, dtype=np.int16)
+        for i in range(far.size // frame):
+            sl = slice(i * frame, (i + 1) * frame)
+            assert r.lib.WebRtcAecm_BufferFarend(r.h, far[sl].ctypes.data, frame) == s.buffer_farend(far[sl])
+            cp = clean[sl].ctypes.data if with_clean else None
+            rc = r.lib.WebRtcAecm_Process(r.h, near[sl].ctypes.data, cp, ob.ctypes.data, frame, ms)
+            rc2, o2 = s.process(near[sl], clean[sl] if with_clean else None, ms)
+            assert rc == rc2 and np.array_equal(ob, o2), (fs, frame, ms, i)
+
+
+@pytest.mark.skipif(not pyoracle.have_reference(), reason="oracle/_ref/libaecm_ref.so not built")
 def test_session_host_logic_matches_reference_abi_odd_call_patterns():
     # 80-sample calls at 16 kHz (start-up never ends, nBlocks10ms == 0), 160-sample calls at 8 kHz,
     # a jittering msInSndCardBuf and a far-end underrun (BufferFarend skipped now and then).
