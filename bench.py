@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: AECM 64-sample frames/s (WebRtcAecm_ProcessBlock-equivalents) on MI355X.
 
-One "step" = one pass of the hot path over one batch: a single launch that advances every one of the
-S resident streams by T blocks (S*T frames).  Inputs are synthetic 16 kHz far/near pairs generated on
-the device and resident in HBM before the timed region; state stays on the device between steps.
+One "step" = one pass of the hot path over one batch of synthetic input: a single launch that advances
+every one of the S resident streams by T blocks (S*T frames).  Inputs are synthetic far/near pairs
+generated on the device and resident in HBM before the timed region; state stays on the device between
+steps.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--blocks T] [--fs 16000|8000]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU): every rank owns S streams (weak
-scaling, no data-path collective); RCCL only gathers the counters.  Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU.  Started by hand (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the
+script re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N`; started by
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  Every rank owns S streams (weak scaling, no
+data-path collective); RCCL only lines the ranks up and gathers the counters.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -27,6 +31,7 @@ sys.path.insert(0, str(ROOT))
 
 ALGO_BYTES_PER_FRAME = 384            # 128 far in + 128 near in + 128 out
 HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_SUMMARY = ROOT / "profiles" / "r02_rocprof_summary.json"
 
 
 def synth_on_device(torch, S, L, seed, device, chunk=8192):
@@ -79,18 +84,19 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(fs, budget_s=12.0):
-    """The reference C path (oracle/_ref, kind 'reference') or our restatement of it (kind 'port')
-    timed on this box's host cores: one stream per thread, bounded to ~budget_s of wall time."""
+def cpu_baseline(fs, pairs, budget_s=12.0):
+    """The reference C path (oracle/_ref, kind 'reference') or our restatement of it (kind 'port') timed
+    on this box's host cores: one stream per thread, bounded to ~budget_s of wall time.  `pairs` are
+    (far, near) int16 host copies of streams of the GPU leg's own workload (the same inputs, same config)."""
     import threading
 
     from oracle import pyoracle
-    from webrtc_aecm_amd.synth import synth_pair
     cores = usable_cores()
     use_ref = pyoracle.have_reference()
     mk = (lambda: pyoracle.RefCoreStream(fs, 1, 1)) if use_ref else (lambda: pyoracle.OracleStream(fs, 1, 1))
-    chunk = 4000                                   # blocks per call (~60 ms of CPU work)
-    pairs = [synth_pair(100 + i, chunk, fs) for i in range(min(cores, 8))]
+    chunk = 4096 * 64                              # samples per call (~40 ms of CPU work)
+    pairs = [(np.ascontiguousarray(f[:chunk]), np.ascontiguousarray(d[:chunk])) for f, d in pairs]
+    blocks_per_call = pairs[0][0].size // 64
     streams = [mk() for _ in range(cores)]
     deadline = [0.0]
     start_gate = threading.Barrier(cores + 1)
@@ -102,7 +108,7 @@ def cpu_baseline(fs, budget_s=12.0):
         done = 0
         while time.perf_counter() < deadline[0]:
             s.process(f, d)
-            done += chunk
+            done += blocks_per_call
         return done
     with ThreadPoolExecutor(max_workers=cores) as ex:
         futs = [ex.submit(work, i) for i in range(cores)]
@@ -114,39 +120,64 @@ def cpu_baseline(fs, budget_s=12.0):
     return {
         "value": total / dt, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
         "per_core": total / dt / cores,
-        "sample": f"{cores} threads (one stream each) x {dt:.1f} s wall = {total} frames of {fs} Hz synthetic pairs, cng on, "
-                  f"echoMode 1; " + ("unmodified reference built -O2 from /root/reference (oracle/_ref)" if use_ref
-                                     else "oracle/aecm_oracle.c restatement built -O2"),
+        "sample": f"{cores} threads (one stream each) x {dt:.1f} s wall = {total} frames; inputs = streams 0..{len(pairs) - 1} of the "
+                  f"GPU leg's own batch ({fs} Hz, cng on, echoMode 1), {blocks_per_call} blocks per call; "
+                  + ("unmodified reference built -O2 from /root/reference (oracle/_ref)" if use_ref
+                     else "oracle/aecm_oracle.c restatement built -O2"),
     }
 
 
-def load_traffic(workload_key):
-    """Per-launch HBM bytes measured with rocprofv3 PMC passes (profiles/hbm_traffic.json, written by
-    tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command,
-    FETCH_SIZE calibrated on a known byte count), if recorded for this workload."""
-    p = ROOT / "profiles" / "hbm_traffic.json"
-    if not p.exists():
-        return None
-    try:
-        rec = json.loads(p.read_text())
-        return rec.get(workload_key, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+def workload_name(S, T, fs, world, clean):
+    """Which BASELINE.json configuration this run is (by streams per GPU, rate and GPU count)."""
+    if clean:
+        tag = "custom (clean near-end input: third transform per block)"
+    elif fs == 16000 and S == 65536 and world == 8:
+        tag = "BASELINE.json configs[4] (524288 streams over 8 GPUs)"
+    elif fs == 16000 and S == 65536:
+        tag = "BASELINE.json configs[2] (65536 streams, 16 kHz)" + (f" on each of {world} GPUs" if world > 1 else "")
+    elif fs == 16000 and S == 4096:
+        tag = "BASELINE.json configs[1] (4096 streams, 16 kHz)"
+    elif fs == 8000 and S == 32768:
+        tag = "BASELINE.json configs[3] (8 kHz mode, 32768 streams)"
+    else:
+        tag = "custom size"
+    return f"{tag}: {S} streams/GPU x {T} blocks/step, {fs} Hz, cng on, echoMode 1, inputs resident in HBM"
 
 
-def load_issue_note():
-    """The resource that actually bounds this kernel (recorded by the last profiling pass)."""
-    p = ROOT / "profiles" / "r01_rocprof_summary.json"
+def load_profile_record(lib_path, workload_key):
+    """Issue-port figures and HBM traffic of the dominant kernel come from separate rocprofv3 PMC passes
+    (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/r02_rocprof_summary.json), which cannot run
+    inside this process.  They are only valid for the binary they were measured on: the summary stores the
+    instruction-stream fingerprint of the profiled kernel (webrtc_aecm_amd/isa_census.py) and is quoted only
+    when the library timed here has the same fingerprint and the same workload; otherwise it is reported as stale."""
+    from webrtc_aecm_amd import isa_census
     try:
-        d = json.loads(p.read_text())["derived"]
-        return {"valu_insts_per_frame": round(d["valu_insts_per_frame"], 1),
-                "salu_insts_per_frame": round(d["salu_insts_per_frame"], 1),
-                "valu_port_busy_frac": round(d["valu_port_busy_frac"], 3),
-                "scalar_port_busy_frac": round(d["scalar_port_busy_frac"], 3),
-                "model": "one wave64 VALU and one scalar instruction per SIMD per 4 shader cycles",
-                "source": "profiles/r01_rocprof_summary.json (rocprofv3 SQ_*), profiles/r01_issue_port_experiments.md"}
-    except Exception:
-        return None
+        now = isa_census.census(lib_path)
+    except Exception as e:
+        return None, {"available": False, "reason": f"could not disassemble {lib_path}: {e}"}
+    static = {"kernel_fingerprint": now["fingerprint"], "static_counts": now["counts"],
+              "static_valu_fast_class": now["valu_fast_class"], "static_valu_8cycle_class": now["valu_8cycle_class"]}
+    if not PROFILE_SUMMARY.exists():
+        return None, dict(static, available=False, reason=f"{PROFILE_SUMMARY.name} not recorded yet")
+    rec = json.loads(PROFILE_SUMMARY.read_text())
+    if rec.get("kernel_fingerprint") != now["fingerprint"]:
+        return None, dict(static, available=False, stale=True,
+                          reason=f"profiles were measured on kernel fingerprint {rec.get('kernel_fingerprint')} "
+                                 f"(commit {rec.get('measured_at_commit')}), this library is {now['fingerprint']}: re-profile")
+    d = rec.get("derived", {})
+    note = dict(static, available=True, measured_at_commit=rec.get("measured_at_commit"),
+                valu_insts_per_frame=d.get("valu_insts_per_frame"), salu_insts_per_frame=d.get("salu_insts_per_frame"),
+                branch_insts_per_frame=d.get("branch_insts_per_frame"),
+                cycles_per_valu_inst=d.get("cycles_per_valu_inst"),
+                valu_port_busy_frac_at_4_cycles_per_inst=d.get("valu_port_busy_frac"),
+                valu_port_busy_frac_at_2_cycles_per_inst=d.get("valu_port_busy_frac_simd32"),
+                scalar_port_busy_frac=d.get("scalar_port_busy_frac"),
+                model="denominators: one wave64 VALU instruction per SIMD per 4 shader cycles (measured for the integer VOP3 / "
+                      "multiply / DPP class this kernel is mostly made of) resp. per 2 cycles (the SIMD-32 rate of "
+                      "MI355X_MICROARCH.md, reached only by back-to-back simple VOP2 ops)",
+                source=f"profiles/{PROFILE_SUMMARY.name} (rocprofv3 SQ_* PMC passes), profiles/r02_valu_class_census.md")
+    traffic = rec.get("traffic_by_workload", {}).get(workload_key)
+    return traffic, note
 
 
 def main():
@@ -155,7 +186,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (BASELINE config 3: 65536)")
-    ap.add_argument("--blocks", type=int, default=128, help="blocks per stream per step (one launch)")
+    ap.add_argument("--blocks", type=int, default=1024,
+                    help="blocks per stream per step (one launch); 1024 makes a 20-step timed region >= 2 s at 65536 streams")
     ap.add_argument("--total-streams", type=int, default=0,
                     help="strong scaling: this many streams in total, split evenly over the GPUs (overrides --streams)")
     ap.add_argument("--clean", action="store_true",
@@ -164,92 +196,113 @@ def main():
     ap.add_argument("--variant", choices=["fast", "safe"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the counter gather (nccl = RCCL)")
-    ap.add_argument("--device", type=int, default=None,
-                    help="force this HIP device index on every rank (only for exercising the N>1 code path on a 1-GPU box, "
-                         "with --dist-backend gloo)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="map rank r to HIP device r %% device_count (exercises the N-rank path on a box with fewer GPUs; "
+                         "implies --dist-backend gloo, RCCL refuses two ranks on one device)")
     ap.add_argument("--fixed-delay", type=int, default=-1,
                     help="WebRtcAecm_Control fixed delay (>= 0 disables the estimator's choice; 0 = no far-history reads; "
                          "used to calibrate the FETCH_SIZE counter on a known byte count)")
     args = ap.parse_args()
 
+    from webrtc_aecm_amd import dist as adist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        adist.self_launch(str(Path(__file__).resolve()), sys.argv[1:], args.gpus)      # does not return
+
     import torch
 
     import webrtc_aecm_amd as aecm
-    from webrtc_aecm_amd import dist as adist
 
+    if args.share_devices:
+        args.dist_backend = "gloo"
     rank, local_rank, world = adist.init(args.dist_backend)
-    if args.device is not None:
-        local_rank = args.device
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AECM hot path has no CPU implementation in the product")
+    n_dev = torch.cuda.device_count()
+    if args.share_devices:
+        local_rank %= n_dev
+    elif local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} HIP device(s) visible "
+                         f"(--share-devices maps ranks onto the devices present)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
     S, T, K, W = args.streams, args.blocks, args.steps, args.warmup
     if args.total_streams:
         _, S = adist.shard_range(args.total_streams, rank, world)
-    segs = 2
-    far, near = synth_on_device(torch, S, segs * T * 64, 1234 + rank, device)
+    far, near = synth_on_device(torch, S, T * 64, 1234 + rank, device)
     clean = (near.to(torch.int32) * 3 // 4).to(torch.int16) if args.clean else None
     batch = aecm.AecmBatch(S, args.fs, cng_mode=1, echo_mode=1, device=local_rank,
                            variant=aecm.KERNEL_FAST if args.variant == "fast" else aecm.KERNEL_SAFE)
     if args.fixed_delay >= 0:
         batch.control(args.fixed_delay, 1)
     stride = far.shape[1]
+    out = torch.empty_like(near)            # same [S][T*64] layout as the inputs
 
-    out_full = torch.empty_like(near)       # same [S][segs*T*64] layout as the inputs
-
-    def step(i):                            # one C-ABI call = one launch = S*T frames
-        off = (i % segs) * T * 64 * 2       # byte offset of this step's input segment
-        batch.process_device(far.data_ptr() + off, near.data_ptr() + off, out_full.data_ptr() + off, stride, 64, T,
-                             clean.data_ptr() + off if clean is not None else None)
+    def step():                             # one C-ABI call = one launch = S*T frames; the input repeats every T blocks
+        batch.process_device(far.data_ptr(), near.data_ptr(), out.data_ptr(), stride, 64, T,
+                             clean.data_ptr() if clean is not None else None)
 
     torch.cuda.synchronize()
-    for i in range(W):
-        step(i)
+    for _ in range(W):
+        step()
+    batch.synchronize()
     torch.cuda.synchronize()
     batch.reset_timers()
     adist.barrier(local_rank)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(K):
-        step(W + i)
+    for _ in range(K):
+        step()
+    batch.synchronize()                     # the engine runs on its own (non-blocking) HIP stream
     torch.cuda.synchronize()
     adist.barrier(local_rank)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kernel_ms_total, launches = batch.timers()
+    kernel_ms_total, launches = batch.timers()      # HIP events recorded by the library around every launch, on its stream
     assert launches == K, (launches, K)
 
-    frames, wall_max, kernel_ms_max = adist.gather_counters(S * T * K, wall, kernel_ms_total,
-                                                            device if args.dist_backend == "nccl" else torch.device("cpu"))
+    c = adist.gather_counters(S * T * K, wall, kernel_ms_total, device if args.dist_backend == "nccl" else torch.device("cpu"))
     if rank == 0:
-        value = frames / wall_max
+        value = c["frames"] / c["seconds"]
         kern_avg_s = kernel_ms_total / launches / 1e3
         algo_bytes = ALGO_BYTES_PER_FRAME + (128 if args.clean else 0)
         achieved = algo_bytes * S * T / kern_avg_s / 1e9
-        workload_key = f"S{S}_T{T}_fs{args.fs}"
+        workload_key = f"S{S}_T{T}_fs{args.fs}" + ("_clean" if args.clean else "")
+        traffic, issue = load_profile_record(aecm.library_path(), workload_key)
+        if args.variant != "fast" or args.clean:
+            traffic, issue = None, None
+        try:
+            commit = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except Exception:
+            commit = None
         res = {
             "metric": "AECM frames/sec (64-sample @16kHz) per GPU; bit-exact vs aecm_core_c.cc",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
+            "ms_per_step": c["seconds"] / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (Q-format fixed point)", "data": "synthetic",
-            "config": {"workload": f"{S} streams/GPU x {T} blocks/step, {args.fs} Hz (BASELINE.json configs[2]; "
-                                   f"configs[1] = --streams 4096), cng on, echoMode 1{', clean near-end input' if args.clean else ''}, inputs resident in HBM",
+            "config": {"workload": workload_name(S, T, args.fs, world, args.clean),
                        "streams_per_gpu": S, "blocks_per_step": T, "fs": args.fs, "kernel_variant": args.variant,
-                       "sharding": f"static, {world} x {S} independent streams, no data-path collective"},
+                       "sharding": f"static, {world} x {S} independent streams, no data-path collective",
+                       "timed_region_s": c["seconds"], "commit": commit},
+            "ranks": {"world_size": world, "ranks_seen": c["ranks_seen"], "collective_backend": c["backend"],
+                      "devices_visible_to_rank0": n_dev, "share_devices": bool(args.share_devices),
+                      "per_rank_frames_per_s": [p[0] / p[1] for p in c["per_rank"]],
+                      "per_rank_kernel_ms_per_step": [p[2] / K for p in c["per_rank"]]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(workload_key),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": f"aecm_process_kernel<{args.variant},{'clean' if args.clean else 'noclean'}>",
                          "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_frame": algo_bytes,
+                         "algorithmic_bytes_per_launch": algo_bytes * S * T,
                          "note": "instruction-issue-bound integer kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "
                                  "see issue_bound for the binding resource",
-                         "issue_bound": load_issue_note()},
+                         "issue_bound": issue},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.fs)
+            n_pairs = min(usable_cores(), S, 32)
+            pairs = [(far[i].cpu().numpy(), near[i].cpu().numpy()) for i in range(n_pairs)]
+            res["cpu_baseline"] = cpu_baseline(args.fs, pairs)
         # RCCL writes its version banner to C stdout; flush that first so the JSON is the last line we emit
         try:
             import ctypes

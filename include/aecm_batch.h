@@ -87,9 +87,13 @@ int32_t WebRtcAecmBatch_ResetTimers(AecmBatch *b);
 int32_t WebRtcAecmBatch_InitEchoPath(AecmBatch *b, int32_t stream, const void *echo_path, size_t size_bytes);
 int32_t WebRtcAecmBatch_GetEchoPath(AecmBatch *b, int32_t stream, void *echo_path, size_t size_bytes);
 
-/* Full snapshot of one stream's device state (checkpoint / migration between batches or GPUs):
- * lane-vector words, scalars and far-spectrum history, WebRtcAecmBatch_state_size_bytes() bytes.
- * A stream restored with ImportState continues bit-exactly where the exported one stopped. */
+/* Full snapshot of one stream's device state (checkpoint / migration between batches or GPUs): a 32-byte
+ * header (magic, layout version, sampling rate, layout sizes) + lane-vector words, scalars and far-spectrum
+ * history, WebRtcAecmBatch_state_size_bytes() bytes.  A stream restored with ImportState continues bit-exactly
+ * where the exported one stopped.  ImportState refuses (AECM_BAD_PARAMETER_ERROR) a blob whose header is not
+ * this build's layout or whose index-like fields are out of range.  Importing a stream of the other sampling
+ * rate is allowed (the rate is part of the state) but disables WebRtcAecmBatch_ProcessRecordings
+ * (AECM_UNSUPPORTED_FUNCTION_ERROR) until the next WebRtcAecmBatch_Init. */
 size_t WebRtcAecmBatch_state_size_bytes(void);
 int32_t WebRtcAecmBatch_ExportState(AecmBatch *b, int32_t stream, void *state, size_t size_bytes);
 int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *state, size_t size_bytes);
@@ -132,6 +136,31 @@ int32_t WebRtcAecmSessions_TickPerSession(AecmSessions *s, const int16_t *far_de
 int32_t WebRtcAecmSessions_TickPerSessionHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
                                               const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
                                               size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host);
+/* The same with per-session call flags (host array, S entries): AECM_SESSION_NO_FAREND = this session gets NO
+ * WebRtcAecm_BufferFarend call in this tick (far-end underrun; its WebRtcAecm_Process then replays the previous
+ * far frame, reference echo_control_mobile.cc:369-380) -- its far row is ignored.  Sessions with different
+ * flag histories live in different flow classes, exactly like different msInSndCardBuf histories. */
+enum { AECM_SESSION_NO_FAREND = 1 };
+int32_t WebRtcAecmSessions_TickFlags(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
+                                     const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples,
+                                     const int16_t *msInSndCardBuf_host, const uint8_t *flags_host, int32_t *codes_host);
+int32_t WebRtcAecmSessions_TickFlagsHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
+                                         const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                         size_t nrOfSamples, const int16_t *msInSndCardBuf_host, const uint8_t *flags_host,
+                                         int32_t *codes_host);
+
+/* Per-session control while the other sessions keep running (a media server recycling one slot when a call
+ * ends).  `session` in [0, S); same return codes as the single-session functions they mirror:
+ *   InitSession           <-> WebRtcAecm_Init(inst_s, same sampFreq)   (echo_control_mobile.h:70): fresh core state,
+ *                             fresh jitter buffer / start-up phase, default config (cng on, echoMode 3)
+ *   set_config_session    <-> WebRtcAecm_set_config(inst_s, config)   (:156)
+ *   InitEchoPath / GetEchoPath <-> WebRtcAecm_InitEchoPath / GetEchoPath (:172, :191), 130 bytes
+ * A re-initialised session starts a flow class of its own (shared with the other sessions re-initialised
+ * between the same two ticks); the 1024-class limit of TickPerSession applies. */
+int32_t WebRtcAecmSessions_InitSession(AecmSessions *s, int32_t session);
+int32_t WebRtcAecmSessions_set_config_session(AecmSessions *s, int32_t session, AecmConfig config);
+int32_t WebRtcAecmSessions_InitEchoPath(AecmSessions *s, int32_t session, const void *echo_path, size_t size_bytes);
+int32_t WebRtcAecmSessions_GetEchoPath(AecmSessions *s, int32_t session, void *echo_path, size_t size_bytes);
 /* Number of distinct msInSndCardBuf histories currently tracked (diagnostics). */
 int32_t WebRtcAecmSessions_num_flow_classes(AecmSessions *s);
 
@@ -141,6 +170,13 @@ int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
 /* Device self test of the wave primitives on device_id; failures[0..7] must all be 0 afterwards
  * (see webrtc_aecm_amd/csrc/aecm_kernels.h).  exhaustive != 0 checks floor-sqrt on all of [0, 2^31). */
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]);
+
+/* Precondition audit (diagnostics).  The block kernel replaces some of the reference's arithmetic by cheaper
+ * instructions where an operand range is provable (24-bit multiplies, int16 narrowings that are the identity).
+ * libaecm_mi355x_checked.so is the same library built with -DAECM_CHECKED: its kernels verify every such claim at
+ * run time and count violations -- counters[0] 24-bit multiply operands, counters[1] int16 narrowings -- while still
+ * producing exact results.  The shipped library carries no checks and returns AECM_UNSUPPORTED_FUNCTION_ERROR. */
+int32_t WebRtcAecmBatch_GetCheckCounters(int32_t device_id, uint64_t counters[2], int32_t reset);
 
 /* Diagnostics: `count` independent 128-point transforms of the block kernel's own FFT code, on host
  * data in natural order (transform k: data[k*256 .. +128) = re, [.. +256) = im, in place).  variant 0 =

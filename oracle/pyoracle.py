@@ -18,6 +18,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 ORACLE_SO = HERE / "_build" / "libaecm_oracle.so"
 REF_SO = HERE / "_ref" / "libaecm_ref.so"
+REFMAIN = HERE / "_ref" / "aecm_run_refmain"     # the reference's main.cc, unmodified, linked against the MI355X library
 BLOCK = 64
 BINS = 65
 DIGEST_WORDS = 24
@@ -41,6 +42,10 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", str(HERE), "oracle"], stdout=subprocess.DEVNULL)
     if Path("/root/reference/aecm").is_dir() and (force or not REF_SO.exists()):
         subprocess.check_call(["make", "-C", str(HERE), "ref"], stdout=subprocess.DEVNULL)
+    product = HERE.parent / "webrtc_aecm_amd" / "_lib" / "libaecm_mi355x.so"
+    if Path("/root/reference/main.cc").is_file() and product.exists() and (
+            force or not REFMAIN.exists() or REFMAIN.stat().st_mtime < product.stat().st_mtime):
+        subprocess.check_call(["make", "-C", str(HERE), "refmain"], stdout=subprocess.DEVNULL)
 
 
 def have_reference() -> bool:
@@ -212,6 +217,35 @@ class RefSession:
         rc = self.lib.WebRtcAecm_set_config(self.h, AecmConfig(cng_mode, echo_mode))
         if rc != 0:
             raise ValueError(rc)
+
+    # one-call doors, same shapes as webrtc_aecm_amd.Aecm (tests drive both with the same sequence)
+    def init(self, fs):
+        return self.lib.WebRtcAecm_Init(self.h, fs)
+
+    def set_config(self, cng_mode, echo_mode):
+        return self.lib.WebRtcAecm_set_config(self.h, AecmConfig(cng_mode, echo_mode))
+
+    def buffer_farend(self, far):
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        return self.lib.WebRtcAecm_BufferFarend(self.h, far.ctypes.data, far.size)
+
+    def process(self, near, clean=None, ms=0):
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        out = np.empty_like(near)
+        cp = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            cp = clean.ctypes.data
+        rc = self.lib.WebRtcAecm_Process(self.h, near.ctypes.data, cp, out.ctypes.data, near.size, ms)
+        return rc, out
+
+    def init_echo_path(self, path):
+        path = np.ascontiguousarray(path, dtype=np.int16)
+        return self.lib.WebRtcAecm_InitEchoPath(self.h, path.ctypes.data, path.nbytes)
+
+    def get_echo_path(self):
+        out = np.zeros(BINS, dtype=np.int16)
+        return self.lib.WebRtcAecm_GetEchoPath(self.h, out.ctypes.data, out.nbytes), out
 
     def run(self, far, near, frame, ms=40):
         """main.cc:105-143 loop: BufferFarend + Process per `frame` samples; returns processed near."""

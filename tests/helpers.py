@@ -87,3 +87,32 @@ def adversarial_cases(n_cases=24, n_blocks=1000, seed=7):
                 rs.choice([0, 1, -1, 32767, -32768, 12000], size=65).astype(np.int16)
         yield dict(far=far, near=near, fs=int(rs.choice([8000, 16000])), cng=int(rs.randint(0, 2)),
                    echo_mode=int(rs.randint(0, 5)), path=path)
+
+
+def call_pattern(seed, n_calls):
+    """A hostile but deterministic call pattern for session tests: msInSndCardBuf jitters around 40 ms with
+    occasional out-of-range / large excursions, and now and then a call comes without a WebRtcAecm_BufferFarend
+    (far-end underrun).  Returns (ms[int16 n_calls], far_present[uint8 n_calls])."""
+    rs = np.random.RandomState(1000 + seed)
+    ms = (40 + rs.randint(-12, 13, size=n_calls)).astype(np.int16)
+    special = np.nonzero(np.arange(n_calls) % 40 == 39)[0]
+    ms[special] = rs.choice([-3, 0, 600, 90, 250], size=special.size)
+    far_present = np.ones(n_calls, dtype=np.uint8)
+    far_present[np.arange(n_calls) % 97 == 96] = 0
+    far_present[(np.arange(n_calls) % 211 >= 205) & (np.arange(n_calls) > 100)] = 0     # a run of underruns
+    return ms, far_present
+
+
+def drive_session(sess, far, near, frame, ms_seq, far_present=None, clean=None):
+    """Drive an ABI-shaped session object (webrtc_aecm_amd.Aecm, pyoracle.RefSession, simlib.SimSession) call by
+    call; returns (out, codes[n_calls])."""
+    n_calls = near.size // frame
+    out = np.empty(n_calls * frame, dtype=np.int16)
+    codes = np.zeros(n_calls, dtype=np.int32)
+    for i in range(n_calls):
+        sl = slice(i * frame, (i + 1) * frame)
+        if far_present is None or far_present[i]:
+            rc = sess.buffer_farend(far[sl])
+            assert rc == 0, (i, rc)
+        codes[i], out[sl] = sess.process(near[sl], None if clean is None else clean[sl], int(ms_seq[i]))
+    return out, codes

@@ -84,7 +84,7 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
 }
 bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks, const int32_t *) { return ProcessBlocksHost(io, num_blocks); }
 bool BatchEngine::Synchronize() { return true; }
-bool BatchEngine::FlushTimers() { return true; }
+bool BatchEngine::HarvestTimers(bool) { return true; }
 bool BatchEngine::LastLaunchMs(float *ms) { *ms = 0.f; return true; }
 bool BatchEngine::Timers(double *t, int64_t *n) { *t = 0; *n = 0; return true; }
 void BatchEngine::ResetTimers() {}
@@ -99,7 +99,7 @@ bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
     return true;
 }
 bool BatchEngine::ExportState(int, void *) { return false; }
-bool BatchEngine::ImportState(int, const void *) { return false; }
+int32_t BatchEngine::ImportState(int, const void *) { return kErrUnspecified; }
 bool BatchEngine::Digest(int stream, uint32_t d[kDigestWords]) {
     SimStore *s = Store(st_);
     ComputeDigest(&s->vec[(size_t)stream * kVecWordsPerStream], &s->scal[(size_t)stream * kNumScal],

@@ -42,10 +42,11 @@ def test_two_rank_gloo_sharded_run_matches_single_process(tmp_path):
             far, near = synth_pair(900 + s, 300, 16000)
             outs.append(simlib.SimStream(16000, 1, 3).process(far, near))
         adist.barrier()
-        frames, secs, kms = adist.gather_counters(count * 300, time.perf_counter() - t0, 1.0 + rank, torch.device("cpu"))
+        c = adist.gather_counters(count * 300, time.perf_counter() - t0, 1.0 + rank, torch.device("cpu"))
         np.save({str(tmp_path)!r} + f"/out_{{rank}}.npy", np.stack(outs))
         if rank == 0:
-            open({str(tmp_path)!r} + "/counters.txt", "w").write(f"{{frames}} {{kms}}")
+            assert c["ranks_seen"] == 2 and [p[0] for p in c["per_rank"]] == [900, 900] and c["backend"] == "gloo"
+            open({str(tmp_path)!r} + "/counters.txt", "w").write(f"{{c['frames']}} {{c['kernel_ms']}}")
     """))
     import simlib
     simlib.build()
@@ -59,3 +60,20 @@ def test_two_rank_gloo_sharded_run_matches_single_process(tmp_path):
     for s in range(6):
         far, near = synth_pair(900 + s, 300, 16000)
         assert np.array_equal(got[s], simlib.SimStream(16000, 1, 3).process(far, near))
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` without WORLD_SIZE re-executes itself under torch.distributed.run with two ranks
+    (the driver's command shape for N = 1 must also work for N > 1).  Without a GPU both ranks get as far as the
+    device check -- after the process group of 2 has formed -- and say so."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: covered by the -m gpu test")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-devices", "--streams", "8", "--blocks", "4",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert out.count("bench.py needs a GPU") >= 2, out[-3000:]          # both ranks ran main() under WORLD_SIZE=2
+    assert "WORLD_SIZE=1" not in out

@@ -1,0 +1,111 @@
+"""N-rank path on real hardware without needing N GPUs: two ranks (torch.distributed.run, gloo for the counter
+collective) share the one MI355X of the GPU box, each creating its own HIP engine with AecmBatch(device=...) and
+owning its static shard of the streams -- the code path `bench.py --gpus N` runs, with RCCL swapped for gloo only
+because RCCL refuses two ranks on one device."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from helpers import oracle_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_two_ranks_shard_8192_streams_on_the_hip_library(tmp_path):
+    """Rank r processes streams shard_range(8192, r, 2) through the C ABI on the GPU; the union must equal the
+    oracle for every stream (64 distinct seeds replicated), and the gathered counters must prove two ranks took part."""
+    total, T, fs, U = 8192, 96, 16000, 64
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, time
+        sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / 'tests')!r})
+        import numpy as np, torch
+        import webrtc_aecm_amd as aecm
+        from webrtc_aecm_amd import dist as adist
+        from helpers import synth_streams
+        rank, local_rank, world = adist.init("gloo")
+        dev = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        first, count = adist.shard_range({total}, rank, world)
+        seeds = [3000 + (s % {U}) for s in range(first, first + count)]
+        far, near = synth_streams(seeds[:{U}] if count >= {U} else seeds, {T}, {fs})
+        idx = np.arange(count) % far.shape[0]
+        dfar = torch.from_numpy(far[idx]).cuda(); dnear = torch.from_numpy(near[idx]).cuda(); dout = torch.empty_like(dnear)
+        torch.cuda.synchronize()
+        b = aecm.AecmBatch(count, {fs}, device=dev)
+        adist.barrier()
+        t0 = time.perf_counter()
+        b.process_device(dfar.data_ptr(), dnear.data_ptr(), dout.data_ptr(), {T} * 64, 64, {T})
+        b.synchronize()
+        adist.barrier()
+        kms, n = b.timers()
+        c = adist.gather_counters(count * {T}, time.perf_counter() - t0, kms, torch.device("cpu"))
+        np.save({str(tmp_path)!r} + f"/out_{{rank}}.npy", dout.cpu().numpy())
+        np.save({str(tmp_path)!r} + f"/first_{{rank}}.npy", np.array([first, count, dev]))
+        if rank == 0:
+            import json
+            json.dump(dict(frames=c["frames"], ranks_seen=c["ranks_seen"], per_rank=c["per_rank"]), open({str(tmp_path)!r} + "/counters.json", "w"))
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    """))
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29631", str(script)], env=_clean_env(), timeout=600)
+    c = json.load(open(tmp_path / "counters.json"))
+    assert c["ranks_seen"] == 2 and c["frames"] == total * T and len(c["per_rank"]) == 2 and all(p[2] > 0 for p in c["per_rank"])
+    spans = [np.load(tmp_path / f"first_{r}.npy") for r in (0, 1)]
+    assert spans[0][0] == 0 and spans[0][1] == 4096 and spans[1][0] == 4096 and spans[1][1] == 4096
+    exp, _ = oracle_batch([3000 + k for k in range(U)], T, fs, [(1, 3)] * U)
+    for r in (0, 1):
+        out = np.load(tmp_path / f"out_{r}.npy")
+        first, count = int(spans[r][0]), int(spans[r][1])
+        want = exp[(np.arange(first, first + count)) % U]
+        assert np.array_equal(out, want), f"rank {r}"
+
+
+def test_bench_self_launch_two_ranks_share_one_gpu():
+    """`python bench.py --gpus 2 --share-devices`: started by hand it must re-execute under torch.distributed.run,
+    both ranks must run the HIP engine and the JSON must show ranks_seen == 2 with per-rank rates."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-devices", "--streams", "4096", "--blocks", "64",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["ranks"]["ranks_seen"] == 2 and d["ranks"]["collective_backend"] == "gloo"
+    assert len(d["ranks"]["per_rank_frames_per_s"]) == 2 and all(v > 1e6 for v in d["ranks"]["per_rank_frames_per_s"])
+    assert d["config"]["streams_per_gpu"] == 4096 and "configs[1]" in d["config"]["workload"]
+    assert d["value"] > 0 and d["roofline"]["kernel_avg_ms"] > 0
+
+
+def test_reference_main_cc_unmodified_on_the_gpu(tmp_path):
+    """The reference's own caller (main.cc, compiled unmodified against include/ and linked to libaecm_mi355x.so by
+    oracle/Makefile: refmain) run on a WAV pair: <near>_out.wav must equal the reference-generated fixture byte for byte."""
+    import wave
+    from oracle import pyoracle
+    from webrtc_aecm_amd.synth import synth_pair
+    if not pyoracle.REFMAIN.exists():
+        pytest.skip("prebuilt oracle/_ref/aecm_run_refmain not present")
+    g = np.load(ROOT / "tests" / "golden" / "session_s7_fs16000_f160_c1_e1_ms40.npz")       # main.cc's parameters
+    far, near = synth_pair(int(g["seed"]), int(g["n_blocks"]), 16000, "mixed")
+    for name, x in (("far.wav", far), ("near.wav", near)):
+        with wave.open(str(tmp_path / name), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(np.asarray(x, dtype="<i2").tobytes())
+    r = subprocess.run([str(pyoracle.REFMAIN), str(tmp_path / "far.wav"), str(tmp_path / "near.wav")], capture_output=True, text=True,
+                       input="\n", timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with wave.open(str(tmp_path / "near_out.wav"), "rb") as w:
+        assert w.getframerate() == 16000 and w.getnchannels() == 1
+        out = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    n = g["out"].size
+    assert np.array_equal(out[:n], g["out"])

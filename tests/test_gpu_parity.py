@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 
 import webrtc_aecm_amd as aecm
-from helpers import (GOLDEN, adversarial_cases, describe_digest_diff, golden_files, oracle_batch, oracle_run, stream_config,
-                     synth_streams)
+from helpers import (GOLDEN, adversarial_cases, call_pattern, describe_digest_diff, drive_session, golden_files, oracle_batch,
+                     oracle_run, stream_config, synth_streams)
 from oracle import pyoracle
 from webrtc_aecm_amd.synth import synth_clean, synth_pair
 
@@ -258,7 +258,7 @@ def test_state_snapshot_migrates_a_stream():
     a = aecm.AecmBatch(3, fs, 1, 2)
     a.process_host(far[:, :T1 * 64], near[:, :T1 * 64])
     blob = a.export_state(2)
-    assert len(blob) == aecm.load().WebRtcAecmBatch_state_size_bytes() == 17408
+    assert len(blob) == aecm.load().WebRtcAecmBatch_state_size_bytes() == 32 + 17408        # header + vec + scal + hist
     b = aecm.AecmBatch(2, 8000, 0, 4)                      # deliberately different rate/config: all of it is state
     b.import_state(1, blob)
     out_a = a.process_host(far[:, T1 * 64:], near[:, T1 * 64:])
@@ -616,3 +616,325 @@ def test_large_batch_properties_65536_streams():
     got = dout.cpu()
     exp = torch.from_numpy(exp_out)[idx]
     assert torch.equal(got, exp)
+
+
+def test_state_snapshot_import_is_validated():
+    """ImportState refuses blobs that are not snapshots of this layout or whose index-like fields are out of
+    range (they would be used as addresses by the kernel), and leaves the stream untouched."""
+    import struct
+    fs = 16000
+    far, near = synth_streams([5], 200, fs)
+    b = aecm.AecmBatch(1, fs)
+    b.process_host(far, near)
+    blob = b.export_state(0)
+    lib = aecm.load()
+    dig = b.digest(0)
+
+    def imp(x):
+        return lib.WebRtcAecmBatch_ImportState(b.h, 0, bytes(x), len(x))
+    assert imp(blob) == 0
+    bad = bytearray(blob)
+    bad[0] ^= 0xff                                                        # magic
+    assert imp(bad) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, 4, 99)                                    # layout version
+    assert imp(bad) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    scal0 = 32 + 17 * 64 * 4                                              # header + lane vectors
+    for field, value in ((3, 1000), (3, -1), (28, 100), (29, 3), (2, 7)):  # S_HISTPOS, S_LAST_DELAY, S_MULT, S_STARTUP
+        bad = bytearray(blob)
+        struct.pack_into("<i", bad, scal0 + 4 * field, value)
+        assert imp(bad) == aecm.ffi.AECM_BAD_PARAMETER_ERROR, (field, value)
+    assert lib.WebRtcAecmBatch_ImportState(b.h, 0, blob[:-2], len(blob) - 2) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert np.array_equal(b.digest(0), dig)
+    # a stream of the other rate may be imported, but whole-recording scheduling is then refused until Init
+    b8 = aecm.AecmBatch(1, 8000)
+    assert lib.WebRtcAecmBatch_ImportState(b8.h, 0, blob, len(blob)) == 0
+    z = np.zeros((1, 1600), np.int16)
+    rc, _ = b8.process_recordings_host(z, z, 160)
+    assert rc == aecm.ffi.AECM_UNSUPPORTED_FUNCTION_ERROR
+    assert lib.WebRtcAecmBatch_Control(b.h, 100, 1, 0, -1) == aecm.ffi.AECM_BAD_PARAMETER_ERROR       # delay beyond the 100-slot history
+
+
+def test_session_jitter_goldens():
+    """Committed reference outputs for a jittering msInSndCardBuf + far-end underruns (tools/gen_golden.py,
+    sessjit_*): the single-session ABI and the streaming ticks (uniform + per-session forms) must reproduce them."""
+    files = golden_files("sessjit_")
+    assert len(files) >= 3
+    for f in files:
+        g = np.load(f)
+        fs, frame, cng, em = int(g["fs"]), int(g["frame"]), int(g["cng"]), int(g["echo_mode"])
+        far, near = synth_pair(int(g["seed"]), int(g["n_blocks"]), fs, "mixed")
+        ms_seq, far_present = g["ms_seq"], g["far_present"]
+        assert np.array_equal(ms_seq, call_pattern(int(g["seed"]), ms_seq.size)[0])
+        s = aecm.Aecm()
+        assert s.init(fs) == 0 and s.set_config(cng, em) == 0
+        out, codes = drive_session(s, far, near, frame, ms_seq, far_present)
+        s.close()
+        assert np.array_equal(codes, g["codes"]) and np.array_equal(out, g["out"]), f.name
+        # the same as session 1 of a 3-session streaming batch (sessions 0 / 2 run a plain pattern)
+        S = 3
+        sb = aecm.AecmSessions(S, fs, cng, em)
+        n_calls = ms_seq.size
+        got = np.empty_like(out)
+        for i in range(n_calls):
+            sl = slice(i * frame, (i + 1) * frame)
+            ms = np.array([40, ms_seq[i], 40], dtype=np.int16)
+            fl = np.array([0, 0 if far_present[i] else aecm.ffi.SESSION_NO_FAREND, 0], dtype=np.uint8)
+            rc, o, c = sb.tick_host_per_session(np.stack([far[sl]] * S), np.stack([near[sl]] * S), ms, flags=fl)
+            assert c[1] == g["codes"][i], (f.name, i)
+            got[sl] = o[1]
+        sb.close()
+        assert np.array_equal(got, g["out"]), f.name
+
+
+_needs_ref = pytest.mark.skipif(not pyoracle.have_reference(), reason="prebuilt oracle/_ref/libaecm_ref.so not present")
+
+
+@_needs_ref
+def test_single_session_abi_vs_reference_jitter_underruns_all_call_sizes():
+    """WebRtcAecm_* on the GPU against the reference's own session ABI driven call by call with the same hostile
+    pattern: jittering / out-of-range msInSndCardBuf, far-end underruns, 80- and 160-sample calls, both rates,
+    with and without nearendClean."""
+    for k, (fs, frame, with_clean) in enumerate(((16000, 160, 0), (16000, 80, 0), (8000, 80, 1), (8000, 160, 0), (16000, 160, 1))):
+        far, near = synth_pair(500 + k, 4 * fs // 64, fs, "mixed")
+        clean = synth_clean(near) if with_clean else None
+        n_calls = far.size // frame
+        ms_seq, far_present = call_pattern(40 + k, n_calls)
+        r = pyoracle.RefSession(fs, 1, 2)
+        s = aecm.Aecm()
+        assert s.init(fs) == 0 and s.set_config(1, 2) == 0
+        exp, exp_codes = drive_session(r, far, near, frame, ms_seq, far_present, clean)
+        got, codes = drive_session(s, far, near, frame, ms_seq, far_present, clean)
+        s.close()
+        assert np.array_equal(codes, exp_codes), (fs, frame)
+        assert np.array_equal(got, exp), (fs, frame, int(np.nonzero(got != exp)[0][0]) // frame)
+
+
+@_needs_ref
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_streaming_ticks_vs_reference_sessions(fused):
+    """WebRtcAecmSessions_Tick / TickPerSession / TickFlags against one reference session per stream (not against
+    our own single-session path): uniform jittering delay, then per-session delays with underruns."""
+    import os
+    import subprocess
+    import sys
+    forced = os.environ.get("AECM_TICK_FUSED")              # the tick form (one launch / three launches) is chosen once per process
+    if forced is not None and forced != fused:
+        pytest.skip("this process is pinned to the other tick form")
+    if forced is None:
+        env = dict(os.environ, AECM_TICK_FUSED=fused)
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k",
+                            f"test_streaming_ticks_vs_reference_sessions and {fused}"], env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    for fs, frame, with_clean in ((16000, 160, 0), (8000, 80, 1), (8000, 160, 0)):
+        S = 6
+        pairs = [synth_pair(640 + k, 4 * fs // 64, fs, "mixed") for k in range(S)]
+        n_calls = pairs[0][0].size // frame
+        far = np.stack([p[0][:n_calls * frame] for p in pairs])
+        near = np.stack([p[1][:n_calls * frame] for p in pairs])
+        clean = synth_clean(near) if with_clean else None
+        pats = [call_pattern(70 + k, n_calls) for k in range(S)]
+        refs = [pyoracle.RefSession(fs, 1, 3) for _ in range(S)]
+        sb = aecm.AecmSessions(S, fs, 1, 3)
+        for i in range(n_calls):
+            sl = slice(i * frame, (i + 1) * frame)
+            c = None if clean is None else clean[:, sl]
+            if i < n_calls // 3:                                   # uniform tick, jittering value
+                ms = np.full(S, pats[0][0][i], dtype=np.int16)
+                fl = np.zeros(S, dtype=np.uint8)
+                rc, out = sb.tick_host(far[:, sl], near[:, sl], int(ms[0]), c)
+                codes = np.full(S, rc)
+            else:                                                  # per-session values + underruns
+                ms = np.array([pats[k][0][i] for k in range(S)], dtype=np.int16)
+                fl = np.array([0 if pats[k][1][i] else aecm.ffi.SESSION_NO_FAREND for k in range(S)], dtype=np.uint8)
+                fl[0] = 0
+                rc, out, codes = sb.tick_host_per_session(far[:, sl], near[:, sl], ms, c, flags=fl)
+            for k in range(S):
+                if not fl[k]:
+                    assert refs[k].buffer_farend(far[k, sl]) == 0
+                rc1, o1 = refs[k].process(near[k, sl], None if clean is None else clean[k, sl], int(ms[k]))
+                assert codes[k] == rc1, (fs, frame, i, k)
+                assert np.array_equal(out[k], o1), (fs, frame, i, k)
+        sb.close()
+
+
+@_needs_ref
+def test_session_churn_slots_recycled_mid_run():
+    """A media server recycling slots: sessions are re-initialised, re-configured and re-seeded (echo path) by index
+    while the others keep running, with per-session delays and underruns; every slot must equal a reference
+    session that received exactly the same calls (WebRtcAecm_Init / set_config / InitEchoPath / BufferFarend / Process)."""
+    rs = np.random.RandomState(77)
+    for fs, frame in ((16000, 160), (8000, 80)):
+        S = 8
+        n_calls = 3 * fs // frame
+        pairs = [synth_pair(900 + k, n_calls * frame // 64 + 1, fs, "mixed") for k in range(S)]
+        far = np.stack([p[0][:n_calls * frame] for p in pairs])
+        near = np.stack([p[1][:n_calls * frame] for p in pairs])
+        refs = [pyoracle.RefSession(fs, 1, 3) for _ in range(S)]
+        sb = aecm.AecmSessions(S, fs, 1, 3)
+        base_ms = np.array([40, 40, 60, 40, 100, 40, 40, 25], dtype=np.int16)
+        path = (np.arange(65) * 53 % 3000 + 100).astype(np.int16)
+        for i in range(n_calls):
+            sl = slice(i * frame, (i + 1) * frame)
+            # churn events between ticks
+            if i in (n_calls // 4, n_calls // 2):
+                for k in (1, 5) if i == n_calls // 4 else (1, 2, 6):
+                    assert sb.init_session(k) == 0 and refs[k].init(fs) == 0
+                    cfg = (int(rs.randint(0, 2)), int(rs.randint(0, 5)))
+                    assert sb.set_config_session(k, *cfg) == 0 and refs[k].set_config(*cfg) == 0
+            if i == n_calls // 3:
+                assert sb.init_echo_path(3, path) == 0 and refs[3].init_echo_path(path) == 0
+                assert sb.set_config_session(4, 0, 1) == 0 and refs[4].set_config(0, 1) == 0
+            ms = base_ms.copy()
+            fl = np.zeros(S, dtype=np.uint8)
+            if i % 37 == 36:
+                fl[[0, 5]] = aecm.ffi.SESSION_NO_FAREND
+            rc, out, codes = sb.tick_host_per_session(far[:, sl], near[:, sl], ms, flags=fl)
+            for k in range(S):
+                if not fl[k]:
+                    assert refs[k].buffer_farend(far[k, sl]) == 0
+                rc1, o1 = refs[k].process(near[k, sl], None, int(ms[k]))
+                assert codes[k] == rc1 and np.array_equal(out[k], o1), (fs, i, k)
+        rc3, p3 = sb.get_echo_path(3)
+        rc3r, p3r = refs[3].get_echo_path()
+        assert rc3 == rc3r == 0 and np.array_equal(p3, p3r)
+        assert sb.init_session(S) == aecm.ffi.AECM_BAD_PARAMETER_ERROR and sb.set_config_session(0, 1, 7) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+        assert sb.num_flow_classes() <= S
+        sb.close()
+
+
+def test_tick_argument_validation():
+    """nrOfSamples is validated as a size_t (2^32 + 80 is not 80), strides must cover the tick."""
+    import ctypes as C
+    lib = aecm.load()
+    sb = aecm.AecmSessions(2, 16000)
+    z = np.zeros((2, 160), np.int16)
+    o = np.zeros_like(z)
+    args = (z.ctypes.data, z.ctypes.data, None, o.ctypes.data)
+    assert lib.WebRtcAecmSessions_TickHost(sb.h, *args, 160, C.c_size_t(2 ** 32 + 80), 40) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert lib.WebRtcAecmSessions_TickHost(sb.h, *args, 160, 100, 40) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert lib.WebRtcAecmSessions_TickHost(sb.h, *args, 100, 160, 40) == aecm.ffi.AECM_BAD_PARAMETER_ERROR      # stride < n
+    assert lib.WebRtcAecmSessions_TickHost(sb.h, *args, 160, 160, 40) == 0
+    with pytest.raises(ValueError):
+        sb.tick_host(np.zeros((3, 160), np.int16), np.zeros((3, 160), np.int16))
+    with pytest.raises(ValueError):
+        sb.tick_host(z, np.zeros((2, 80), np.int16))
+    sb.close()
+
+
+def test_config4_8khz_32768_streams_property():
+    """BASELINE config 4 at full size (8 kHz mode, 32768 streams): replicated streams must equal the oracle's answer
+    for the 64 distinct seeds they replicate (size-independent property, as for config 3)."""
+    import torch
+    S, T, fs, U = 32768, 320, 8000, 64
+    seeds = list(range(1400, 1400 + U))
+    far, near = synth_streams(seeds, T, fs)
+    exp_out, exp_dig = oracle_batch(seeds, T, fs, [(1, 3)] * U)
+    idx = torch.arange(S) % U
+    dfar = torch.from_numpy(far)[idx].contiguous().cuda()
+    dnear = torch.from_numpy(near)[idx].contiguous().cuda()
+    dout = torch.empty_like(dnear)
+    torch.cuda.synchronize()
+    b = aecm.AecmBatch(S, fs)
+    b.process_device(dfar.data_ptr(), dnear.data_ptr(), dout.data_ptr(), T * 64, 64, T)
+    b.synchronize()
+    assert torch.equal(dout.cpu(), torch.from_numpy(exp_out)[idx])
+    for s in (0, 63, 64, S - 1):
+        assert np.array_equal(b.digest(s), exp_dig[s % U])
+
+
+def test_recordings_batch_larger_than_the_scratch_budget():
+    """ProcessRecordings cuts the streams into chunks that fit its fixed scratch budget and folds the stream index
+    into grid.x: a batch of more than 65535 recordings (the old grid.y limit) must work and equal a small batch."""
+    import torch
+    S, fs, frame, n_calls, U = 66000, 16000, 160, 150, 4
+    pairs = [synth_pair(1700 + k, n_calls * frame // 64 + 1, fs, "mixed") for k in range(U)]
+    far = np.stack([p[0][:n_calls * frame] for p in pairs])
+    near = np.stack([p[1][:n_calls * frame] for p in pairs])
+    small = aecm.AecmBatch(U, fs, 1, 1)
+    rc, exp = small.process_recordings_host(far, near, frame, 40)
+    assert rc == 0
+    idx = torch.arange(S) % U
+    dfar = torch.from_numpy(far)[idx].contiguous().cuda()
+    dnear = torch.from_numpy(near)[idx].contiguous().cuda()
+    dout = torch.zeros_like(dnear)
+    torch.cuda.synchronize()
+    big = aecm.AecmBatch(S, fs, 1, 1)
+    assert big.process_recordings_device(dfar.data_ptr(), dnear.data_ptr(), dout.data_ptr(), n_calls * frame, frame, n_calls, 40) == 0
+    assert torch.equal(dout.cpu(), torch.from_numpy(exp)[idx])
+
+
+def test_device_precondition_audit_build(tmp_path):
+    """Every "provably fits" claim of the block kernel (24-bit multiplies, int16 narrowings dropped as the identity;
+    aecm_ops.h mul24 / as_i16) verified ON THE DEVICE: libaecm_mi355x_checked.so (same sources, -DAECM_CHECKED) counts
+    violations while the adversarial corpus, the mixed-profile streams of both rates, the clean-input path, random
+    full-range echo paths and states restored through ImportState from long runs go through it.  Counters must stay 0
+    and the outputs must still equal the oracle's.  The shipped library has no such counters (12001)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    from webrtc_aecm_amd import build
+    with pytest.raises(aecm.AecmError) as e:
+        aecm.check_counters(0)
+    assert e.value.code == aecm.ffi.AECM_UNSUPPORTED_FUNCTION_ERROR
+    assert build.LIB_CHECKED.exists()
+    script = tmp_path / "audit.py"
+    script.write_text(textwrap.dedent("""
+        import sys
+        import numpy as np
+        import webrtc_aecm_amd as aecm
+        from helpers import adversarial_cases, synth_streams, oracle_batch, stream_config
+        from oracle import pyoracle
+        from webrtc_aecm_amd.synth import synth_clean
+        assert aecm.check_counters(0, reset=True) is not None
+        for fs in (16000, 8000):
+            sel = [c for c in adversarial_cases(n_cases=36, n_blocks=700, seed=19) if c["fs"] == fs]
+            b = aecm.AecmBatch(len(sel), fs)
+            for k, c in enumerate(sel):
+                b.set_config(c["cng"], c["echo_mode"], k, 1)
+                if c["path"] is not None:
+                    b.init_echo_path(k, c["path"])
+            out = b.process_host(np.stack([c["far"] for c in sel]), np.stack([c["near"] for c in sel]))
+            for k, c in enumerate(sel):
+                o = pyoracle.OracleStream(fs, c["cng"], c["echo_mode"])
+                if c["path"] is not None:
+                    o.init_echo_path(c["path"])
+                assert np.array_equal(out[k], o.process(c["far"], c["near"])), (fs, k)
+            S, T = 32, 2100
+            seeds = list(range(5000, 5000 + S))
+            cfgs = [stream_config(s) for s in range(S)]
+            far, near = synth_streams(seeds, T, fs)
+            b = aecm.AecmBatch(S, fs)
+            for s, (cng, em) in enumerate(cfgs):
+                b.set_config(cng, em, s, 1)
+            half = (T // 2) * 64
+            out1 = b.process_host(far[:, :half], near[:, :half])
+            # states restored through ImportState from a long run continue in another batch
+            b2 = aecm.AecmBatch(S, fs)
+            for s in range(S):
+                b2.import_state(s, b.export_state(S - 1 - s))
+            out2 = b2.process_host(far[::-1, half:].copy(), near[::-1, half:].copy())[::-1]
+            exp, _ = oracle_batch(seeds, T, fs, cfgs)
+            assert np.array_equal(np.concatenate([out1, out2], axis=1), exp), fs
+            clean = synth_clean(near[:8, :600 * 64])
+            bc = aecm.AecmBatch(8, fs)
+            bc.process_host(far[:8, :600 * 64], near[:8, :600 * 64], clean)
+        # full-scale white noise on both ends, loud channel, every echo mode
+        rs = np.random.RandomState(3)
+        far = rs.randint(-32768, 32768, size=(10, 500 * 64)).astype(np.int16)
+        near = rs.randint(-32768, 32768, size=(10, 500 * 64)).astype(np.int16)
+        b = aecm.AecmBatch(10, 16000)
+        for k in range(10):
+            b.set_config(k % 2, k % 5, k, 1)
+            b.init_echo_path(k, np.full(65, 32767 if k % 3 else -32768, np.int16))
+        b.process_host(far, near)
+        c = aecm.check_counters(0)
+        print("AUDIT", int(c[0]), int(c[1]))
+    """))
+    env = dict(os.environ, AECM_LIB_PATH=str(build.LIB_CHECKED),
+               PYTHONPATH=os.pathsep.join([str(GOLDEN.parent.parent), str(GOLDEN.parent), os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "AUDIT 0 0" in r.stdout, r.stdout[-500:]

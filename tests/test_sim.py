@@ -239,3 +239,19 @@ def test_host_built_kernel_constants_equal_their_definitions():
     assert np.array_equal(blob[512:512 + tw.size], tw)
     hann = blob[512 + tw.size + 360:]
     assert hann.size == 68 and hann[0] == 0 and hann[64] == 16384
+
+
+def test_session_jitter_goldens_on_the_host_session_logic():
+    """sessjit_* fixtures (reference outputs for a jittering msInSndCardBuf + far-end underruns): the product's
+    Session class over the simulated engine must reproduce them call by call."""
+    from helpers import drive_session
+    files = golden_files("sessjit_")
+    assert len(files) >= 3
+    for f in files:
+        g = np.load(f)
+        fs, frame = int(g["fs"]), int(g["frame"])
+        far, near = synth_pair(int(g["seed"]), int(g["n_blocks"]), fs, "mixed")
+        s = simlib.SimSession()
+        assert s.init(fs) == 0 and s.set_config(int(g["cng"]), int(g["echo_mode"])) == 0
+        out, codes = drive_session(s, far, near, frame, g["ms_seq"], g["far_present"])
+        assert np.array_equal(codes, g["codes"]) and np.array_equal(out, g["out"]), f.name

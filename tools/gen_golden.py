@@ -35,6 +35,12 @@ SESSION_CASES = [
     (10, 6, 16000, 160, 1, 3, 40, 1),     # noise suppressor upstream: WebRtcAecm_Process(noisy, clean, ...)
     (11, 4, 8000, 160, 1, 1, 40, 1),
 ]
+# Jittering msInSndCardBuf + far-end underruns (tests/helpers.py: call_pattern): (seed, seconds, fs, frame, cng, echo_mode)
+SESSJIT_CASES = [
+    (12, 6, 16000, 160, 1, 3),
+    (13, 6, 8000, 80, 1, 1),
+    (14, 5, 16000, 80, 0, 4),
+]
 
 
 def main():
@@ -82,6 +88,21 @@ def main():
                             fs=fs, frame=frame, cng=cng, echo_mode=em, ms=ms, clean=with_clean, out=out[:n],
                             codes=np.array(sorted(codes)), sha256=hashlib.sha256(out[:n].tobytes()).hexdigest())
         print("session", seed, fs, frame, cng, em, ms, with_clean, sorted(codes))
+    sys.path.insert(0, str(ROOT / "tests"))
+    from helpers import call_pattern, drive_session
+    for seed, secs, fs, frame, cng, em in SESSJIT_CASES:
+        name = f"sessjit_s{seed}_fs{fs}_f{frame}_c{cng}_e{em}"
+        if only and only not in name:
+            continue
+        nb = secs * fs // 64
+        far, near = synth_pair(seed, nb, fs, "mixed")
+        n_calls = far.size // frame
+        ms_seq, far_present = call_pattern(seed, n_calls)
+        out, codes = drive_session(pyoracle.RefSession(fs, cng, em), far, near, frame, ms_seq, far_present)
+        np.savez_compressed(GOLD / f"{name}.npz", seed=seed, n_blocks=nb, fs=fs, frame=frame, cng=cng, echo_mode=em,
+                            ms_seq=ms_seq, far_present=far_present, out=out, codes=codes,
+                            sha256=hashlib.sha256(out.tobytes()).hexdigest())
+        print("sessjit", seed, fs, frame, cng, em, sorted(set(codes.tolist())), int((far_present == 0).sum()), "underruns")
     if only:
         return
     # 60 s reference-CLI-shaped run: hash only

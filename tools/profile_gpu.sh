@@ -1,23 +1,58 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py.
-# Outputs land in gpurun_out/prof_*; copy the summaries you want judged into profiles/.
+# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py (and of the streaming
+# tick bench).  Outputs land in gpurun_out/prof_*; tools/summarize_profile.py condenses them into profiles/.
+#   PARTS="stats hbm sq cal tick pcs" tools/profile_gpu.sh      (default: stats hbm sq cal tick)
+# Counters are collected in their own runs with --kernel-trace only (never together with sys/hip/hsa tracing).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+PARTS=${PARTS:-"stats hbm sq cal tick"}
 BENCH="python $R/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
-rocprofv3 -L > "$OUT/counters_available.txt" 2>&1 || true
-# 1. per-kernel time (same command as the bench line)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -o bench -- $BENCH --steps 10 --warmup 2 > "$OUT/prof_stats.log" 2>&1
-# 2. HBM traffic: separate passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/prof_write" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_write.log" 2>&1
-# 3. SQ counters: instruction mix, busy cycles, LDS bank conflicts
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$OUT/prof_sq1" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_sq1.log" 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_sq2" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_sq2.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace --output-format csv -d "$OUT/prof_grbm" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_grbm.log" 2>&1
-find "$OUT" -name "*.csv" | head -50
-# 4. FETCH_SIZE calibration on a known byte count: fixed delay 0 => no far-history reads, so the
-#    kernel reads exactly inputs (256 B/frame) + state (4608 B/stream) per launch.
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_cal" -o bench -- $BENCH --steps 3 --warmup 1 --fixed-delay 0 > "$OUT/prof_fetch_cal.log" 2>&1
+PMC_STEPS="--steps 2 --warmup 1"
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+pmc() {   # pmc <dir> <counters...>
+  local d=$1; shift
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$d" -o bench -- $BENCH $PMC_STEPS > "$OUT/$d.log" 2>&1
+}
+python - > "$OUT/prof_meta.json" <<PY
+import json, subprocess, sys
+sys.path.insert(0, "$R")
+import webrtc_aecm_amd as aecm
+from webrtc_aecm_amd import isa_census
+lib = aecm.load()
+c = isa_census.census(aecm.library_path())
+commit = subprocess.run(["git", "-C", "$R", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+print(json.dumps({"state_size_bytes": lib.WebRtcAecmBatch_state_size_bytes(), "kernel_fingerprint": c["fingerprint"],
+                  "static_counts": c["counts"], "static_valu_fast_class": c["valu_fast_class"], "commit": commit or None}))
+PY
+if has stats; then   # per-kernel time (same command as the bench line)
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -o bench -- $BENCH --steps 10 --warmup 2 > "$OUT/prof_stats.log" 2>&1
+fi
+if has hbm; then     # HBM traffic: separate passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
+  pmc prof_fetch FETCH_SIZE
+  pmc prof_write WRITE_SIZE
+fi
+if has sq; then      # SQ counters: instruction mix, busy cycles, LDS bank conflicts
+  pmc prof_sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+  pmc prof_sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+  pmc prof_sq3 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_INT32 SQ_IFETCH
+  pmc prof_grbm GRBM_GUI_ACTIVE GRBM_COUNT
+fi
+if has cal; then     # FETCH_SIZE calibration on a known byte count: fixed delay 0 => no far-history reads, so the
+                     # kernel reads exactly inputs (256 B/frame) + one state image per stream per launch
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_cal" -o bench -- $BENCH $PMC_STEPS --fixed-delay 0 > "$OUT/prof_fetch_cal.log" 2>&1
+fi
+if has tick; then    # the streaming path: 65 536 sessions on a 10 ms clock
+  TICK="python $R/tools/bench_sessions.py --streams 65536 --ticks 200"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_tick" -o tick -- $TICK > "$OUT/prof_tick.log" 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_tick_fetch" -o tick -- $TICK > "$OUT/prof_tick_fetch.log" 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/prof_tick_write" -o tick -- $TICK > "$OUT/prof_tick_write.log" 2>&1
+fi
+if has pcs; then     # PC sampling of the block kernel (beta feature; bounded by a short timeout of its own)
+  ROCPROFILER_PC_SAMPLING_BETA_ENABLED=1 timeout 180 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-unit time --pc-sampling-method host_trap \
+      --pc-sampling-interval 1000 --kernel-trace --output-format csv -d "$OUT/prof_pcs" -o bench -- $BENCH --steps 3 --warmup 1 --streams 16384 --blocks 256 > "$OUT/prof_pcs.log" 2>&1
+  echo "pc sampling rc=$?" >> "$OUT/prof_pcs.log"
+fi
+find "$OUT" -name "*.csv" -newer "$OUT/prof_meta.json" | head -60

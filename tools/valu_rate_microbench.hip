@@ -182,6 +182,29 @@ KERNEL_SCLOB(k_salu, "s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 
 KERNEL_SCLOB(k_valu_salu, "v_lshlrev_b32 %0, 3, %0\n s_add_u32 s20, s20, 1\n v_lshlrev_b32 %1, 3, %1\n s_add_u32 s21, s21, 1\n"
                     "v_lshlrev_b32 %2, 3, %2\n s_add_u32 s22, s22, 1\n v_lshlrev_b32 %3, 3, %3\n s_add_u32 s23, s23, 1\n")
 
+// ---- third batch (round 2): how long must a run of fast-class ops be to keep its ~2.3-cycle rate? -------------
+// A = v_add_u32 (fast class), X = v_perm_b32 (4-cycle class), all on independent registers.
+#define A_(i) "v_add_u32 %" #i ", %" #i ", %8\n"
+#define X_(i) "v_perm_b32 %" #i ", %" #i ", %8, %9\n"
+#define M_(i) "v_mov_b32 %" #i ", %8\n"
+#define S_(i) "v_ashrrev_i32 %" #i ", 3, %" #i "\n"
+#define D_(i) "v_dot2c_i32_i16 %" #i ", %8, %9\n"
+KERNEL(k_run1, A_(0) X_(1) A_(2) X_(3) A_(4) X_(5) A_(6) X_(7))                 // A X A X ...
+KERNEL(k_run2, A_(0) A_(1) X_(2) X_(3) A_(4) A_(5) X_(6) X_(7))                 // AA XX AA XX
+KERNEL(k_run4, A_(0) A_(1) A_(2) A_(3) X_(4) X_(5) X_(6) X_(7))                 // AAAA XXXX
+KERNEL(k_run6, A_(0) A_(1) A_(2) A_(3) A_(4) A_(5) X_(6) X_(7))                 // AAAAAA XX
+KERNEL(k_run7, A_(0) A_(1) A_(2) A_(3) A_(4) A_(5) A_(6) X_(7))                 // AAAAAAA X
+KERNEL(k_aax, A_(0) A_(1) X_(2) A_(3) A_(4) X_(5) A_(6) A_(7))                  // AAX AAX AA (wraps into AAAAX...)
+KERNEL(k_mixfast, A_(0) M_(1) S_(2) A_(3) M_(4) S_(5) A_(6) S_(7))              // different fast-class opcodes back to back
+KERNEL(k_dep2, "v_add_u32 %0, %0, %8\n v_add_u32 %0, %0, %8\n" X_(1) "v_add_u32 %2, %2, %8\n v_add_u32 %2, %2, %8\n" X_(3)
+               "v_add_u32 %4, %4, %8\n v_add_u32 %4, %4, %8\n" X_(5))           // dependent fast pairs between 4-cycle ops (9 instructions)
+KERNEL(k_run2d, A_(0) A_(1) D_(2) D_(3) A_(4) A_(5) D_(6) D_(7))                // AA DD with dot2c
+KERNEL(k_e64, "v_add_u32_e64 %0, %0, %8\n v_add_u32_e64 %1, %1, %8\n v_add_u32_e64 %2, %2, %8\n v_add_u32_e64 %3, %3, %8\n"
+              "v_add_u32_e64 %4, %4, %8\n v_add_u32_e64 %5, %5, %8\n v_add_u32_e64 %6, %6, %8\n v_add_u32_e64 %7, %7, %8\n")   // fast op, VOP3 encoding
+KERNEL_SCLOB(k_addsgpr, "v_add_u32 %0, s20, %0\n v_add_u32 %1, s20, %1\n v_add_u32 %2, s20, %2\n v_add_u32 %3, s20, %3\n"
+                        "v_add_u32 %4, s20, %4\n v_add_u32 %5, s20, %5\n v_add_u32 %6, s20, %6\n v_add_u32 %7, s20, %7\n")        // SGPR operand
+KERNEL_SCLOB(k_nop, "s_nop 0\n v_perm_b32 %0, %0, %8, %9\n s_nop 0\n v_perm_b32 %1, %1, %8, %9\n s_nop 0\n v_perm_b32 %2, %2, %8, %9\n s_nop 0\n v_perm_b32 %3, %3, %8, %9\n")
+
 typedef void (*kern_t)(int *, int);
 static void run(const char *name, kern_t fn, int waves_per_simd, double extra_per_8 = 0) {
     int *out;
@@ -230,6 +253,19 @@ int main(int argc, char **argv) {
         {"dependent v_add chain", k_dep_add, 0}, {"dependent v_lshl chain", k_dep_shl, 0}, {"s_add_u32", k_salu, 0},
         {"v_lshl + s_add interleaved (per pair)", k_valu_salu, -4},
     };
+    if (argc > 1 && !strcmp(argv[1], "--batch3")) {
+        // extra = instructions per unrolled body - 8
+        struct { const char *n; kern_t f; double extra; } t3[] = {
+            {"A X A X A X A X (run 1)", k_run1, 0}, {"AA XX AA XX (run 2)", k_run2, 0}, {"AAAA XXXX (run 4)", k_run4, 0},
+            {"AAAAAA XX (run 6)", k_run6, 0}, {"AAAAAAA X (run 7)", k_run7, 0}, {"AAX AAX AA", k_aax, 0},
+            {"add mov ashr mixed fast ops", k_mixfast, 0}, {"dependent AA X x3 (9 instr)", k_dep2, 1},
+            {"AA DD (dot2c) run 2", k_run2d, 0}, {"v_add_u32_e64 x8", k_e64, 0}, {"v_add_u32 sgpr operand x8", k_addsgpr, 0},
+            {"s_nop 0 + v_perm x4 (per pair)", k_nop, -4},
+        };
+        for (int w : {2, 7})
+            for (auto &e : t3) run(e.n, e.f, w, e.extra);
+        return 0;
+    }
     const bool second = argc > 1 && !strcmp(argv[1], "--batch2");
     if (!second)
         for (auto &e : t) run(e.n, e.f, 5, e.extra);

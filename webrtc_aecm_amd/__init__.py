@@ -4,7 +4,7 @@ The hot path -- WebRtcAecm_ProcessBlock of cpuimage/WebRTC_AECM -- is hand-writt
 (one wavefront per stream, webrtc_aecm_amd/csrc/), exposed through the reference's own C ABI plus a
 batch extension (include/*.h).  This package only builds and binds that shared library.
 """
-from .ffi import (Aecm, AecmBatch, AecmSessions, AecmConfig, AecmError, KERNEL_FAST, KERNEL_SAFE, debug_fft128,  # noqa: F401
-                  device_info, load, self_test)
+from .ffi import (check_counters, Aecm, AecmBatch, AecmSessions, AecmConfig, AecmError, KERNEL_FAST, KERNEL_SAFE, debug_fft128,  # noqa: F401
+                  device_info, library_path, load, self_test)
 
-__all__ = ["Aecm", "AecmBatch", "AecmSessions", "AecmConfig", "AecmError", "KERNEL_FAST", "KERNEL_SAFE", "debug_fft128", "device_info", "load", "self_test"]
+__all__ = ["check_counters", "Aecm", "AecmBatch", "AecmSessions", "AecmConfig", "AecmError", "KERNEL_FAST", "KERNEL_SAFE", "debug_fft128", "device_info", "library_path", "load", "self_test"]

@@ -1,15 +1,18 @@
-"""Build the HIP shared library in-tree: webrtc_aecm_amd/_lib/libaecm_mi355x.so (gfx950 only)."""
+"""Build the HIP shared library in-tree: webrtc_aecm_amd/_lib/libaecm_mi355x.so (gfx950 only), the CLI next to
+it, and the precondition-audit twin libaecm_mi355x_checked.so (same sources, kernels built with -DAECM_CHECKED)."""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "_lib"
 LIB = LIB_DIR / "libaecm_mi355x.so"
+LIB_CHECKED = LIB_DIR / "libaecm_mi355x_checked.so"
 CLI = LIB_DIR / "aecm_run"
 SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_schedule.cpp", "aecm_sessions.cpp", "aecm_capi.cpp",
            "aecm_host_state.cpp"]
@@ -26,18 +29,23 @@ def _hipcc() -> str:
 
 
 def is_stale() -> bool:
-    if not LIB.exists():
+    if not LIB.exists() or not LIB_CHECKED.exists() or not CLI.exists():
         return True
-    t = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*")) + list((PKG.parent / "include").glob("*.h"))
+    t = min(LIB.stat().st_mtime, LIB_CHECKED.stat().st_mtime)
+    deps = list(CSRC.glob("*")) + list((PKG.parent / "include").rglob("*.h"))
     return any(d.stat().st_mtime > t for d in deps)
 
 
+def _compile_flags():
+    return [f for f in HIPCC_FLAGS if f != "-shared"]
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP/C++ source of the engine into one shared library for gfx950.
+    """Compile every HIP/C++ source of the engine for gfx950 (one hipcc -c per source, in parallel) and link the
+    shipped library, its audit twin and the CLI.
 
     Safe to call from several processes at once (one rank per GPU under torch.distributed.run): the
-    build is serialised by a file lock and the library is moved into place atomically."""
+    build is serialised by a file lock and the libraries are moved into place atomically."""
     if not force and not is_stale():
         return LIB
     import fcntl
@@ -47,18 +55,35 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         try:
             if not force and not is_stale():          # another process built it while we waited
                 return LIB
-            tmp = LIB_DIR / f".{LIB.name}.{os.getpid()}.tmp"
-            cmd = [_hipcc(), *HIPCC_FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(tmp)]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd, cwd=str(CSRC))
-            os.replace(tmp, LIB)
+            obj_dir = LIB_DIR / f".obj.{os.getpid()}"
+            obj_dir.mkdir(exist_ok=True)
+            hipcc = _hipcc()
+            jobs = [(s, obj_dir / (s + ".o"), []) for s in SOURCES]
+            jobs.append(("aecm_kernels.hip", obj_dir / "aecm_kernels.checked.o", ["-DAECM_CHECKED"]))
+
+            def compile_one(job):
+                src, obj, extra = job
+                cmd = [hipcc, *_compile_flags(), *extra, "-c", str(CSRC / src), "-o", str(obj)]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.check_call(cmd, cwd=str(CSRC))
+            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+                list(ex.map(compile_one, jobs))
+            common = [str(obj_dir / (s + ".o")) for s in SOURCES if s != "aecm_kernels.hip"]
+            for out, kern in ((LIB, obj_dir / "aecm_kernels.hip.o"), (LIB_CHECKED, obj_dir / "aecm_kernels.checked.o")):
+                tmp = LIB_DIR / f".{out.name}.{os.getpid()}.tmp"
+                cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", str(kern), *common, "-o", str(tmp)]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.check_call(cmd, cwd=str(CSRC))
+                os.replace(tmp, out)
+            shutil.rmtree(obj_dir, ignore_errors=True)
             # the command-line front end (reference main.cc equivalent + multi-file batch mode)
             tmp_cli = LIB_DIR / f".{CLI.name}.{os.getpid()}.tmp"
             cli = ["g++", "-O2", "-std=c++17", str(CSRC / "aecm_cli.cpp"), "-o", str(tmp_cli), f"-L{LIB_DIR}", "-laecm_mi355x",
                    "-Wl,-rpath,$ORIGIN"]
             if verbose:
-                print(" ".join(cli))
+                print(" ".join(cli), flush=True)
             subprocess.check_call(cli, cwd=str(CSRC))
             os.replace(tmp_cli, CLI)
         finally:

@@ -110,6 +110,8 @@ int32_t WebRtcAecmBatch_set_config(AecmBatch *b, AecmConfig config, int32_t firs
 
 int32_t WebRtcAecmBatch_Control(AecmBatch *b, int32_t fixed_delay, int32_t nlp_flag, int32_t first, int32_t count) {
     if (int32_t rc = CheckRange(b, first, &count)) return rc;
+    // the reference uses fixedDelay unchecked as a far-history offset (aecm_core.cc:157-172, MAX_DELAY = 100 slots)
+    if (fixed_delay >= aecm::kHistory) return AECM_BAD_PARAMETER_ERROR;
     return b->engine->Control(fixed_delay, nlp_flag, first, count) ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
@@ -230,7 +232,7 @@ int32_t WebRtcAecmBatch_ExportState(AecmBatch *b, int32_t stream, void *state, s
 
 int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *state, size_t size_bytes) {
     if (int32_t rc = CheckState(b, stream, state, size_bytes)) return rc;
-    return b->engine->ImportState(stream, state) ? 0 : AECM_UNSPECIFIED_ERROR;
+    return b->engine->ImportState(stream, state);
 }
 
 int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]) {
@@ -268,20 +270,35 @@ int32_t WebRtcAecmSessions_set_config(AecmSessions *s, AecmConfig config) {
     return s ? s->batch->SetConfig(config.cngMode, config.echoMode) : -1;
 }
 
+int32_t WebRtcAecmSessions_InitSession(AecmSessions *s, int32_t session) { return s ? s->batch->InitSession(session) : -1; }
+
+int32_t WebRtcAecmSessions_set_config_session(AecmSessions *s, int32_t session, AecmConfig config) {
+    return s ? s->batch->SetConfigSession(session, config.cngMode, config.echoMode) : -1;
+}
+
+int32_t WebRtcAecmSessions_InitEchoPath(AecmSessions *s, int32_t session, const void *echo_path, size_t size_bytes) {
+    return s ? s->batch->InitEchoPathSession(session, echo_path, size_bytes) : -1;
+}
+
+int32_t WebRtcAecmSessions_GetEchoPath(AecmSessions *s, int32_t session, void *echo_path, size_t size_bytes) {
+    return s ? s->batch->GetEchoPathSession(session, echo_path, size_bytes) : -1;
+}
+
+// nrOfSamples stays a size_t all the way down: 2^32 + 80 must be refused like the reference does, not narrowed to 80.
 int32_t WebRtcAecmSessions_Tick(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
                                 const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples,
                                 int16_t msInSndCardBuf) {
     if (!s) return -1;
-    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, (int)nrOfSamples, msInSndCardBuf, nullptr,
-                          nullptr, false);
+    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, nrOfSamples, msInSndCardBuf, nullptr,
+                          nullptr, nullptr, false);
 }
 
 int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
                                     const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
                                     size_t nrOfSamples, int16_t msInSndCardBuf) {
     if (!s) return -1;
-    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, (int)nrOfSamples, msInSndCardBuf,
-                          nullptr, nullptr, true);
+    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, nrOfSamples, msInSndCardBuf,
+                          nullptr, nullptr, nullptr, true);
 }
 
 int32_t WebRtcAecmSessions_TickPerSession(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
@@ -289,8 +306,8 @@ int32_t WebRtcAecmSessions_TickPerSession(AecmSessions *s, const int16_t *far_de
                                           size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host) {
     if (!s) return -1;
     if (!msInSndCardBuf_host) return AECM_NULL_POINTER_ERROR;
-    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, (int)nrOfSamples, 0, msInSndCardBuf_host,
-                          codes_host, false);
+    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, nrOfSamples, 0, msInSndCardBuf_host,
+                          nullptr, codes_host, false);
 }
 
 int32_t WebRtcAecmSessions_TickPerSessionHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
@@ -298,8 +315,27 @@ int32_t WebRtcAecmSessions_TickPerSessionHost(AecmSessions *s, const int16_t *fa
                                               size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host) {
     if (!s) return -1;
     if (!msInSndCardBuf_host) return AECM_NULL_POINTER_ERROR;
-    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, (int)nrOfSamples, 0,
-                          msInSndCardBuf_host, codes_host, true);
+    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, nrOfSamples, 0,
+                          msInSndCardBuf_host, nullptr, codes_host, true);
+}
+
+int32_t WebRtcAecmSessions_TickFlags(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
+                                     const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples,
+                                     const int16_t *msInSndCardBuf_host, const uint8_t *flags_host, int32_t *codes_host) {
+    if (!s) return -1;
+    if (!msInSndCardBuf_host || !flags_host) return AECM_NULL_POINTER_ERROR;
+    return s->batch->Tick(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, nrOfSamples, 0, msInSndCardBuf_host,
+                          flags_host, codes_host, false);
+}
+
+int32_t WebRtcAecmSessions_TickFlagsHost(AecmSessions *s, const int16_t *far_host, const int16_t *near_host,
+                                         const int16_t *near_clean_host, int16_t *out_host, int64_t stream_stride,
+                                         size_t nrOfSamples, const int16_t *msInSndCardBuf_host, const uint8_t *flags_host,
+                                         int32_t *codes_host) {
+    if (!s) return -1;
+    if (!msInSndCardBuf_host || !flags_host) return AECM_NULL_POINTER_ERROR;
+    return s->batch->Tick(far_host, near_host, near_clean_host, out_host, stream_stride, nrOfSamples, 0,
+                          msInSndCardBuf_host, flags_host, codes_host, true);
 }
 
 int32_t WebRtcAecmSessions_num_flow_classes(AecmSessions *s) { return s ? s->batch->num_flow_classes() : -1; }
@@ -322,6 +358,14 @@ int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t
     (void)hipFree(dev);
     (void)hipFree(consts);
     return rc;
+}
+
+int32_t WebRtcAecmBatch_GetCheckCounters(int32_t device_id, uint64_t counters[2], int32_t reset) {
+    if (!counters) return AECM_NULL_POINTER_ERROR;
+    if (hipSetDevice(device_id) != hipSuccess) return AECM_UNSPECIFIED_ERROR;
+    const hipError_t e = aecm::ReadCheckCounters(counters, reset != 0);
+    if (e == hipErrorNotSupported) return AECM_UNSUPPORTED_FUNCTION_ERROR;
+    return e == hipSuccess ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
 int32_t WebRtcAecmBatch_DebugFft128(int32_t device_id, int16_t *data_host, int32_t *scales_host, int32_t variant,

@@ -31,7 +31,7 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
               AECM_HIP_OK(hipMalloc((void **)&e->image_scal_dev_, kNumScal * sizeof(int32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&e->patch_dev_, 32 * sizeof(int32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&e->consts_dev_, kConstBlobWords * sizeof(uint32_t))) &&
-              AECM_HIP_OK(hipEventCreate(&e->ev_start_)) && AECM_HIP_OK(hipEventCreate(&e->ev_stop_));
+              true;                                   // the timing events are created on first use (ProcessBlocks)
     if (ok) {
         std::vector<uint32_t> blob;
         BuildKernelConstants(&blob);
@@ -48,8 +48,10 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
 BatchEngine::~BatchEngine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (ev_start_) (void)hipEventDestroy(ev_start_);
-    if (ev_stop_) (void)hipEventDestroy(ev_stop_);
+    for (int i = 0; i < kTimerSlots; ++i) {
+        if (ev_start_[i]) (void)hipEventDestroy(ev_start_[i]);
+        if (ev_stop_[i]) (void)hipEventDestroy(ev_stop_[i]);
+    }
     (void)hipFree(st_.vec);
     (void)hipFree(st_.scal);
     (void)hipFree(st_.hist);
@@ -58,6 +60,8 @@ BatchEngine::~BatchEngine() {
     (void)hipFree(patch_dev_);
     (void)hipFree(consts_dev_);
     (void)hipFree(stage_dev_);
+    (void)hipFree(rec_maps_);
+    (void)hipFree(rec_scratch_);
     if (download_stream_) (void)hipStreamDestroy(download_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -76,7 +80,15 @@ bool BatchEngine::Init(int fs) {
     if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;   // img goes out of scope
     initialized_ = true;
     fs_ = fs;
+    mixed_rates_ = false;
     return true;
+}
+
+bool BatchEngine::InitStreams(int first, int count) {
+    if (!initialized_ || first < 0 || count < 0 || first + count > num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    // image_*_dev_ still hold the initial image of the last Init
+    return AECM_HIP_OK(LaunchBroadcastImage(st_, image_vec_dev_, image_scal_dev_, first, count, stream_));
 }
 
 bool BatchEngine::PatchScalars(const int32_t *fields, const int32_t *values, int n, int first, int count) {
@@ -115,25 +127,51 @@ bool BatchEngine::Control(int fixed_delay, int nlp_flag, int first, int count) {
     return PatchScalars(fields, values, 2, first, count);
 }
 
-bool BatchEngine::FlushTimers() {
-    if (!timed_pending_) return true;
-    if (!AECM_HIP_OK(hipEventSynchronize(ev_stop_))) return false;
-    float ms = 0.f;
-    if (!AECM_HIP_OK(hipEventElapsedTime(&ms, ev_start_, ev_stop_))) return false;
-    last_ms_ = ms;
-    total_ms_ += ms;
-    launches_ += 1;
-    timed_pending_ = false;
+// Collect the durations of finished launches.  wait_all: block until every pending pair has completed
+// (getters); otherwise take only what has already finished -- never blocks.
+bool BatchEngine::HarvestTimers(bool wait_all) {
+    while (timer_pending_ > 0) {
+        const int slot = timer_head_;
+        if (wait_all) {
+            if (!AECM_HIP_OK(hipEventSynchronize(ev_stop_[slot]))) return false;
+        } else {
+            const hipError_t q = hipEventQuery(ev_stop_[slot]);
+            if (q == hipErrorNotReady) return true;
+            if (q != hipSuccess) return false;
+        }
+        float ms = 0.f;
+        if (!AECM_HIP_OK(hipEventElapsedTime(&ms, ev_start_[slot], ev_stop_[slot]))) return false;
+        last_ms_ = ms;
+        total_ms_ += ms;
+        launches_ += 1;
+        timer_head_ = (timer_head_ + 1) % kTimerSlots;
+        --timer_pending_;
+    }
     return true;
 }
 
 bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks, const int32_t *blocks_per_stream_dev) {
+    return ProcessBlocksRange(io, num_blocks, 0, num_streams_, blocks_per_stream_dev);
+}
+
+// Streams [first, first + count); io (and blocks_per_stream_dev) are indexed from `first`.
+bool BatchEngine::ProcessBlocksRange(const IoView &io, int num_blocks, int first, int count, const int32_t *blocks_per_stream_dev) {
+    if (first < 0 || count < 0 || first + count > num_streams_) return false;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
-    if (!FlushTimers()) return false;            // the event pair is reused: harvest the previous launch first
-    if (!AECM_HIP_OK(hipEventRecord(ev_start_, stream_))) return false;
-    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, io, num_streams_, num_blocks, variant_, stream_, blocks_per_stream_dev))) return false;
-    if (!AECM_HIP_OK(hipEventRecord(ev_stop_, stream_))) return false;
-    timed_pending_ = true;
+    if (!HarvestTimers(false)) return false;
+    if (timer_pending_ == kTimerSlots) {         // ring full: wait for the oldest launch only
+        if (!AECM_HIP_OK(hipEventSynchronize(ev_stop_[timer_head_])) || !HarvestTimers(false)) return false;
+    }
+    const int slot = (timer_head_ + timer_pending_) % kTimerSlots;
+    if (!ev_start_[slot] && (!AECM_HIP_OK(hipEventCreate(&ev_start_[slot])) || !AECM_HIP_OK(hipEventCreate(&ev_stop_[slot])))) return false;
+    if (!AECM_HIP_OK(hipEventRecord(ev_start_[slot], stream_))) return false;
+    StatePtrs st = st_;
+    st.vec += (size_t)first * kVecWordsPerStream;
+    st.scal += (size_t)first * kNumScal;
+    st.hist += (size_t)first * kHistWordsPerStream;
+    if (!AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, stream_, blocks_per_stream_dev))) return false;
+    if (!AECM_HIP_OK(hipEventRecord(ev_stop_[slot], stream_))) return false;
+    ++timer_pending_;
     return true;
 }
 
@@ -247,62 +285,90 @@ bool BatchEngine::ProcessBlocksHostPipelined(const IoView &io, int num_blocks) {
     return ok;
 }
 
+// Grow-only device scratch shared by the recording batches (no hipMalloc / hipFree per call).
+bool BatchEngine::EnsureRecordingScratch(size_t map_elems, size_t sample_elems) {
+    if (map_elems > rec_maps_elems_) {
+        (void)hipFree(rec_maps_);
+        rec_maps_ = nullptr;
+        rec_maps_elems_ = 0;
+        if (!AECM_HIP_OK(hipMalloc((void **)&rec_maps_, map_elems * sizeof(int32_t)))) return false;
+        rec_maps_elems_ = map_elems;
+    }
+    if (sample_elems > rec_scratch_elems_) {
+        (void)hipFree(rec_scratch_);
+        rec_scratch_ = nullptr;
+        rec_scratch_elems_ = 0;
+        if (!AECM_HIP_OK(hipMalloc((void **)&rec_scratch_, sample_elems * sizeof(int16_t)))) return false;
+        rec_scratch_elems_ = sample_elems;
+    }
+    return true;
+}
+
 bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out,
                                     int64_t stream_stride, int frame, int n_calls, int16_t ms, bool host_pointers, int32_t *rc) {
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    if (mixed_rates_) { *rc = kErrUnsupported; return true; }        // an imported stream runs at another rate than fs_
     const RecordingSchedule sch = BuildRecordingSchedule(fs_, frame, n_calls, ms);
     if (sch.first_error) { *rc = sch.first_error; return true; }
     *rc = sch.warned ? kWarnBadParameter : 0;
     const int64_t n_in = (int64_t)n_calls * frame, n_blk = (int64_t)sch.n_blocks * kBlock;
-    const size_t S = (size_t)num_streams_;
     const int n_near = clean ? 2 : 1;      // the clean near-end follows the near-end's schedule sample for sample
-    // device scratch: [maps: far, near, out] + gathered far/near(/clean) blocks + block outputs (+ staged I/O for host pointers)
-    int32_t *maps = nullptr;
-    int16_t *scratch = nullptr;
-    const size_t map_elems = (size_t)(2 * n_blk + n_in);
-    const size_t blk_elems = (size_t)(2 + n_near) * S * (size_t)n_blk;
-    const size_t io_elems = host_pointers ? (size_t)(2 + n_near) * S * (size_t)n_in : 0;
-    bool ok = AECM_HIP_OK(hipMalloc((void **)&maps, std::max<size_t>(map_elems, 1) * sizeof(int32_t))) &&
-              AECM_HIP_OK(hipMalloc((void **)&scratch, std::max<size_t>(blk_elems + io_elems, 1) * sizeof(int16_t)));
-    const int16_t *dfar = far, *dnear = near, *dclean = clean;
-    int16_t *dout = out;
-    int64_t dstride = stream_stride;
-    if (ok && host_pointers) {
-        int16_t *io = scratch + blk_elems;
-        dstride = n_in;
-        auto upload = [&](const int16_t *src, int16_t *dst) {
-            return AECM_HIP_OK(hipMemcpy2DAsync(dst, n_in * 2, src, stream_stride * 2, n_in * 2, S, hipMemcpyHostToDevice, stream_));
-        };
-        ok = upload(far, io) && upload(near, io + S * n_in) && (!clean || upload(clean, io + 3 * S * n_in));
-        dfar = io;
-        dnear = io + S * n_in;
-        dout = io + 2 * S * n_in;
-        if (clean) dclean = io + 3 * S * n_in;
-    }
-    if (ok && n_blk > 0) {
+    // Device scratch per stream: gathered far/near(/clean) blocks + block outputs (+ staged I/O for host pointers).
+    // The streams are processed in chunks so that the scratch stays below kRecordingScratchBytes whatever the
+    // batch size and recording length (and the 1-D grids of the gather kernels stay below 2^31 workgroups).
+    const size_t blk_per_stream = (size_t)(2 + n_near) * (size_t)n_blk;
+    const size_t io_per_stream = host_pointers ? (size_t)(2 + n_near) * (size_t)n_in : 0;
+    const size_t per_stream = std::max<size_t>(blk_per_stream + io_per_stream, 1);
+    const int64_t tiles = std::max<int64_t>((std::max(n_in, n_blk) + 255) / 256, 1);
+    int64_t chunk = std::max<int64_t>((int64_t)(kRecordingScratchBytes / (per_stream * sizeof(int16_t))), 1);
+    chunk = std::min<int64_t>(chunk, 0x7fffffffll / tiles);
+    chunk = std::min<int64_t>(chunk, num_streams_);
+    const size_t map_elems = std::max<size_t>((size_t)(2 * n_blk + n_in), 1);
+    if (!EnsureRecordingScratch(map_elems, (size_t)chunk * per_stream)) return false;
+    int32_t *maps = rec_maps_;
+    bool ok = true;
+    if (n_blk > 0) {
         ok = AECM_HIP_OK(hipMemcpyAsync(maps, sch.far_map.data(), n_blk * sizeof(int32_t), hipMemcpyHostToDevice, stream_)) &&
              AECM_HIP_OK(hipMemcpyAsync(maps + n_blk, sch.near_map.data(), n_blk * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     }
     if (ok) ok = AECM_HIP_OK(hipMemcpyAsync(maps + 2 * n_blk, sch.out_map.data(), n_in * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    int16_t *bfar = scratch, *bnear = scratch + S * n_blk, *bout = scratch + 2 * S * n_blk, *bclean = scratch + 3 * S * n_blk;
-    if (ok && n_blk > 0) {
-        ok = AECM_HIP_OK(LaunchGatherByMap(dfar, dstride, maps, n_blk, bfar, n_blk, num_streams_, stream_)) &&
-             AECM_HIP_OK(LaunchGatherByMap(dnear, dstride, maps + n_blk, n_blk, bnear, n_blk, num_streams_, stream_)) &&
-             (!clean || AECM_HIP_OK(LaunchGatherByMap(dclean, dstride, maps + n_blk, n_blk, bclean, n_blk, num_streams_, stream_)));
-        if (ok) {
-            IoView io{bfar, bnear, clean ? bclean : nullptr, bout, n_blk, kBlock};
-            ok = ProcessBlocks(io, sch.n_blocks);
+    for (int64_t s0 = 0; ok && s0 < num_streams_; s0 += chunk) {
+        const size_t C = (size_t)std::min<int64_t>(chunk, num_streams_ - s0);
+        int16_t *bfar = rec_scratch_, *bnear = bfar + C * n_blk, *bout = bnear + C * n_blk, *bclean = bout + C * n_blk;
+        const int16_t *dfar = far + s0 * stream_stride, *dnear = near + s0 * stream_stride;
+        const int16_t *dclean = clean ? clean + s0 * stream_stride : nullptr;
+        int16_t *dout = out + s0 * stream_stride;
+        int64_t dstride = stream_stride;
+        if (host_pointers) {
+            int16_t *io = rec_scratch_ + C * blk_per_stream;
+            dstride = n_in;
+            auto upload = [&](const int16_t *src, int16_t *dst) {
+                return AECM_HIP_OK(hipMemcpy2DAsync(dst, n_in * 2, src, stream_stride * 2, n_in * 2, C, hipMemcpyHostToDevice, stream_));
+            };
+            ok = upload(dfar, io) && upload(dnear, io + C * n_in) && (!clean || upload(dclean, io + 3 * C * n_in));
+            dfar = io;
+            dnear = io + C * n_in;
+            dout = io + 2 * C * n_in;
+            if (clean) dclean = io + 3 * C * n_in;
         }
+        if (ok && n_blk > 0) {
+            ok = AECM_HIP_OK(LaunchGatherByMap(dfar, dstride, maps, n_blk, bfar, n_blk, (int)C, stream_)) &&
+                 AECM_HIP_OK(LaunchGatherByMap(dnear, dstride, maps + n_blk, n_blk, bnear, n_blk, (int)C, stream_)) &&
+                 (!clean || AECM_HIP_OK(LaunchGatherByMap(dclean, dstride, maps + n_blk, n_blk, bclean, n_blk, (int)C, stream_)));
+            if (ok) {
+                IoView io{bfar, bnear, clean ? bclean : nullptr, bout, n_blk, kBlock};
+                ok = ProcessBlocksRange(io, sch.n_blocks, (int)s0, (int)C, nullptr);
+            }
+        }
+        // pass-through samples of the start-up phase come from the clean near-end when there is one
+        // (reference echo_control_mobile.cc:285-291)
+        if (ok) ok = AECM_HIP_OK(LaunchAssembleOutput(bout, n_blk, clean ? dclean : dnear, dstride, maps + 2 * n_blk, n_in, dout, dstride,
+                                                      (int)C, stream_));
+        if (ok && host_pointers)
+            ok = AECM_HIP_OK(hipMemcpy2DAsync(out + s0 * stream_stride, stream_stride * 2, dout, n_in * 2, n_in * 2, C,
+                                              hipMemcpyDeviceToHost, stream_));
     }
-    // pass-through samples of the start-up phase come from the clean near-end when there is one
-    // (reference echo_control_mobile.cc:285-291)
-    if (ok) ok = AECM_HIP_OK(LaunchAssembleOutput(bout, n_blk, clean ? dclean : dnear, dstride, maps + 2 * n_blk, n_in, dout, dstride,
-                                                  num_streams_, stream_));
-    if (ok && host_pointers)
-        ok = AECM_HIP_OK(hipMemcpy2DAsync(out, stream_stride * 2, dout, n_in * 2, n_in * 2, S, hipMemcpyDeviceToHost, stream_));
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) ok = false;      // maps / scratch are freed below; sch goes out of scope
-    (void)hipFree(maps);
-    (void)hipFree(scratch);
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) ok = false;      // sch (the maps' host copy) goes out of scope
     return ok;
 }
 
@@ -363,24 +429,62 @@ bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
     return true;
 }
 
+// Snapshot = header + vec + scal + hist.  The header pins the layout the blob was written with, so a blob from
+// another build (different field lists) or a corrupted one is refused instead of being used as addresses.
+namespace {
+struct SnapshotHeader {
+    uint32_t magic, version, fs, num_vec, num_scal, history, lanes, reserved;
+};
+constexpr uint32_t kSnapshotMagic = 0x53434541u;      // "AECS"
+static_assert(sizeof(SnapshotHeader) == BatchEngine::kStateHeaderBytes, "snapshot header size");
+}  // namespace
+
 bool BatchEngine::ExportState(int stream, void *buf) {
     if (stream < 0 || stream >= num_streams_) return false;
     if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
     uint8_t *p = static_cast<uint8_t *>(buf);
-    return AECM_HIP_OK(hipMemcpy(p, st_.vec + (size_t)stream * kVecWordsPerStream, kVecWordsPerStream * 4, hipMemcpyDeviceToHost)) &&
-           AECM_HIP_OK(hipMemcpy(p + kVecWordsPerStream * 4, st_.scal + (size_t)stream * kNumScal, kNumScal * 4, hipMemcpyDeviceToHost)) &&
-           AECM_HIP_OK(hipMemcpy(p + kVecWordsPerStream * 4 + kNumScal * 4, st_.hist + (size_t)stream * kHistWordsPerStream,
-                                 kHistWordsPerStream * 2, hipMemcpyDeviceToHost));
+    uint8_t *body = p + kStateHeaderBytes;
+    if (!(AECM_HIP_OK(hipMemcpy(body, st_.vec + (size_t)stream * kVecWordsPerStream, kVecWordsPerStream * 4, hipMemcpyDeviceToHost)) &&
+          AECM_HIP_OK(hipMemcpy(body + kVecWordsPerStream * 4, st_.scal + (size_t)stream * kNumScal, kNumScal * 4, hipMemcpyDeviceToHost)) &&
+          AECM_HIP_OK(hipMemcpy(body + kVecWordsPerStream * 4 + kNumScal * 4, st_.hist + (size_t)stream * kHistWordsPerStream,
+                                kHistWordsPerStream * 2, hipMemcpyDeviceToHost))))
+        return false;
+    int32_t mult = 0;
+    memcpy(&mult, body + kVecWordsPerStream * 4 + S_MULT * 4, 4);
+    const SnapshotHeader h{kSnapshotMagic, kStateLayoutVersion, (uint32_t)mult * 8000u, (uint32_t)kNumVec, (uint32_t)kNumScal,
+                           (uint32_t)kHistory, (uint32_t)kLanes, 0u};
+    memcpy(p, &h, sizeof h);
+    return true;
 }
 
-bool BatchEngine::ImportState(int stream, const void *buf) {
-    if (stream < 0 || stream >= num_streams_) return false;
-    if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+// 0, kErrBadParameter (not a snapshot of this layout, or index-like fields out of range) or kErrUnspecified (HIP).
+int32_t BatchEngine::ImportState(int stream, const void *buf) {
+    if (stream < 0 || stream >= num_streams_) return kErrBadParameter;
     const uint8_t *p = static_cast<const uint8_t *>(buf);
-    return AECM_HIP_OK(hipMemcpy(st_.vec + (size_t)stream * kVecWordsPerStream, p, kVecWordsPerStream * 4, hipMemcpyHostToDevice)) &&
-           AECM_HIP_OK(hipMemcpy(st_.scal + (size_t)stream * kNumScal, p + kVecWordsPerStream * 4, kNumScal * 4, hipMemcpyHostToDevice)) &&
-           AECM_HIP_OK(hipMemcpy(st_.hist + (size_t)stream * kHistWordsPerStream, p + kVecWordsPerStream * 4 + kNumScal * 4,
-                                 kHistWordsPerStream * 2, hipMemcpyHostToDevice));
+    SnapshotHeader h;
+    memcpy(&h, p, sizeof h);
+    if (h.magic != kSnapshotMagic || h.version != kStateLayoutVersion || h.num_vec != (uint32_t)kNumVec ||
+        h.num_scal != (uint32_t)kNumScal || h.history != (uint32_t)kHistory || h.lanes != (uint32_t)kLanes ||
+        (h.fs != 8000u && h.fs != 16000u))
+        return kErrBadParameter;
+    const uint8_t *body = p + kStateHeaderBytes;
+    int32_t scal[kNumScal];
+    memcpy(scal, body + kVecWordsPerStream * 4, sizeof scal);
+    // everything the kernel uses as an index or a shift count (aecm_wave.h: hist rows, readlane / writelane lanes)
+    const bool sane = scal[S_MULT] * 8000 == (int32_t)h.fs && scal[S_HISTPOS] >= 0 && scal[S_HISTPOS] <= kHistory &&
+                      scal[S_LAST_DELAY] >= -2 && scal[S_LAST_DELAY] < kHistory && scal[S_FIXED_DELAY] < kHistory &&
+                      scal[S_STARTUP] >= 0 && scal[S_STARTUP] <= 2 && (scal[S_CNG] == 0 || scal[S_CNG] == 1) &&
+                      scal[S_DFANOISYQ] >= 0 && scal[S_DFANOISYQ] <= 15 && scal[S_DFACLEANQ] >= 0 && scal[S_DFACLEANQ] <= 15 &&
+                      scal[S_DFANOISYQ_OLD] >= 0 && scal[S_DFANOISYQ_OLD] <= 15 && scal[S_DFACLEANQ_OLD] >= 0 && scal[S_DFACLEANQ_OLD] <= 15;
+    if (!sane) return kErrBadParameter;
+    if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return kErrUnspecified;
+    if (!(AECM_HIP_OK(hipMemcpy(st_.vec + (size_t)stream * kVecWordsPerStream, body, kVecWordsPerStream * 4, hipMemcpyHostToDevice)) &&
+          AECM_HIP_OK(hipMemcpy(st_.scal + (size_t)stream * kNumScal, body + kVecWordsPerStream * 4, kNumScal * 4, hipMemcpyHostToDevice)) &&
+          AECM_HIP_OK(hipMemcpy(st_.hist + (size_t)stream * kHistWordsPerStream, body + kVecWordsPerStream * 4 + kNumScal * 4,
+                                kHistWordsPerStream * 2, hipMemcpyHostToDevice))))
+        return kErrUnspecified;
+    if ((int)h.fs != fs_) mixed_rates_ = true;       // ProcessRecordings schedules every stream for fs_: refuse until the next Init
+    return 0;
 }
 
 bool BatchEngine::Digest(int stream, uint32_t digest[kDigestWords]) {

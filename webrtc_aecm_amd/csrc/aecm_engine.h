@@ -23,11 +23,15 @@ public:
 
     // All methods return a hipError_t-free status: true on success.
     bool Init(int fs);
+    // Re-initialise streams [first, first + count) only (same rate as the last Init; default config): WebRtcAecm_InitCore
+    // + default set_config for those streams, asynchronous on stream().
+    bool InitStreams(int first, int count);
     bool SetConfig(int cng_mode, int echo_mode, int first, int count);
     bool SetCngMode(int cng_mode, int first, int count);
     bool Control(int fixed_delay, int nlp_flag, int first, int count);
     // async; blocks_per_stream_dev (may be null): per-stream block counts <= num_blocks
     bool ProcessBlocks(const IoView &io_dev, int num_blocks, const int32_t *blocks_per_stream_dev = nullptr);
+    bool ProcessBlocksRange(const IoView &io_dev, int num_blocks, int first, int count, const int32_t *blocks_per_stream_dev);
     bool ProcessBlocksHost(const IoView &io_host, int num_blocks);     // sync
     // Whole recordings as sessions: every stream is driven like a fresh WebRtcAecm_* session by
     // n_calls x (BufferFarend, Process) of `frame` samples with a constant msInSndCardBuf
@@ -44,9 +48,11 @@ public:
     bool SetEchoPath(int stream, const int16_t path[kBins]);
     bool GetEchoPath(int stream, int16_t path[kBins]);
     bool Digest(int stream, uint32_t digest[kDigestWords]);
-    static constexpr size_t kStateBytes = kVecWordsPerStream * 4 + kNumScal * 4 + kHistWordsPerStream * 2;
+    static constexpr size_t kStateHeaderBytes = 32;
+    static constexpr uint32_t kStateLayoutVersion = 2;      // bump whenever aecm_state.h's field lists change
+    static constexpr size_t kStateBytes = kStateHeaderBytes + kVecWordsPerStream * 4 + kNumScal * 4 + kHistWordsPerStream * 2;
     bool ExportState(int stream, void *buf);
-    bool ImportState(int stream, const void *buf);
+    int32_t ImportState(int stream, const void *buf);       // 0 / AECM_BAD_PARAMETER_ERROR / AECM_UNSPECIFIED_ERROR
     void set_variant(int v) { variant_ = v; }
     int variant() const { return variant_; }
     const StatePtrs &state_ptrs() const { return st_; }      // for kernels launched by the session batch on stream()
@@ -54,7 +60,7 @@ public:
 private:
     BatchEngine() = default;
     bool PatchScalars(const int32_t *fields, const int32_t *values, int n, int first, int count);
-    bool FlushTimers();
+    bool FlushTimers() { return HarvestTimers(true); }
 
     int device_ = 0;
     int num_streams_ = 0;
@@ -67,8 +73,13 @@ private:
     uint32_t *image_vec_dev_ = nullptr;
     int32_t *image_scal_dev_ = nullptr;
     int32_t *patch_dev_ = nullptr;       // 2 x 16 ints
-    hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
-    bool timed_pending_ = false;
+    // Launch timing: a small ring of HIP event pairs recorded around every block-kernel launch on stream_.
+    // ProcessBlocks only harvests pairs that have already completed (hipEventQuery) and waits for the oldest
+    // one only when the ring is full, so launches queue back to back; the getters harvest everything.
+    static constexpr int kTimerSlots = 16;
+    hipEvent_t ev_start_[kTimerSlots] = {}, ev_stop_[kTimerSlots] = {};
+    int timer_head_ = 0, timer_pending_ = 0;     // oldest pending slot, number of pending slots
+    bool HarvestTimers(bool wait_all);
     float last_ms_ = 0.f;
     double total_ms_ = 0.0;
     int64_t launches_ = 0;
@@ -77,6 +88,14 @@ private:
     size_t stage_elems_ = 0;
     static constexpr int kHostChunkStreams = 8192;
     bool ProcessBlocksHostPipelined(const IoView &io_host, int num_blocks);
+    // scratch of ProcessRecordings (grow-only; the streams of a batch are processed in chunks that fit it)
+    static constexpr size_t kRecordingScratchBytes = size_t(1) << 30;
+    int32_t *rec_maps_ = nullptr;
+    size_t rec_maps_elems_ = 0;
+    int16_t *rec_scratch_ = nullptr;
+    size_t rec_scratch_elems_ = 0;
+    bool EnsureRecordingScratch(size_t map_elems, size_t sample_elems);
+    bool mixed_rates_ = false;            // ImportState brought in a stream of the other sampling rate
     hipStream_t download_stream_ = nullptr;    // ProcessBlocksHost: downloads overlap the next chunk's uploads
 };
 

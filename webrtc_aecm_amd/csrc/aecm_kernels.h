@@ -116,6 +116,11 @@ hipError_t LaunchTick(const StatePtrs &st, const TickIo &io, int n_streams, int 
 hipError_t LaunchFft128(int16_t *data_dev, int32_t *scales_dev, int variant, int fast, int count, const uint32_t *consts_dev,
                         hipStream_t stream);
 
+// Audit build only (-DAECM_CHECKED): how often a "provably fits" precondition of the block DSP was violated on
+// the device since the last reset -- [0] mul24 operands, [1] as_i16 arguments (aecm_ops.h).  Synchronises the
+// device.  hipErrorNotSupported in the shipped build, whose kernels carry no checks.
+hipError_t ReadCheckCounters(uint64_t counters[2], bool reset);
+
 // Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
 //  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,
 //  6 isqrt31 (exhaustive over [0, 2^31) when exhaustive != 0, else 2^24 samples), 7 table upload.

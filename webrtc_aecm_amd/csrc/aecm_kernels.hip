@@ -18,6 +18,31 @@
 
 namespace aecm {
 
+#if defined(AECM_CHECKED)
+__device__ unsigned long long g_aecm_check_fail[2];
+#endif
+// Audit counters of the -DAECM_CHECKED build (aecm_ops.h); hipErrorNotSupported in the shipped build.
+hipError_t ReadCheckCounters(uint64_t counters[2], bool reset) {
+#if defined(AECM_CHECKED)
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    unsigned long long host[2] = {0, 0};
+    e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_aecm_check_fail), sizeof host);
+    if (e != hipSuccess) return e;
+    counters[0] = host[0];
+    counters[1] = host[1];
+    if (reset) {
+        const unsigned long long zero[2] = {0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_aecm_check_fail), zero, sizeof zero);
+    }
+    return e;
+#else
+    (void)counters;
+    (void)reset;
+    return hipErrorNotSupported;
+#endif
+}
+
 // The LDS tables are an image inside the host-built constants blob: one coalesced copy per workgroup.
 __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
     uint32_t *lds = reinterpret_cast<uint32_t *>(&g_lds[0]);
@@ -30,7 +55,11 @@ __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
 // fast variants need 68 / 71 (no spills).  Measured: 5 -> 6 -> 7 waves = 609 -> 657 -> 674 M frames/s;
 // 8 waves (64 VGPRs) fit without spills under the default scheduler but cost 3 % more instructions: 668 M.
 #ifndef AECM_WAVES_PER_EU
+#if defined(AECM_CHECKED)
+#define AECM_WAVES_PER_EU 4       // the audit build's checks need registers; its speed does not matter
+#else
 #define AECM_WAVES_PER_EU 7
+#endif
 #endif
 template <bool kFast, bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
@@ -105,29 +134,33 @@ hipError_t LaunchPatchScalars(const StatePtrs &st, const int32_t *fields_dev, co
 
 // ---- session-schedule gather / scatter ---------------------------------------------------------------
 
+// One workgroup per (stream, 256-sample tile); the stream index is folded into blockIdx.x (no 65 535 grid.y limit).
 __global__ void aecm_gather_by_map_kernel(const int16_t *src, int64_t src_stride, const int32_t *map, int64_t n,
-                                          int16_t *dst, int64_t dst_stride) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                          int16_t *dst, int64_t dst_stride, unsigned tiles) {
+    const int64_t s = blockIdx.x / tiles;
+    const int64_t j = (int64_t)(blockIdx.x % tiles) * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const int64_t s = blockIdx.y;
     const int32_t m = map[j];
     dst[s * dst_stride + j] = m >= 0 ? src[s * src_stride + m] : (int16_t)0;
 }
 
+// The host side cuts batches so that n_streams * tiles fits a 31-bit grid (aecm_engine.cpp).
 hipError_t LaunchGatherByMap(const int16_t *src, int64_t src_stride, const int32_t *map_dev, int64_t n, int16_t *dst,
                              int64_t dst_stride, int n_streams, hipStream_t stream) {
     if (n <= 0 || n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_gather_by_map_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream, src,
-                       src_stride, map_dev, n, dst, dst_stride);
+    const int64_t tiles = (n + 255) / 256;
+    if (tiles * n_streams > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(aecm_gather_by_map_kernel, dim3((unsigned)(tiles * n_streams)), dim3(256), 0, stream, src,
+                       src_stride, map_dev, n, dst, dst_stride, (unsigned)tiles);
     return hipGetLastError();
 }
 
 __global__ void aecm_assemble_output_kernel(const int16_t *blocks, int64_t blocks_stride, const int16_t *near,
                                             int64_t near_stride, const int32_t *map, int64_t n, int16_t *out,
-                                            int64_t out_stride) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                            int64_t out_stride, unsigned tiles) {
+    const int64_t s = blockIdx.x / tiles;
+    const int64_t j = (int64_t)(blockIdx.x % tiles) * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const int64_t s = blockIdx.y;
     const int32_t v = map[j];
     int16_t r = 0;
     if (v >= 0) r = blocks[s * blocks_stride + v];
@@ -139,8 +172,10 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
                                 const int32_t *map_dev, int64_t n, int16_t *out, int64_t out_stride, int n_streams,
                                 hipStream_t stream) {
     if (n <= 0 || n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_assemble_output_kernel, dim3((unsigned)((n + 255) / 256), n_streams), dim3(256), 0, stream,
-                       blocks, blocks_stride, near, near_stride, map_dev, n, out, out_stride);
+    const int64_t tiles = (n + 255) / 256;
+    if (tiles * n_streams > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(aecm_assemble_output_kernel, dim3((unsigned)(tiles * n_streams)), dim3(256), 0, stream,
+                       blocks, blocks_stride, near, near_stride, map_dev, n, out, out_stride, (unsigned)tiles);
     return hipGetLastError();
 }
 
@@ -302,6 +337,9 @@ hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const
 }
 
 // ---- fused tick -------------------------------------------------------------------------------------
+#if defined(AECM_CHECKED) && !defined(AECM_TICK_WAVES_PER_EU)
+#define AECM_TICK_WAVES_PER_EU 4
+#endif
 #ifndef AECM_TICK_WAVES_PER_EU
 #define AECM_TICK_WAVES_PER_EU 6      // the coded I/O needs a few more registers than the strided one: 7 waves would spill
 #endif

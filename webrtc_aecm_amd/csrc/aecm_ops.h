@@ -60,9 +60,20 @@ AECM_HD int divu(int a, int b) { return b == 0 ? -1 : (int)((unsigned)a / (unsig
 // precondition (the CPU lane simulator runs every test input through it).
 #if !defined(__HIP_DEVICE_COMPILE__)
 [[noreturn]] void aecm_mul24_range_violation(int a, int b);
+#elif defined(AECM_CHECKED)
+// Audit build (-DAECM_CHECKED, libaecm_mi355x_checked.so; never the shipped kernel): the device counts violated
+// preconditions instead of assuming them, and computes the exact result so that parity still holds.
+// [0] mul24 operand outside 24 signed bits, [1] as_i16 argument outside int16.
+extern __device__ unsigned long long g_aecm_check_fail[2];
 #endif
 AECM_HD int mul24(int a, int b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AECM_CHECKED)
+    if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) {
+        atomicAdd(&g_aecm_check_fail[0], 1ull);
+        return mul(a, b);
+    }
+    return __mul24(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
     return __mul24(a, b);
 #else
     if (a < -(1 << 23) || a >= (1 << 23) || b < -(1 << 23) || b >= (1 << 23)) aecm_mul24_range_violation(a, b);
@@ -79,6 +90,11 @@ AECM_HD int mul24(int a, int b) {
 AECM_HD int as_i16(int v) {
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (v < -32768 || v > 32767) aecm_i16_range_violation(v);
+#elif defined(AECM_CHECKED)
+    if (v < -32768 || v > 32767) {
+        atomicAdd(&g_aecm_check_fail[1], 1ull);
+        return sext16(v);                                 // what the reference's (int16_t) cast does
+    }
 #endif
     return v;
 }

@@ -31,7 +31,7 @@ constexpr int kSampMsNb = 8;                  // samples per ms, narrowband (:37
 constexpr short kInitCheck = 42;              // (:40)
 
 // Return codes of the ABI (echo_control_mobile.h:23-30), kept numeric here to stay header-only.
-constexpr int32_t kErrUnspecified = 12000, kErrUninitialized = 12002, kErrNullPointer = 12003,
+constexpr int32_t kErrUnspecified = 12000, kErrUnsupported = 12001, kErrUninitialized = 12002, kErrNullPointer = 12003,
                   kErrBadParameter = 12004, kWarnBadParameter = 12100;
 
 // FIFO with the read-pointer semantics of the reference ring buffer (aecm/ring_buffer.c:97-211):

@@ -61,17 +61,100 @@ int32_t SessionBatch::Init(int32_t samp_freq) {
         (clean_ring_ && !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, engine_->stream()))))
         return AECM_UNSPECIFIED_ERROR;
     near_pos_ = 0;
+    tick_count_ = 0;
+    fs_ = samp_freq;
+    poisoned_ = false;
     classes_.clear();
     classes_.emplace_back();                      // every session starts in one class
     classes_[0].members = S;
     class_of_.assign((size_t)S, 0);
-    last_ms_.clear();
+    last_key_.clear();
     class_of_dirty_ = true;
     return classes_[0].flow.Init(samp_freq);
 }
 
+int32_t SessionBatch::CheckSession(int session) const {
+    if (classes_.empty() || !classes_[0].flow.initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (poisoned_) return AECM_UNSPECIFIED_ERROR;
+    if (session < 0 || session >= engine_->num_streams()) return AECM_BAD_PARAMETER_ERROR;
+    return 0;
+}
+
+void SessionBatch::DropEmptyClasses() {
+    std::vector<int32_t> remap(classes_.size(), -1);
+    std::vector<FlowClass> kept;
+    for (size_t k = 0; k < classes_.size(); ++k)
+        if (classes_[k].members > 0) {
+            remap[k] = (int32_t)kept.size();
+            kept.push_back(std::move(classes_[k]));
+        }
+    if (kept.size() == classes_.size()) return;
+    classes_.swap(kept);
+    for (int32_t &c : class_of_) c = remap[c];
+    class_of_dirty_ = true;
+}
+
+// WebRtcAecm_Init of ONE session (same sampling rate as the batch): fresh core state on the device, fresh
+// session flow on the host.  Sessions re-initialised between the same two ticks share one flow class.  The
+// session's device rings need no clearing: a fresh flow only ever refers to samples appended after its birth
+// (its far / output tags restart at 0), everything older reads as "never written" = 0.
+int32_t SessionBatch::InitSession(int session) {
+    if (int32_t rc = CheckSession(session)) return rc;
+    int32_t id = -1;
+    for (size_t k = 0; k < classes_.size(); ++k)
+        if (classes_[k].born == tick_count_ && classes_[k].far_count == 0 && classes_[k].blocks_done == 0) { id = (int32_t)k; break; }
+    if (id < 0) {
+        if ((int)classes_.size() >= kMaxFlowClasses) return AECM_UNSUPPORTED_FUNCTION_ERROR;
+        classes_.emplace_back();
+        id = (int32_t)classes_.size() - 1;
+        classes_[id].born = tick_count_;
+        if (int32_t rc = classes_[id].flow.Init(fs_)) return rc;
+    }
+    if (!engine_->InitStreams(session, 1)) { poisoned_ = true; return AECM_UNSPECIFIED_ERROR; }
+    const int32_t old = class_of_[(size_t)session];
+    if (old != id) {
+        classes_[old].members--;
+        classes_[id].members++;
+        class_of_[(size_t)session] = id;
+        class_of_dirty_ = true;
+        last_key_.clear();
+        DropEmptyClasses();
+    }
+    return 0;
+}
+
+int32_t SessionBatch::SetConfigSession(int session, int16_t cng_mode, int16_t echo_mode) {
+    if (int32_t rc = CheckSession(session)) return rc;
+    if (cng_mode != AecmFalse && cng_mode != AecmTrue) return AECM_BAD_PARAMETER_ERROR;
+    if (echo_mode < 0 || echo_mode > 4) {                    // the reference commits cngMode before it rejects echoMode (:421-428)
+        if (!engine_->SetCngMode(cng_mode, session, 1)) return AECM_UNSPECIFIED_ERROR;
+        return AECM_BAD_PARAMETER_ERROR;
+    }
+    return engine_->SetConfig(cng_mode, echo_mode, session, 1) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t SessionBatch::InitEchoPathSession(int session, const void *path, size_t size_bytes) {
+    if (path == nullptr) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes != kBins * sizeof(int16_t)) return AECM_BAD_PARAMETER_ERROR;
+    if (int32_t rc = CheckSession(session)) return rc;
+    int16_t tmp[kBins];
+    memcpy(tmp, path, sizeof tmp);
+    return engine_->SetEchoPath(session, tmp) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t SessionBatch::GetEchoPathSession(int session, void *path, size_t size_bytes) {
+    if (path == nullptr) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes != kBins * sizeof(int16_t)) return AECM_BAD_PARAMETER_ERROR;
+    if (int32_t rc = CheckSession(session)) return rc;
+    int16_t tmp[kBins];
+    if (!engine_->GetEchoPath(session, tmp)) return AECM_UNSPECIFIED_ERROR;
+    memcpy(path, tmp, sizeof tmp);
+    return 0;
+}
+
 int32_t SessionBatch::SetConfig(int16_t cng_mode, int16_t echo_mode) {
     if (classes_.empty() || !classes_[0].flow.initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (poisoned_) return AECM_UNSPECIFIED_ERROR;
     if (cng_mode != AecmFalse && cng_mode != AecmTrue) return AECM_BAD_PARAMETER_ERROR;
     if (echo_mode < 0 || echo_mode > 4) {
         if (!engine_->SetCngMode(cng_mode, 0, -1)) return AECM_UNSPECIFIED_ERROR;
@@ -87,34 +170,41 @@ bool SessionBatch::FusedTick(int num_streams) {
     return forced >= 0 ? forced != 0 : num_streams < 32768;
 }
 
-// Give every session the class that matches (its previous class, its msInSndCardBuf of this tick).
-int32_t SessionBatch::Regroup(const int16_t *ms_per_session) {
+// Give every session the class that matches (its previous class, its msInSndCardBuf and far-end flag of this tick).
+int32_t SessionBatch::Regroup(const int16_t *ms_per_session, int16_t ms_uniform, const uint8_t *flags_per_session) {
     const size_t S = class_of_.size();
-    if (last_ms_.size() == S && memcmp(last_ms_.data(), ms_per_session, S * sizeof(int16_t)) == 0) return 0;   // same grouping as last tick
-    struct Child { int16_t ms; int32_t id; };
+    std::vector<int32_t> key(S);
+    for (size_t s = 0; s < S; ++s) {
+        const int32_t ms = (uint16_t)(ms_per_session ? ms_per_session[s] : ms_uniform);
+        key[s] = ms | (flags_per_session && (flags_per_session[s] & kNoFarend) ? 1 << 16 : 0);
+    }
+    if (last_key_ == key) {                                                     // same grouping as last tick
+        return 0;
+    }
+    struct Child { int32_t key; int32_t id; };
     std::vector<std::vector<Child>> children(classes_.size());
     std::vector<FlowClass> next;
     std::vector<int32_t> next_class_of(S);
     for (size_t s = 0; s < S; ++s) {
         const int32_t old = class_of_[s];
-        const int16_t ms = ms_per_session[s];
         int32_t id = -1;
         for (const Child &c : children[old])
-            if (c.ms == ms) { id = c.id; break; }
+            if (c.key == key[s]) { id = c.id; break; }
         if (id < 0) {
             if ((int)next.size() >= kMaxFlowClasses) return AECM_UNSUPPORTED_FUNCTION_ERROR;
             id = (int32_t)next.size();
             next.push_back(classes_[old]);           // the flow state before this tick
-            next.back().ms = ms;
+            next.back().ms = (int16_t)(uint16_t)(key[s] & 0xffff);
+            next.back().no_far = (key[s] >> 16) != 0;
             next.back().members = 0;
-            children[old].push_back({ms, id});
+            children[old].push_back({key[s], id});
         }
         next[id].members++;
         next_class_of[s] = id;
     }
     classes_.swap(next);
     class_of_.swap(next_class_of);
-    last_ms_.assign(ms_per_session, ms_per_session + S);
+    last_key_.swap(key);
     class_of_dirty_ = true;
     return 0;
 }
@@ -132,11 +222,14 @@ int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClas
     entry->far_pos = c.far_count;
     entry->out_pos = c.blocks_done * kBlock;
     for (int i = 0; i < n; ++i) entry->assemble.out[i] = -1;
-    int32_t rc = c.flow.BufferFarend(far_tags, (size_t)n);
-    if (rc != 0) return rc;
+    int32_t rc = 0;
     const int64_t far_first = c.far_count;
-    entry->n_far = (int32_t)c.flow.last_far_accepted();
-    c.far_count += entry->n_far;
+    if (!c.no_far) {                                       // far-end underrun: no BufferFarend call in this tick
+        rc = c.flow.BufferFarend(far_tags, (size_t)n);
+        if (rc != 0) return rc;
+        entry->n_far = (int32_t)c.flow.last_far_accepted();
+        c.far_count += entry->n_far;
+    }
     int64_t blk_far[kTickMaxBlockSamples], blk_near[kTickMaxBlockSamples];
     int n_blocks = 0;
     bool passthrough = false;
@@ -177,11 +270,15 @@ int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClas
     return rc;
 }
 
-int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, int n,
-                           int16_t ms, const int16_t *ms_per_session, int32_t *codes, bool host_pointers) {
+int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
+                           int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
+                           bool host_pointers) {
     if (far == nullptr || near == nullptr || out == nullptr) return AECM_NULL_POINTER_ERROR;
     if (classes_.empty() || !classes_[0].flow.initialized()) return AECM_UNINITIALIZED_ERROR;
-    if (n != 80 && n != 160) return AECM_BAD_PARAMETER_ERROR;
+    if (n_samples != 80 && n_samples != 160) return AECM_BAD_PARAMETER_ERROR;       // compared as size_t: 2^32 + 80 is not 80
+    if (stride < (int64_t)n_samples) return AECM_BAD_PARAMETER_ERROR;
+    if (poisoned_) return AECM_UNSPECIFIED_ERROR;
+    const int n = (int)n_samples;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
     hipStream_t st = engine_->stream();
@@ -191,11 +288,11 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
             return AECM_UNSPECIFIED_ERROR;
     }
     // 1. which class every session is in for this tick
-    if (ms_per_session) {
-        if (int32_t rc = Regroup(ms_per_session)) return rc;
+    if (ms_per_session || flags_per_session) {
+        if (int32_t rc = Regroup(ms_per_session, ms, flags_per_session)) return rc;
     } else {
-        for (FlowClass &c : classes_) c.ms = ms;
-        last_ms_.clear();
+        for (FlowClass &c : classes_) { c.ms = ms; c.no_far = false; }
+        last_key_.clear();
     }
     const int n_classes = (int)classes_.size();
     // 2. the session machinery of every class in the index domain (the table is read by the previous tick's
@@ -208,7 +305,14 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         if (class_rc[k] != 0 && first_rc == 0) first_rc = class_rc[k];
         max_nbs = std::max(max_nbs, table_host_[k].n_block_samples);
     }
-    if (stale) return AECM_UNSPECIFIED_ERROR;
+    // From here on the host-side flows have advanced: a failure leaves them out of step with the device rings,
+    // so it poisons the object (every later call is refused until Init) instead of silently corrupting audio.
+    auto fail = [&]() -> int32_t {
+        poisoned_ = true;
+        (void)hipStreamSynchronize(st);              // async copies from caller / pinned memory may still be in flight
+        return AECM_UNSPECIFIED_ERROR;
+    };
+    if (stale) return fail();
     if (codes)
         for (int s = 0; s < S; ++s) codes[s] = class_rc[class_of_[s]];
     // 3. device side of the tick: prepare -> blocks -> finish
@@ -221,7 +325,7 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         if (!AECM_HIP_OK(hipMemcpy2DAsync(f, 320, far, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
             !AECM_HIP_OK(hipMemcpy2DAsync(d, 320, near, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
             (clean && !AECM_HIP_OK(hipMemcpy2DAsync(c, 320, clean, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st))))
-            return AECM_UNSPECIFIED_ERROR;
+            return fail();
         dfar = f;
         dnear = d;
         dout = io_dev_ + 2 * (size_t)S * 160;
@@ -274,11 +378,12 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         }
     }
     near_pos_ += n;
-    if (!ok) return AECM_UNSPECIFIED_ERROR;
+    tick_count_ += 1;
+    if (!ok) return fail();
     if (host_pointers &&
         !AECM_HIP_OK(hipMemcpy2DAsync(out, stride * 2, dout, 320, (size_t)n * 2, S, hipMemcpyDeviceToHost, st)))
-        return AECM_UNSPECIFIED_ERROR;
-    if (!AECM_HIP_OK(hipStreamSynchronize(st))) return AECM_UNSPECIFIED_ERROR;
+        return fail();
+    if (!AECM_HIP_OK(hipStreamSynchronize(st))) return fail();
     return first_rc;
 }
 

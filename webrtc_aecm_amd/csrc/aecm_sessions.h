@@ -34,6 +34,12 @@ public:
 
     int32_t Init(int32_t samp_freq);
     int32_t SetConfig(int16_t cng_mode, int16_t echo_mode);
+    // Per-session control (a media server recycling one slot while the others keep running), reference
+    // echo_control_mobile.cc:142-191 (WebRtcAecm_Init), :410-479 (set_config), :481-532 (Init/GetEchoPath).
+    int32_t InitSession(int session);
+    int32_t SetConfigSession(int session, int16_t cng_mode, int16_t echo_mode);
+    int32_t InitEchoPathSession(int session, const void *path, size_t size_bytes);
+    int32_t GetEchoPathSession(int session, void *path, size_t size_bytes);
     // One tick for every session; far/near/clean/out are [S][>= n] with the given stream stride, device
     // or host pointers; clean (WebRtcAecm_Process's nearendClean) may be null.
     //   ms_per_session == nullptr: every session gets `ms`; the return value is the code each session's
@@ -41,8 +47,12 @@ public:
     //   ms_per_session != nullptr (host array, S entries): session s gets ms_per_session[s]; codes (host,
     //     S entries, may be null) receives each session's code, the return value is 0 or the first
     //     non-zero code.
-    int32_t Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, int n,
-                 int16_t ms, const int16_t *ms_per_session, int32_t *codes, bool host_pointers);
+    //   flags_per_session (host array, S entries, may be null): bit 0 (kNoFarend) = this session gets NO
+    //     WebRtcAecm_BufferFarend call in this tick (far-end underrun: its Process replays the last far frame,
+    //     reference echo_control_mobile.cc:369-380); its far row is ignored.
+    int32_t Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
+                 int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers);
+    static constexpr uint8_t kNoFarend = 1;
     int num_flow_classes() const { return (int)classes_.size(); }
 
     static constexpr int kMaxFlowClasses = 1024;
@@ -55,18 +65,27 @@ private:
         int64_t blocks_done = 0;
         int64_t far_count = 0;   // far samples its jitter buffer has accepted so far = the next far tag
         int16_t ms = 0;          // this tick's msInSndCardBuf
+        bool no_far = false;     // this tick: no BufferFarend call
+        int64_t born = -1;       // tick at which InitSession created it (-1: from Init); fresh sessions of one tick share a class
         int32_t members = 0;
         FlowClass() : flow(-1) {}
     };
     SessionBatch() {}
     static bool FusedTick(int num_streams);
-    int32_t Regroup(const int16_t *ms_per_session);
+    int32_t Regroup(const int16_t *ms_per_session, int16_t ms_uniform, const uint8_t *flags_per_session);
+    void DropEmptyClasses();
+    int32_t CheckSession(int session) const;
     int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, bool *stale);
     static constexpr int64_t kRing = 8192;     // >= 4000 (jitter buffer) + 160 + 144 + stale re-reads; power of two
     std::unique_ptr<BatchEngine> engine_;
     std::vector<FlowClass> classes_;
     std::vector<int32_t> class_of_;            // host copy, [S]
-    std::vector<int16_t> last_ms_;             // per-session values of the previous per-session tick
+    std::vector<int32_t> last_key_;            // per-session (ms | flags << 16) of the previous per-session tick
+    int64_t tick_count_ = 0;
+    int fs_ = 0;
+    // A tick that failed after the host-side flows advanced leaves them out of step with the device rings:
+    // every later call is refused (AECM_UNSPECIFIED_ERROR) until Init.
+    bool poisoned_ = false;
     bool class_of_dirty_ = false;
     int64_t near_pos_ = 0;
     int16_t *far_ring_ = nullptr, *near_ring_ = nullptr, *out_ring_ = nullptr;   // [S][kRing]

@@ -4,6 +4,8 @@ only to line the ranks up for timing and to gather a handful of throughput count
 from __future__ import annotations
 
 import os
+import socket
+import sys
 
 import torch
 import torch.distributed as dist
@@ -19,6 +21,26 @@ def shard_range(total: int, rank: int, world: int):
 
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(script: str, argv, n_ranks: int):
+    """`python script --gpus N` started by hand (no WORLD_SIZE in the environment): replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... script argv` -- one rank per GPU of
+    this node, rendezvous on 127.0.0.1.  Does not return."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def init(backend: str):
@@ -41,11 +63,19 @@ def barrier(device_index=None):
 
 
 def gather_counters(frames: int, seconds: float, kernel_ms: float, device):
-    """Whole-job counters: (sum of frames, max of wall seconds, max of kernel ms) over ranks."""
+    """Whole-job counters over the ranks (the only collective traffic of a run):
+    returns dict(frames = sum, seconds = max, kernel_ms = max, ranks_seen = all-reduce of 1 per rank,
+    per_rank = [(frames, seconds, kernel_ms)] in rank order)."""
     if not dist.is_initialized():
-        return int(frames), float(seconds), float(kernel_ms)
-    s = torch.tensor([float(frames)], dtype=torch.float64, device=device)
-    m = torch.tensor([float(seconds), float(kernel_ms)], dtype=torch.float64, device=device)
-    dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    return int(round(s.item())), float(m[0].item()), float(m[1].item())
+        return dict(frames=int(frames), seconds=float(seconds), kernel_ms=float(kernel_ms), ranks_seen=1,
+                    per_rank=[(int(frames), float(seconds), float(kernel_ms))], backend=None)
+    world = dist.get_world_size()
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)                       # proves every rank took part in the collective
+    mine = torch.tensor([float(frames), float(seconds), float(kernel_ms)], dtype=torch.float64, device=device)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    per_rank = [(int(round(r[0].item())), float(r[1].item()), float(r[2].item())) for r in rows]
+    return dict(frames=sum(p[0] for p in per_rank), seconds=max(p[1] for p in per_rank),
+                kernel_ms=max(p[2] for p in per_rank), ranks_seen=int(one.item()), per_rank=per_rank,
+                backend=dist.get_backend())

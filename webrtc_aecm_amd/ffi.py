@@ -40,13 +40,16 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
     "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
-    "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo",
+    "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
 ]
 SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_Create", "WebRtcAecmSessions_Free", "WebRtcAecmSessions_Init", "WebRtcAecmSessions_set_config",
     "WebRtcAecmSessions_Tick", "WebRtcAecmSessions_TickHost", "WebRtcAecmSessions_TickPerSession",
-    "WebRtcAecmSessions_TickPerSessionHost", "WebRtcAecmSessions_num_flow_classes",
+    "WebRtcAecmSessions_TickPerSessionHost", "WebRtcAecmSessions_TickFlags", "WebRtcAecmSessions_TickFlagsHost",
+    "WebRtcAecmSessions_InitSession", "WebRtcAecmSessions_set_config_session", "WebRtcAecmSessions_InitEchoPath",
+    "WebRtcAecmSessions_GetEchoPath", "WebRtcAecmSessions_num_flow_classes",
 ]
+SESSION_NO_FAREND = 1
 
 
 class AecmConfig(C.Structure):
@@ -57,7 +60,8 @@ _lib = None
 
 
 def library_path() -> Path:
-    return _build.LIB
+    """The library load() binds: $AECM_LIB_PATH (kernel A/B experiments) or the in-tree build."""
+    return Path(os.environ["AECM_LIB_PATH"]) if os.environ.get("AECM_LIB_PATH") else _build.LIB
 
 
 def load():
@@ -121,7 +125,14 @@ def load():
     lib.WebRtcAecmSessions_TickHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16]
     lib.WebRtcAecmSessions_TickPerSession.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, vp, vp]
     lib.WebRtcAecmSessions_TickPerSessionHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, vp, vp]
+    lib.WebRtcAecmSessions_TickFlags.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, vp, vp, vp]
+    lib.WebRtcAecmSessions_TickFlagsHost.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, vp, vp, vp]
+    lib.WebRtcAecmSessions_InitSession.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmSessions_set_config_session.argtypes = [vp, C.c_int32, AecmConfig]
+    lib.WebRtcAecmSessions_InitEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmSessions_GetEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmSessions_num_flow_classes.argtypes = [vp]
+    lib.WebRtcAecmBatch_GetCheckCounters.argtypes = [C.c_int32, vp, C.c_int32]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
     lib.WebRtcAecmBatch_DebugFft128.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DeviceInfo.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -244,6 +255,7 @@ class AecmBatch:
         cp = None
         if clean is not None:
             clean = np.ascontiguousarray(clean, dtype=np.int16)
+            assert clean.shape == near.shape, "clean must have the shape of near"
             cp = clean.ctypes.data
         t = far.shape[1] // BLOCK
         self._check(self.lib.WebRtcAecmBatch_ProcessBlocksHost(self.h, far.ctypes.data, near.ctypes.data, cp,
@@ -345,14 +357,25 @@ class AecmSessions:
         if rc != 0:
             raise AecmError(rc, "WebRtcAecmSessions_set_config")
 
-    def tick_host(self, far, near, ms: int = 40, clean=None):
-        """far/near(/clean): [S, n] int16 (n = 80 or 160).  Returns (code, out)."""
+    def _rows(self, far, near, clean):
+        """Validated contiguous [S, n] int16 rows (the C side strides by far.shape[1] and reads S rows)."""
         far = np.ascontiguousarray(far, dtype=np.int16)
         near = np.ascontiguousarray(near, dtype=np.int16)
+        if far.ndim != 2 or far.shape[0] != self.num_streams or far.shape[1] not in (80, 160):
+            raise ValueError(f"far must be [{self.num_streams}, 80 or 160] int16, got {far.shape}")
+        if near.shape != far.shape:
+            raise ValueError(f"near {near.shape} must have the shape of far {far.shape}")
         cptr = None
         if clean is not None:
             clean = np.ascontiguousarray(clean, dtype=np.int16)
+            if clean.shape != far.shape:
+                raise ValueError(f"clean {clean.shape} must have the shape of far {far.shape}")
             cptr = clean.ctypes.data
+        return far, near, clean, cptr
+
+    def tick_host(self, far, near, ms: int = 40, clean=None):
+        """far/near(/clean): [S, n] int16 (n = 80 or 160).  Returns (code, out)."""
+        far, near, clean, cptr = self._rows(far, near, clean)
         out = np.empty_like(near)
         rc = self.lib.WebRtcAecmSessions_TickHost(self.h, far.ctypes.data, near.ctypes.data, cptr, out.ctypes.data, far.shape[1],
                                                   far.shape[1], ms)
@@ -361,24 +384,46 @@ class AecmSessions:
     def tick_device(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms=40, clean_ptr=None):
         return self.lib.WebRtcAecmSessions_Tick(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n, ms)
 
-    def tick_host_per_session(self, far, near, ms_per_session, clean=None):
-        """far/near(/clean): [S, n] int16; ms_per_session: S msInSndCardBuf values.  Returns (code, out, codes[S])."""
-        far = np.ascontiguousarray(far, dtype=np.int16)
-        near = np.ascontiguousarray(near, dtype=np.int16)
+    def tick_host_per_session(self, far, near, ms_per_session, clean=None, flags=None):
+        """far/near(/clean): [S, n] int16; ms_per_session: S msInSndCardBuf values; flags: S uint8 (SESSION_NO_FAREND)
+        or None.  Returns (code, out, codes[S])."""
+        far, near, clean, cptr = self._rows(far, near, clean)
         ms = np.ascontiguousarray(ms_per_session, dtype=np.int16)
-        assert ms.shape == (far.shape[0],)
-        cptr = None
-        if clean is not None:
-            clean = np.ascontiguousarray(clean, dtype=np.int16)
-            cptr = clean.ctypes.data
+        if ms.shape != (self.num_streams,):
+            raise ValueError("ms_per_session must have one entry per session")
         out = np.empty_like(near)
         codes = np.zeros(far.shape[0], dtype=np.int32)
-        rc = self.lib.WebRtcAecmSessions_TickPerSessionHost(self.h, far.ctypes.data, near.ctypes.data, cptr, out.ctypes.data,
-                                                            far.shape[1], far.shape[1], ms.ctypes.data, codes.ctypes.data)
+        if flags is None:
+            rc = self.lib.WebRtcAecmSessions_TickPerSessionHost(self.h, far.ctypes.data, near.ctypes.data, cptr, out.ctypes.data,
+                                                                far.shape[1], far.shape[1], ms.ctypes.data, codes.ctypes.data)
+        else:
+            fl = np.ascontiguousarray(flags, dtype=np.uint8)
+            if fl.shape != (self.num_streams,):
+                raise ValueError("flags must have one entry per session")
+            rc = self.lib.WebRtcAecmSessions_TickFlagsHost(self.h, far.ctypes.data, near.ctypes.data, cptr, out.ctypes.data,
+                                                           far.shape[1], far.shape[1], ms.ctypes.data, fl.ctypes.data,
+                                                           codes.ctypes.data)
         return rc, out, codes
+
+    def init_session(self, session: int) -> int:
+        return self.lib.WebRtcAecmSessions_InitSession(self.h, session)
+
+    def set_config_session(self, session: int, cng_mode: int, echo_mode: int) -> int:
+        return self.lib.WebRtcAecmSessions_set_config_session(self.h, session, AecmConfig(cng_mode, echo_mode))
+
+    def init_echo_path(self, session: int, path) -> int:
+        a, p = _i16(path)
+        return self.lib.WebRtcAecmSessions_InitEchoPath(self.h, session, p, a.nbytes)
+
+    def get_echo_path(self, session: int):
+        out = np.zeros(BINS, dtype=np.int16)
+        rc = self.lib.WebRtcAecmSessions_GetEchoPath(self.h, session, out.ctypes.data, out.nbytes)
+        return rc, out
 
     def tick_device_per_session(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms_per_session, clean_ptr=None):
         ms = np.ascontiguousarray(ms_per_session, dtype=np.int16)
+        if ms.shape != (self.num_streams,):
+            raise ValueError("ms_per_session must have one entry per session")
         return self.lib.WebRtcAecmSessions_TickPerSession(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n,
                                                           ms.ctypes.data, None)
 
@@ -405,6 +450,17 @@ def self_test(device: int = 0, exhaustive: bool = False):
     if rc != 0:
         raise AecmError(rc, "WebRtcAecmBatch_SelfTest")
     return f
+
+
+def check_counters(device: int = 0, reset: bool = False):
+    """Precondition-violation counters of the audit build (AECM_LIB_PATH=.../libaecm_mi355x_checked.so):
+    [mul24 operands, as_i16 arguments].  Raises AecmError(12001) on the shipped library."""
+    lib = load()
+    c = np.zeros(2, dtype=np.uint64)
+    rc = lib.WebRtcAecmBatch_GetCheckCounters(device, c.ctypes.data, 1 if reset else 0)
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_GetCheckCounters")
+    return c
 
 
 def debug_fft128(re, im, variant: int, kernel_variant: int = KERNEL_FAST, device: int = 0):
