@@ -15,10 +15,13 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "webrtc_aecm_amd" / "csrc"
+FAST_CLASS = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32",
+              "v_ashrrev_i32", "v_mov_b32"}          # the ~2.3-cycle class of the issue-rate micro-benchmark (VGPR / constant operands only)
+SLOW8 = {"v_permlane32_swap_b32", "v_permlane16_swap_b32", "v_sqrt_f32"}
 PHASES = {0: "load+prefetch", 1: "far window+FFT+mag", 2: "near window+FFT+mag", 3: "far history/binary far",
           4: "binary near + delay estimator", 5: "aligned far fetch", 6: "energies/VAD", 7: "NLMS channel update",
           8: "store/restore + supgain + Wiener", 9: "NLP + comfort noise prep", 10: "comfort noise",
-          11: "IFFT", 12: "synthesis + store", 13: "loop tail"}
+          11: "IFFT", 12: "synthesis + store", 13: "output store + loop control", 14: "(after the loop: state store)", 15: "(epilogue)"}
 
 
 def classify(op):
@@ -40,6 +43,10 @@ def main():
     ap.add_argument("--kernel", default="aecm_process_kernelILb1ELb0EE")
     ap.add_argument("--dump")
     ap.add_argument("--extra", default="", help="extra hipcc flags")
+    ap.add_argument("--hot", action="store_true",
+                    help="-DAECM_CENSUS_HOTPATH: steady-state-unreachable branches compiled out, so the block loop is the straight-line "
+                         "hot path and its static count approximates the dynamic mix; also prints the fast-class share per phase")
+    ap.add_argument("--json", help="write the per-phase counts here")
     a = ap.parse_args()
     sys.path.insert(0, str(ROOT))
     from webrtc_aecm_amd import build as B
@@ -47,7 +54,7 @@ def main():
         ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "k.s"
-        cmd = ["/opt/rocm/bin/hipcc", *flags, *a.extra.split(), "-DAECM_MARKERS", "-S", "--cuda-device-only",
+        cmd = ["/opt/rocm/bin/hipcc", *flags, *a.extra.split(), *(["-DAECM_CENSUS_HOTPATH"] if a.hot else []), "-DAECM_MARKERS", "-S", "--cuda-device-only",
                f"-I{CSRC}", str(CSRC / "aecm_kernels.hip"), "-o", str(out)]
         subprocess.check_call(cmd)
         text = out.read_text()
@@ -77,13 +84,30 @@ def main():
         op = s.split()[0]
         counts.setdefault(cur, collections.Counter())[classify(op)] += 1
         counts[cur]["op:" + op] += 1
+        base = op
+        for suf in ("_e32", "_e64"):
+            if base.endswith(suf):
+                base = base[:-4]
+        operands = s.split(None, 1)[1] if len(s.split(None, 1)) > 1 else ""
+        srcs = [x.strip() for x in operands.split(",")[1:]]
+        if base in FAST_CLASS and not op.endswith(("_dpp", "_sdwa")) and not any(x.startswith(("s", "vcc", "exec", "m0", "ttmp")) for x in srcs):
+            counts[cur]["VALU_fast"] += 1
+        if base in SLOW8:
+            counts[cur]["VALU_8cyc"] += 1
     tot = collections.Counter()
-    print(f"{'phase (code after marker n-1)':44s} {'VALU':>6s} {'SALU':>6s} {'LDS':>5s} {'VMEM':>5s}")
+    print(f"{'phase (code after marker n-1)':44s} {'VALU':>6s} {'fast':>5s} {'8cyc':>5s} {'SALU':>6s} {'SCTL':>5s} {'LDS':>5s} {'VMEM':>5s}")
     for ph, c in counts.items():
-        print(f"{ph:2d} {PHASES.get(ph, '?'):41s} {c['VALU']:6d} {c['SALU']:6d} {c['LDS']:5d} {c['VMEM']:5d}")
-        for k in ("VALU", "SALU", "LDS", "VMEM"):
-            tot[k] += c[k]
-    print(f"{'total (all textual code after first marker)':44s} {tot['VALU']:6d} {tot['SALU']:6d} {tot['LDS']:5d} {tot['VMEM']:5d}")
+        print(f"{ph:2d} {PHASES.get(ph, '?'):41s} {c['VALU']:6d} {c['VALU_fast']:5d} {c['VALU_8cyc']:5d} {c['SALU']:6d} {c['SCTL']:5d} {c['LDS']:5d} {c['VMEM']:5d}")
+        if ph <= 13:
+            for k in ("VALU", "VALU_fast", "VALU_8cyc", "SALU", "SCTL", "LDS", "VMEM"):
+                tot[k] += c[k]
+    print(f"{'block loop (phases 1..13)':44s} {tot['VALU']:6d} {tot['VALU_fast']:5d} {tot['VALU_8cyc']:5d} {tot['SALU']:6d} {tot['SCTL']:5d} {tot['LDS']:5d} {tot['VMEM']:5d}")
+    if a.json:
+        import json
+        Path(a.json).write_text(json.dumps({"hot": a.hot, "kernel": a.kernel, "loop_total": dict(tot),
+                                            "phases": {str(ph): {"name": PHASES.get(ph, "?"), **{k: v for k, v in c.items() if not k.startswith("op:")},
+                                                                 "top_ops": dict(collections.Counter({k[3:]: v for k, v in c.items() if k.startswith("op:")}).most_common(12))}
+                                                       for ph, c in counts.items()}}, indent=1))
     return counts
 
 

@@ -81,6 +81,9 @@ int32_t SessionBatch::CheckSession(int session) const {
 }
 
 void SessionBatch::DropEmptyClasses() {
+    bool any_empty = false;
+    for (const FlowClass &c : classes_) any_empty = any_empty || c.members <= 0;
+    if (!any_empty) return;
     std::vector<int32_t> remap(classes_.size(), -1);
     std::vector<FlowClass> kept;
     for (size_t k = 0; k < classes_.size(); ++k)
@@ -88,7 +91,6 @@ void SessionBatch::DropEmptyClasses() {
             remap[k] = (int32_t)kept.size();
             kept.push_back(std::move(classes_[k]));
         }
-    if (kept.size() == classes_.size()) return;
     classes_.swap(kept);
     for (int32_t &c : class_of_) c = remap[c];
     class_of_dirty_ = true;

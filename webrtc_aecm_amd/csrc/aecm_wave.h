@@ -47,6 +47,18 @@
 #define AECM_LIKELY(c) (c)
 #endif
 
+// Census builds (-DAECM_CENSUS_HOTPATH, tools/isa_phase_breakdown.py --hot): the branches a block of the steady state
+// never takes (start-up over, far end active with a non-zero delay, no rescaling inside the inverse transform, none of
+// the once-per-30-blocks channel bookkeeping) are declared unreachable, so the block loop becomes the straight-line
+// hot path and a static count of it approximates the dynamic instruction mix.  Identity in every other build.
+#if defined(AECM_CENSUS_HOTPATH) && defined(__HIP_DEVICE_COMPILE__)
+#define AECM_STEADY_NEVER(c) (__builtin_expect(!!(c), 0) && (__builtin_unreachable(), true))
+#define AECM_STEADY_ALWAYS(c) (__builtin_expect(!!(c), 1) || (__builtin_unreachable(), false))
+#else
+#define AECM_STEADY_NEVER(c) (c)
+#define AECM_STEADY_ALWAYS(c) (c)
+#endif
+
 namespace aecm {
 
 // ---- algorithm constants (reference aecm/aecm_defines.h:17-85, delay_estimator.cc:23-28) --------
@@ -255,7 +267,7 @@ struct BlockEngine {
                 shift = (W::ballot(m > 13573) != 0 ? 1 : 0) + (W::ballot(m > 27146) != 0 ? 1 : 0);
                 scale += shift;
             }
-            if (AECM_UNLIKELY(shift == 1)) {
+            if (AECM_STEADY_NEVER(AECM_UNLIKELY(shift == 1))) {
                 // sh = 15: as in fft_stage0_real, with a complex twiddle
                 vi acc_re = dot2_i16(b, w_re, shl_add(lo16(a), 15, 32769));      // base + T_re
                 vi z_re = sub(shl_add(a, 16, 65537), acc_re);                    // Z = 2*base + 1 - acc
@@ -264,7 +276,7 @@ struct BlockEngine {
                 if (kNeedImB) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);
                 a = kNeedImA ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);
                 b = kNeedImB ? pack_hi16(z_re, z_im) : lsr(z_re, 16);
-            } else if (AECM_LIKELY(shift == 0)) {
+            } else if (AECM_STEADY_ALWAYS(AECM_LIKELY(shift == 0))) {
                 // sh = 14 (the usual case of the inverse transform: the suppressed output is small).
                 // base = (x_a << 16) + 2^15 has 15 zero low bits and (T >> 1) << 2 is 2T with bit 1
                 // cleared, so V = base + 2T equals Y+ except possibly in bit 1, and Z = 2*base + 2 - V
@@ -381,7 +393,7 @@ struct BlockEngine {
     static AECM_HD int binary_spectrum(const Regs &r, vi mag, int q, vi &threshold, int &initialized) {
         vb in_band = (r.lane >= kBandFirst) & (r.lane <= kBandLast);
         vi v = shl(mag, 15 - q);                                        // Q15
-        if (!initialized) {
+        if (AECM_STEADY_NEVER(!initialized)) {
             vb seed = in_band & (mag > 0);
             threshold = sel(seed, sar(v, 1), threshold);
             if (W::ballot(seed) != 0) initialized = 1;
@@ -459,9 +471,9 @@ struct BlockEngine {
         r.adapt_log = W::shift_up1(r.adapt_log, log_energy_q8(e_adapt, kResChannel16 + far_q));
         r.stored_log = W::shift_up1(r.stored_log, log_energy_q8(e_stored, kResChannel16 + far_q));
 
-        if (u.far_log > kFarEnergyMin) {                                              // :692-730
+        if (AECM_STEADY_ALWAYS(u.far_log > kFarEnergyMin)) {                          // :692-730
             int inc_max = 4, dec_max = 11, inc_min = 11, dec_min = 3;
-            if (u.startup == 0) { inc_max = 2; dec_min = 2; inc_min = 8; }
+            if (AECM_STEADY_NEVER(u.startup == 0)) { inc_max = 2; dec_min = 2; inc_min = 8; }
             u.fe_min = asym_filt(u.fe_min, u.far_log, inc_min, dec_min);
             u.fe_max = asym_filt(u.fe_max, u.far_log, inc_max, dec_max);
             u.fe_maxmin = sext16(u.fe_max - u.fe_min);
@@ -483,7 +495,7 @@ struct BlockEngine {
         } else {
             u.cur_vad = 0;
         }
-        if (u.cur_vad && u.first_vad) {                                               // :741-754
+        if (AECM_STEADY_NEVER(u.cur_vad && u.first_vad)) {                            // :741-754
             u.first_vad = 0;
             int adapt0 = W::readlane(r.adapt_log, 0), near0 = W::readlane(r.near_log, 0);
             if (adapt0 > near0) {
@@ -497,9 +509,9 @@ struct BlockEngine {
 
     static AECM_HD int calc_step_size(const Uniform &u) {                             // :767-794
         int mu = kMuMax;
-        if (!u.cur_vad) {
+        if (AECM_STEADY_NEVER(!u.cur_vad)) {
             mu = 0;
-        } else if (u.startup > 0) {
+        } else if (AECM_STEADY_ALWAYS(u.startup > 0)) {
             if (u.fe_min >= u.fe_max) {
                 mu = kMuMin;
             } else {
@@ -558,16 +570,16 @@ struct BlockEngine {
     static AECM_HD void update_channel(Regs &r, vi far, int far64, int far_q, vi dfa, int dfa64, int mu,
                                        vi &echo_est, int &echo_est64) {
         Uniform &u = r.u;
-        if (mu) {
+        if (AECM_STEADY_ALWAYS(mu)) {
             nlms_bin<vi>(r.b, far, dfa, lane_const<LC_DIV_MAGIC>(r), lane_const<LC_DIV_SHIFT>(r), u.dfa_noisy_q, far_q, mu);
             nlms_bin<int>(r.b64, far64, dfa64, r.bin64_div_magic, r.bin64_div_shift, u.dfa_noisy_q, far_q, mu);
         }
-        if ((u.startup == 0) & (u.cur_vad != 0)) {                                            // :926-929
+        if (AECM_STEADY_NEVER((u.startup == 0) & (u.cur_vad != 0))) {                         // :926-929
             store_adaptive_channel(r, far, far64, echo_est, echo_est64);
         } else {
             if (u.far_log < u.fe_mse) u.mse_cnt = 0;                                          // :931-935
             else u.mse_cnt = sext16(u.mse_cnt + 1);
-            if (u.mse_cnt >= (kMinMseCount + 10)) {                                           // :937-983
+            if (AECM_STEADY_NEVER(u.mse_cnt >= (kMinMseCount + 10))) {                        // :937-983
                 vb first20 = r.lane < kMinMseCount;
                 int mse_stored = W::reduce_add(sel(first20, iabs(r.stored_log - r.near_log), vi(0)));
                 int mse_adapt = W::reduce_add(sel(first20, iabs(r.adapt_log - r.near_log), vi(0)));
@@ -597,7 +609,7 @@ struct BlockEngine {
     static AECM_HD int calc_suppression_gain(Regs &r) {                               // :1000-1052
         Uniform &u = r.u;
         int sup;
-        if (!u.cur_vad) {
+        if (AECM_STEADY_NEVER(!u.cur_vad)) {
             sup = 0;
         } else {
             int near0 = W::readlane(r.near_log, 0), stored0 = W::readlane(r.stored_log, 0);
@@ -776,7 +788,7 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     static AECM_HD vi process_block(Regs &r, uint16_t *hist, vi far_new, vi near_new, vi clean_new) {
         Uniform &u = r.u;
-        if (u.startup < 2) u.startup = (gtu(u.tot_count, kConvLen - 1) ? 1 : 0) + (gtu(u.tot_count, kConvLen2 - 1) ? 1 : 0);  // :420-424
+        if (AECM_STEADY_NEVER(u.startup < 2)) u.startup = (gtu(u.tot_count, kConvLen - 1) ? 1 : 0) + (gtu(u.tot_count, kConvLen2 - 1) ? 1 : 0);  // :420-424
 
         if (W::kLaneConstsInTable) r.table_index = W::table_index_for_this_block();
 
@@ -844,7 +856,7 @@ struct BlockEngine {
         const int far_q = sar(side, 16);
         const int far64 = zext16(side);
         vi far = xf.mag;
-        if (delay != 0) far = W::load_u16(hist + pos * kLanes, r.lane);
+        if (AECM_STEADY_ALWAYS(delay != 0)) far = W::load_u16(hist + pos * kLanes, r.lane);
 
         vi echo_est;
         int echo_est64;
@@ -862,7 +874,7 @@ struct BlockEngine {
         const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
 
         AECM_PHASE_MARK(8, hnl, r.b.near_filt);
-        if (u.mult == 2) {                                                            // :618-648
+        if (AECM_STEADY_ALWAYS(u.mult == 2)) {                                        // :618-648
             hnl = as_i16(sar(mul24(hnl, hnl), 14));
             hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
             int avg = W::reduce_add(sel((r.lane >= 4) & (r.lane <= 24), hnl, vi(0)));
@@ -870,7 +882,7 @@ struct BlockEngine {
             hnl = sel((r.lane >= 24) & (hnl > avg), vi(avg), hnl);
             if (hnl64 > avg) hnl64 = avg;
         }
-        if (u.nlp) {                                                                  // :651-686
+        if (AECM_STEADY_ALWAYS(u.nlp)) {                                              // :651-686
             hnl = sel(hnl > kNlpCompHigh, vi(kOneQ14), sel(hnl < kNlpCompLow, vi(0), hnl));
             hnl64 = hnl64 > kNlpCompHigh ? kOneQ14 : (hnl64 < kNlpCompLow ? 0 : hnl64);
             if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
@@ -881,10 +893,10 @@ struct BlockEngine {
         int e_im64 = 0;
 
         AECM_PHASE_MARK(9, e_re, e_im);
-        if (u.cng == 1) {                                                             // :702-705
+        if (AECM_STEADY_ALWAYS(u.cng == 1)) {                                         // :702-705
             int shift_n = sext16(15 - u.dfa_clean_q);
             int min_track = 9;
-            if (u.noise_ctr < 100) { u.noise_ctr = sext16(u.noise_ctr + 1); min_track = 6; }
+            if (AECM_STEADY_NEVER(u.noise_ctr < 100)) { u.noise_ctr = sext16(u.noise_ctr + 1); min_track = 6; }
             // LCG jump-ahead: lane t gets the t-th of this block's 64 draws
             vi st = add(mul(lane_const<LC_LCG_MUL>(r), vi(u.seed)), lane_const<LC_LCG_ADD>(r)) & 0x7fffffff;
             int s64 = add(mul(r.lcg_mul64, u.seed), r.lcg_add64) & 0x7fffffff;
@@ -954,7 +966,9 @@ struct BlockEngine {
             W::begin_block(blk, n_blocks);
             vi out = process_block(r, hist, far_cur, near_cur, clean_cur);
             io.out(r, blk, out);
+            AECM_PHASE_MARK(13, r.out_ovl, r.x_old);
         }
+        AECM_PHASE_MARK(14, r.out_ovl, r.x_old);
         store_state(r, vec, scal);
     }
 
