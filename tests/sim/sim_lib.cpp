@@ -59,10 +59,10 @@ void sim_constants(uint32_t *blob_out, uint32_t *defined_lane_rows, uint32_t *de
         for (int t = 0; t < kLanes; ++t) defined_lane_rows[k * kLanes + t] = (uint32_t)r.lc[k].v[t];
     VecI wre, wim;
     uint32_t *o = defined_twiddles;
-#define SIM_TW(INV, S) SimWave::twiddles<S, INV>(wre, wim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)wre.v[t]; *o++ = (uint32_t)wim.v[t]; }
-    SIM_TW(true, 0) SIM_TW(true, 1) SIM_TW(true, 2) SIM_TW(true, 3) SIM_TW(true, 4) SIM_TW(true, 5) SIM_TW(true, 6)
-#undef SIM_TW
     VecI nwre, nwim, sre, cre, sim_, cim;
+#define SIM_TW(S) SimWave::inv_twiddles<S>(wre, wim, nwre, nwim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)wre.v[t]; *o++ = (uint32_t)wim.v[t]; *o++ = (uint32_t)nwre.v[t]; *o++ = (uint32_t)nwim.v[t]; }
+    SIM_TW(0) SIM_TW(1) SIM_TW(2) SIM_TW(3) SIM_TW(4) SIM_TW(5) SIM_TW(6)
+#undef SIM_TW
 #define SIM_FT(S) SimWave::fwd_twiddles<S>(wre, wim, nwre, nwim); for (int t = 0; t < kLanes; ++t) { *o++ = (uint32_t)wre.v[t]; *o++ = (uint32_t)wim.v[t]; *o++ = (uint32_t)nwre.v[t]; *o++ = (uint32_t)nwim.v[t]; }
     SIM_FT(1) SIM_FT(2) SIM_FT(3) SIM_FT(4) SIM_FT(5) SIM_FT(6)
 #undef SIM_FT
@@ -85,9 +85,10 @@ int sim_fft128(int16_t *re, int16_t *im, int variant) {
         b.v[t] = (re[t + 64] & 0xffff) | (int)((unsigned)im_b << 16);
     }
     int scale = 0;
-    if (variant == 0) scale = E::fft128<false, true>(a, b);
-    else if (variant == 1) scale = E::fft128<false, false>(a, b);
-    else scale = E::fft128<true, false>(a, b);
+    const VecI kp = SimWave::opaque_const(32770);
+    if (variant == 0) scale = E::fft128<false, true>(a, b, kp);
+    else if (variant == 1) scale = E::fft128<false, false>(a, b, kp);
+    else scale = E::fft128<true, false>(a, b, kp);
     for (int t = 0; t < kLanes; ++t) {
         int r = 0;
         for (int k = 0; k < 6; ++k) r |= ((t >> k) & 1) << (5 - k);

@@ -51,6 +51,11 @@ SIM_BIN(divi, divi(x, y))
 SIM_BIN(divu, divu(x, y))
 SIM_BIN(pack_hi16, pack_hi16(x, y))
 SIM_BIN(pk_max_i16, pk_max_i16(x, y))
+SIM_BIN(pk_add_u16, pk_add_u16(x, y))
+SIM_BIN(pk_max_u16, pk_max_u16(x, y))
+SIM_BIN(pk_sub_sat_u16, pk_sub_sat_u16(x, y))
+SIM_BIN(dot2_i16_c0, dot2_i16_c0(x, y))
+SIM_BIN(dot2_i16_cm1, dot2_i16_cm1(x, y))
 #undef SIM_BIN
 
 #define SIM_UN(NAME, EXPR)                                                    \
@@ -179,6 +184,16 @@ struct SimWave {
             w_im.v[t] = (wi & 0xffff) | (int)((unsigned)wr << 16);
         }
     }
+    // Inverse stages: the twiddles and their per-half negations.
+    template <int S>
+    static void inv_twiddles(vi &w_re, vi &w_im, vi &nw_re, vi &nw_im) {
+        twiddles<S, true>(w_re, w_im);
+        for (int t = 0; t < 64; ++t) {
+            nw_re.v[t] = ((-sext16(w_re.v[t])) & 0xffff) | (int)((unsigned)(-(w_re.v[t] >> 16)) << 16);
+            nw_im.v[t] = ((-sext16(w_im.v[t])) & 0xffff) | (int)((unsigned)(-(w_im.v[t] >> 16)) << 16);
+        }
+    }
+    static vi opaque_const(int k) { return vi(k); }        // device: a constant pinned in a VGPR
     // Forward stages 1..6 in multiply-add form: the twiddles, their negations, and (even stages) the
     // accumulator offsets s and 1 - s, s = sum of the halves of the packed twiddle (see fft128).
     template <int S>

@@ -159,8 +159,8 @@ def sim_recordings(far, near, fs, frame, cng, echo_mode, ms, clean=None):
 
 def constants():
     """(host-built blob, lane-constant rows from their definitions, twiddle pairs from their definitions)."""
-    blob = np.zeros(8 * 64 + 7 * 64 * 2 + 6 * 64 * 4 + 3 * 64 * 4 + 360 + 68, dtype=np.uint32)
+    blob = np.zeros(8 * 64 + 7 * 64 * 4 + 6 * 64 * 4 + 3 * 64 * 4 + 360 + 68, dtype=np.uint32)
     rows = np.zeros(8 * 64, dtype=np.uint32)
-    tw = np.zeros(7 * 64 * 2 + 6 * 64 * 4 + 3 * 64 * 4, dtype=np.uint32)
+    tw = np.zeros(7 * 64 * 4 + 6 * 64 * 4 + 3 * 64 * 4, dtype=np.uint32)
     lib().sim_constants(blob, rows, tw)
     return blob, rows, tw

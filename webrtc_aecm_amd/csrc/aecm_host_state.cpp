@@ -145,9 +145,11 @@ void BuildKernelConstants(std::vector<uint32_t> *blob) {
         for (int t = 0; t < kLanes; ++t) {
             const int idx = (BitRev6(t) & ((1 << stage) - 1)) << (6 - stage);
             const int wr = kAecmTwiddleCosQ15[idx], wi = kAecmTwiddleSinQ15[idx];
-            uint32_t *e = img + (stage * kLanes + t) * 2;
+            uint32_t *e = img + (stage * kLanes + t) * 4;
             e[0] = Pack16(wr, -wi);
             e[1] = Pack16(wi, wr);
+            e[2] = Pack16(-wr, wi);                           // per-half negations (|twiddle| <= 32767: no overflow)
+            e[3] = Pack16(-wi, -wr);
         }
     // Forward stages 1..6 in the multiply-add form of fft128 (aecm_wave.h): (w_re, w_im, -w_re, -w_im) per
     // lane, and for the even stages the accumulator offsets (s_re, 1 - s_re, s_im, 1 - s_im) with

@@ -110,6 +110,15 @@ AECM_HD int dot2_i16(int a, int b, int c) {
     return add(add(mul(sext16(a), sext16(b)), mul(sar(a, 16), sar(b, 16))), c);
 #endif
 }
+// The same with the addend fixed to 0 / -1.  On the GPU this is the three-source VOP3P form with an inline constant
+// (the compiler would otherwise emit v_mov + the accumulating VOP2 form v_dot2c: one instruction more per product).
+#if defined(__HIP_DEVICE_COMPILE__)
+AECM_HD int dot2_i16_c0(int a, int b) { int r; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+AECM_HD int dot2_i16_cm1(int a, int b) { int r; asm("v_dot2_i32_i16 %0, %1, %2, -1" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+AECM_HD int dot2_i16_c0(int a, int b) { return dot2_i16(a, b, 0); }
+AECM_HD int dot2_i16_cm1(int a, int b) { return dot2_i16(a, b, -1); }
+#endif
 // sext(a.lo) * sext(k.lo) + c resp. sext(a.hi) * sext(k.lo) + c  (wrapping)    -> v_mad_i32_i16 (op_sel picks the half)
 // The _uc forms take a wave-uniform c (kept in an SGPR on the GPU).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -153,6 +162,33 @@ AECM_HD int pk_max_i16(int a, int b) {
 #else
     int lo = imax(sext16(a), sext16(b)), hi = imax(sar(a, 16), sar(b, 16));
     return (lo & 0xffff) | (int)((unsigned)hi << 16);
+#endif
+}
+// per half, unsigned: a + b wrapping / max / a - b saturating at 0          -> v_pk_add_u16 / v_pk_max_u16 / v_pk_sub_u16 clamp
+AECM_HD int pk_add_u16(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short aecm_ushort2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, (aecm_ushort2)(__builtin_bit_cast(aecm_ushort2, a) + __builtin_bit_cast(aecm_ushort2, b)));
+#else
+    return (int)((((unsigned)a + (unsigned)b) & 0xffffu) | (((unsigned)a & 0xffff0000u) + ((unsigned)b & 0xffff0000u)));
+#endif
+}
+AECM_HD int pk_max_u16(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short aecm_ushort2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(aecm_ushort2, a), __builtin_bit_cast(aecm_ushort2, b)));
+#else
+    const unsigned al = (unsigned)a & 0xffffu, bl = (unsigned)b & 0xffffu, ah = (unsigned)a >> 16, bh = (unsigned)b >> 16;
+    return (int)((al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16));
+#endif
+}
+AECM_HD int pk_sub_sat_u16(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short aecm_ushort2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(__builtin_bit_cast(aecm_ushort2, a), __builtin_bit_cast(aecm_ushort2, b)));
+#else
+    const unsigned al = (unsigned)a & 0xffffu, bl = (unsigned)b & 0xffffu, ah = (unsigned)a >> 16, bh = (unsigned)b >> 16;
+    return (int)((al > bl ? al - bl : 0u) | ((ah > bh ? ah - bh : 0u) << 16));
 #endif
 }
 // max(sext(lo), sext(hi))

@@ -81,7 +81,7 @@ enum LaneConstRow : int {
     LC_HANN_SYN_LO, LC_HANN_SYN_HI,      // synthesis window in IFFT output lane order
     kLaneConstRows
 };
-constexpr int kLdsTwiddleWords = 7 * kLanes * 2;       // inverse transform: [stage][lane] (w_re, w_im)
+constexpr int kLdsTwiddleWords = 7 * kLanes * 4;       // inverse transform: [stage][lane] (w_re, w_im, -w_re, -w_im)
 constexpr int kLdsFwdTwiddleWords = 6 * kLanes * 4;    // forward stages 1..6: (w_re, w_im, -w_re, -w_im) per lane
 constexpr int kLdsFwdOffsetWords = 3 * kLanes * 4;     // forward stages 2,4,6: accumulator offsets (see fft128)
 constexpr int kLdsCosSinWords = 360;

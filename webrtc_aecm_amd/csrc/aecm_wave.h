@@ -106,6 +106,7 @@ struct BlockEngine {
         vi lane, brev;
         vi lc[kLaneConstRows];             // LaneConstRow (aecm_state.h); unused when the policy serves them from a table
         vi table_index;                    // this lane's index into the policy's constant table, renewed every block
+        vi k_p;                            // 32770 in a vector register (see fft_stage)
         int lcg_mul64, lcg_add64, bin64_div_magic, bin64_div_shift;
     };
 
@@ -132,6 +133,7 @@ struct BlockEngine {
     static AECM_HD void init_lane_constants(Regs &r, const uint32_t *consts) {
         r.lane = W::lane_id();
         r.brev = bitrev6(r.lane);
+        r.k_p = W::opaque_const(32770);
         r.lcg_mul64 = (int)lcg_pow(64);
         r.lcg_add64 = (int)lcg_inc(64);
         r.bin64_div_magic = (int)4228890877u;            // ceil(2^38 / 65), see div_magic()
@@ -249,70 +251,89 @@ struct BlockEngine {
     // The generic stage: every inverse stage (data-dependent scaling, complex_fft.c:382-396) and forward
     // stage 0 of a complex signal.  Returns the sum of the shifts applied (inverse only).
     template <bool kInverse, int S, int N>
-    static AECM_HD int fft_stage_generic(vi (&aa)[N], vi (&bb)[N]) {
+    static AECM_HD int fft_stage_generic(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
         int scale = 0;
-        vi w_re, w_im;
-        W::template twiddles<S, kInverse>(w_re, w_im);       // (wr,-wi) and (wi,wr), packed
+        vi w_re, w_im, nw_re = vi(0), nw_im = vi(0);
+        if constexpr (kInverse) W::template inv_twiddles<S>(w_re, w_im, nw_re, nw_im);   // (wr,-wi), (wi,wr) packed, and negated
+        else W::template twiddles<S, kInverse>(w_re, w_im);
         // Last stage: the caller only consumes the real parts (inverse: real_fft.c:97-99) resp. bins
         // 0..63 complex and the real part of bin 64 (forward: aecm_core_c.cc:297)
         constexpr bool kNeedImA = !(S == 6 && kInverse), kNeedImB = S != 6;
         for (int n = 0; n < N; ++n) {
             vi &a = aa[n], &b = bb[n];
             if constexpr (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);
-            int shift = 1;
+            // Data-dependent scaling of the inverse transform (complex_fft.c:382-396): shift = [max|x| > 13573] +
+            // [max|x| > 27146] over all 256 int16 of the transform (|-32768| counts as 32767: above both thresholds
+            // either way).  For an int16 x, |x| > T  <=>  (uint16)(x + T) > 2T, so per packed word: add, unsigned max
+            // over a and b, saturating subtract of 2T, and "some half non-zero" is one compare + ballot -- no abs, no
+            // unpacking.  "No scaling" is the usual case (the suppressed output is small) and the fall-through path;
+            // the second threshold is only looked at when the first one fired.
+            bool rescale = !kInverse;                      // the forward transform always scales by one bit (sh = 15)
             if (kInverse) {
-                // only "max|x| > 13573" and "> 27146" matter: two ballots instead of a wave max-reduction
-                // (|-32768| saturates to 32767, the reference clamps it the same)
-                vi m = max_halves_i16(pk_max_i16(pk_abs_sat_i16(a), pk_abs_sat_i16(b)));
-                shift = (W::ballot(m > 13573) != 0 ? 1 : 0) + (W::ballot(m > 27146) != 0 ? 1 : 0);
-                scale += shift;
+                constexpr int kT1 = 13573 * 0x10001, kT2 = 27146 * 0x10001;
+                const vi over1 = pk_sub_sat_u16(pk_max_u16(pk_add_u16(a, vi(kT1)), pk_add_u16(b, vi(kT1))), vi(kT2));
+                rescale = W::ballot(over1 != 0) != 0;
             }
-            if (AECM_STEADY_NEVER(AECM_UNLIKELY(shift == 1))) {
-                // sh = 15: as in fft_stage0_real, with a complex twiddle
-                vi acc_re = dot2_i16(b, w_re, shl_add(lo16(a), 15, 32769));      // base + T_re
-                vi z_re = sub(shl_add(a, 16, 65537), acc_re);                    // Z = 2*base + 1 - acc
-                vi acc_im = vi(0), z_im = vi(0);
-                if (kNeedImA) acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));
-                if (kNeedImB) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);
-                a = kNeedImA ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);
-                b = kNeedImB ? pack_hi16(z_re, z_im) : lsr(z_re, 16);
-            } else if (AECM_STEADY_ALWAYS(AECM_LIKELY(shift == 0))) {
-                // sh = 14 (the usual case of the inverse transform: the suppressed output is small).
-                // base = (x_a << 16) + 2^15 has 15 zero low bits and (T >> 1) << 2 is 2T with bit 1
-                // cleared, so V = base + 2T equals Y+ except possibly in bit 1, and Z = 2*base + 2 - V
-                // equals Y- or Y- + 2 with Y- a multiple of 4: the upper halves are those of Y+ and Y-.
-                vi v_re = shl_add(dot2_i16(b, w_re, vi(1)), 1, shl_add(a, 16, 32768));
-                vi z_re = sub(shl_add(a, 17, 65538), v_re);
+            if (AECM_STEADY_NEVER(AECM_UNLIKELY(rescale))) {
+                int shift = 1;
+                if (kInverse) {
+                    constexpr int kT2 = 27146 * 0x10001, kT4 = (int)(54292u * 0x10001u);
+                    const vi over2 = pk_sub_sat_u16(pk_max_u16(pk_add_u16(a, vi(kT2)), pk_add_u16(b, vi(kT2))), vi(kT4));
+                    shift = W::ballot(over2 != 0) != 0 ? 2 : 1;
+                    scale += shift;
+                }
+                if (shift == 1) {
+                    // sh = 15: as in fft_stage0_real, with a complex twiddle
+                    vi acc_re = dot2_i16(b, w_re, shl_add(lo16(a), 15, 32769));      // base + T_re
+                    vi z_re = sub(shl_add(a, 16, 65537), acc_re);                    // Z = 2*base + 1 - acc
+                    vi acc_im = vi(0), z_im = vi(0);
+                    if (kNeedImA) acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));
+                    if (kNeedImB) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);
+                    a = kNeedImA ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);
+                    b = kNeedImB ? pack_hi16(z_re, z_im) : lsr(z_re, 16);
+                } else {
+                    // shift == 2, sh = 16 (rare): Y = (x_a << 14) +- (T >> 1) + 2^15
+                    vi t_re = sar(dot2_i16(b, w_re, vi(1)), 1);
+                    vi base_re = shl(lo16(a), 14) + 32768;
+                    if (kNeedImA) {
+                        vi t_im = sar(dot2_i16(b, w_im, vi(1)), 1);
+                        vi base_im = shl(hi16(a), 14) + 32768;
+                        a = pack_hi16(add(base_re, t_re), add(base_im, t_im));
+                        b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));
+                    } else {
+                        a = lsr(add(base_re, t_re), 16);
+                        b = lsr(sub(base_re, t_re), 16);
+                    }
+                }
+            } else {
+                // sh = 14, inverse only.  base = (x_a << 16) + 2^15 has 15 zero low bits and (T >> 1) << 2 is 2T with
+                // bit 1 cleared, so V = base + 2T equals Y+ except possibly in bit 1, and Z = 2*base + 2 - V equals Y- or
+                // Y- + 2 with Y- a multiple of 4: the upper halves are those of Y+ and Y-.  With T = D + 1 (D the dot
+                // product) and P = base + 2:   V = P + 2D,   Z = P - 2 - 2D = P + 2(-D - 1),
+                // and -D - 1 is the dot product with the negated twiddle and addend -1: five instructions per
+                // component (P, two dot products, two shift-adds), no subtraction, no constant moves.
+                const vi p_re = shl(a, 16) | k_p;
+                const vi v_re = shl_add(dot2_i16_c0(b, w_re), 1, p_re);
+                const vi z_re = shl_add(dot2_i16_cm1(b, nw_re), 1, p_re);
                 if (kNeedImA) {
-                    vi base_im = (a & (int)0xffff0000) | 32768;
-                    vi v_im = shl_add(dot2_i16(b, w_im, vi(1)), 1, base_im);
-                    vi z_im = sub(shl_add(base_im, 1, 2), v_im);
+                    const vi p_im = (a & (int)0xffff0000) | k_p;
+                    const vi v_im = shl_add(dot2_i16_c0(b, w_im), 1, p_im);
+                    const vi z_im = shl_add(dot2_i16_cm1(b, nw_im), 1, p_im);
                     a = pack_hi16(v_re, v_im);
                     b = pack_hi16(z_re, z_im);
                 } else {
                     a = lsr(v_re, 16);
                     b = lsr(z_re, 16);
                 }
-            } else {
-                // shift == 2, sh = 16 (rare): Y = (x_a << 14) +- (T >> 1) + 2^15
-                vi t_re = sar(dot2_i16(b, w_re, vi(1)), 1);
-                vi base_re = shl(lo16(a), 14) + 32768;
-                if (kNeedImA) {
-                    vi t_im = sar(dot2_i16(b, w_im, vi(1)), 1);
-                    vi base_im = shl(hi16(a), 14) + 32768;
-                    a = pack_hi16(add(base_re, t_re), add(base_im, t_im));
-                    b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));
-                } else {
-                    a = lsr(add(base_re, t_re), 16);
-                    b = lsr(sub(base_re, t_re), 16);
-                }
             }
         }
         return scale;
     }
 
+    // k_p: the constant 32770 pinned in a VGPR for the whole launch (Regs::k_p; only the inverse stages use it: one
+    // register constant serves both their shift-or and their and-or, which take a single scalar operand).
     template <bool kInverse, bool kRealInput, int N, int S>
-    static AECM_HD int fft_stage(vi (&aa)[N], vi (&bb)[N]) {
+    static AECM_HD int fft_stage(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
         if constexpr (S == 0 && kRealInput && !kInverse) {
             for (int n = 0; n < N; ++n) fft_stage0_real(aa[n], bb[n]);
             return 0;
@@ -320,7 +341,7 @@ struct BlockEngine {
             fft_stage_forward<S, N>(aa, bb);
             return 0;
         } else {
-            return fft_stage_generic<kInverse, S, N>(aa, bb);
+            return fft_stage_generic<kInverse, S, N>(aa, bb, k_p);
         }
     }
 
@@ -328,21 +349,21 @@ struct BlockEngine {
     // near-end windows of a block): each stage's twiddles are fetched once and are dead again before
     // the next stage, which keeps the register footprint of the tables at one stage's worth.
     template <bool kInverse, bool kRealInput, int N>
-    static AECM_HD int fft128(vi (&aa)[N], vi (&bb)[N]) {
+    static AECM_HD int fft128(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
         int scale = 0;
-        scale += fft_stage<kInverse, kRealInput, N, 0>(aa, bb);
-        scale += fft_stage<kInverse, kRealInput, N, 1>(aa, bb);
-        scale += fft_stage<kInverse, kRealInput, N, 2>(aa, bb);
-        scale += fft_stage<kInverse, kRealInput, N, 3>(aa, bb);
-        scale += fft_stage<kInverse, kRealInput, N, 4>(aa, bb);
-        scale += fft_stage<kInverse, kRealInput, N, 5>(aa, bb);
-        scale += fft_stage<kInverse, kRealInput, N, 6>(aa, bb);
+        scale += fft_stage<kInverse, kRealInput, N, 0>(aa, bb, k_p);
+        scale += fft_stage<kInverse, kRealInput, N, 1>(aa, bb, k_p);
+        scale += fft_stage<kInverse, kRealInput, N, 2>(aa, bb, k_p);
+        scale += fft_stage<kInverse, kRealInput, N, 3>(aa, bb, k_p);
+        scale += fft_stage<kInverse, kRealInput, N, 4>(aa, bb, k_p);
+        scale += fft_stage<kInverse, kRealInput, N, 5>(aa, bb, k_p);
+        scale += fft_stage<kInverse, kRealInput, N, 6>(aa, bb, k_p);
         return scale;
     }
     template <bool kInverse, bool kRealInput>
-    static AECM_HD int fft128(vi &a, vi &b) {
+    static AECM_HD int fft128(vi &a, vi &b, const vi &k_p) {
         vi aa[1] = {a}, bb[1] = {b};
-        const int scale = fft128<kInverse, kRealInput, 1>(aa, bb);
+        const int scale = fft128<kInverse, kRealInput, 1>(aa, bb, k_p);
         a = aa[0];
         b = bb[0];
         return scale;
@@ -360,8 +381,10 @@ struct BlockEngine {
         int mx = imin(max_abs, 32767);
         int q = norm_w16(mx);
         // window (:174-182): scale, truncate to int16, multiply by sqrt-Hanning Q14, truncate
-        vi wo = sext16(sar(mul24(sext16(shl(old_s, q)), lane_const<LC_HANN_LO>(r)), 14));
-        vi wn = sext16(sar(mul24(sext16(shl(new_s, q)), lane_const<LC_HANN_HI>(r)), 14));
+        // q = norm16(max |x|) with the maximum clamped to 32767, so x << q fits int16 for every sample of the window
+        // (the reference's (int16_t) cast is the identity; for x = -32768 the clamp makes q = 0)
+        vi wo = sext16(sar(mul24(as_i16(shl(old_s, q)), lane_const<LC_HANN_LO>(r)), 14));
+        vi wn = sext16(sar(mul24(as_i16(shl(new_s, q)), lane_const<LC_HANN_HI>(r)), 14));
         a = zext16(wo);                                     // packed (re, 0): imaginary input is zero (real_fft.c:59-65)
         b = zext16(wn);
         return q;
@@ -807,7 +830,7 @@ struct BlockEngine {
                 max_abs[2] = W::reduce_max(abs_max(r.c_old, clean_new));
                 q[2] = window(r, r.c_old, clean_new, max_abs[2], fa[kSignals - 1], fb[kSignals - 1]);
             }
-            fft128<false, true, kSignals>(fa, fb);
+            fft128<false, true, kSignals>(fa, fb, r.k_p);
             spectrum(r, fa[0], fb[0], q[0], xf);
             AECM_PHASE_MARK(1, xf.mag, xf.re);
             spectrum(r, fa[1], fb[1], q[1], df);
@@ -924,7 +947,7 @@ struct BlockEngine {
         int y64 = zext16(e_re64) | shl(sext16(neg(e_im64)), 16);
         vi a = y;
         vi b = sel(r.lane == 0, vi(y64), mirrored);
-        const int out_cfft = fft128<true, false>(a, b);
+        const int out_cfft = fft128<true, false>(a, b, r.k_p);
         AECM_PHASE_MARK(11, a, b);
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only

@@ -22,9 +22,9 @@ namespace aecm {
 // LDS tables, filled by the kernel prologue (aecm_kernels.hip).
 struct LdsTables {
     int lane_rows[kLaneConstRows][kLanes];   // LaneConstRow: per-lane constants (see lane_const() in aecm_wave.h)
-    // Packed twiddles of the inverse transform, one (w_re, w_im) pair per [stage][lane]: a stage is one
-    // conflict-free ds_read_b64 at lane*8 + constant offset, no VALU address or packing work.
-    int2 twiddle_inv[7][64];
+    // Packed twiddles of the inverse transform and their per-half negations, (w_re, w_im, -w_re, -w_im) per
+    // [stage][lane]: a stage is one ds_read_b128 at lane*16 + constant offset, no VALU address or packing work.
+    int4 twiddle_inv[7][64];
     // Forward stages 1..6 in the multiply-add form of fft128: (w_re, w_im, -w_re, -w_im), one ds_read_b128;
     // stages 2, 4, 6 additionally (s_re, 1 - s_re, s_im, 1 - s_im).
     int4 fwd_twiddle[6][64];
@@ -101,7 +101,7 @@ struct Gfx950Wave {
     template <int S, bool kInverse>
     static __device__ __forceinline__ void twiddles(int &w_re, int &w_im) {
         if constexpr (kInverse) {
-            const int2 w = g_lds[0].twiddle_inv[S][lane_id()];
+            const int4 w = g_lds[0].twiddle_inv[S][lane_id()];
             w_re = w.x;
             w_im = w.y;
         } else if constexpr (S == 0) {            // W^0 = (32767, 0)
@@ -112,6 +112,17 @@ struct Gfx950Wave {
             w_re = w.x;
             w_im = w.y;
         }
+    }
+    template <int S>
+    static __device__ __forceinline__ void inv_twiddles(int &w_re, int &w_im, int &nw_re, int &nw_im) {
+        const int4 w = g_lds[0].twiddle_inv[S][lane_id()];
+        w_re = w.x; w_im = w.y; nw_re = w.z; nw_im = w.w;
+    }
+    // A compile-time constant the compiler must keep in a VGPR (three-operand VALU instructions take one scalar
+    // or literal operand only; pinning the other constant of an and-or in a register keeps it one instruction).
+    static __device__ __forceinline__ int opaque_const(int k) {
+        asm("" : "+v"(k));
+        return k;
     }
     template <int S>
     static __device__ __forceinline__ void fwd_twiddles(int &w_re, int &w_im, int &nw_re, int &nw_im) {
