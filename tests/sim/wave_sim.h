@@ -43,6 +43,7 @@ SIM_BIN(lsr, lsr(x, y))
 SIM_BIN(mul, mul(x, y))
 SIM_BIN(mul24, mul24(x, y))
 SIM_BIN(mulhi_u32, mulhi_u32(x, y))
+SIM_BIN(mulhi_i32, mulhi_i32(x, y))
 SIM_BIN(add, add(x, y))
 SIM_BIN(sub, sub(x, y))
 SIM_BIN(imin, imin(x, y))
@@ -68,6 +69,7 @@ SIM_UN(operator~, ~x)
 SIM_UN(neg, neg(x))
 SIM_UN(sext16, sext16(x))
 SIM_UN(as_i16, as_i16(x))
+SIM_UN(as_nonneg, as_nonneg(x))
 SIM_UN(zext16, zext16(x))
 SIM_UN(iabs, iabs(x))
 SIM_UN(clz32, clz32(x))

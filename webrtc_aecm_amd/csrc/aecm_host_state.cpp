@@ -18,6 +18,10 @@ namespace aecm {
     fprintf(stderr, "aecm: as_i16 precondition violated (%d)\n", v);
     abort();
 }
+[[noreturn]] void aecm_nonneg_violation(int v) {
+    fprintf(stderr, "aecm: as_nonneg precondition violated (%d)\n", v);
+    abort();
+}
 namespace {
 
 inline uint32_t Pack16(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | (((uint32_t)(uint16_t)hi) << 16); }

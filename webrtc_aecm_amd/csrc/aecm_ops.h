@@ -99,6 +99,20 @@ AECM_HD int as_i16(int v) {
     return v;
 }
 
+// A value the surrounding arithmetic proves non-negative (as a signed 32-bit number); the host build checks the claim
+// like as_i16, the audit build counts violations on the device (counter 1).
+#if !defined(__HIP_DEVICE_COMPILE__)
+[[noreturn]] void aecm_nonneg_violation(int v);
+#endif
+AECM_HD int as_nonneg(int v) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (v < 0) aecm_nonneg_violation(v);
+#elif defined(AECM_CHECKED)
+    if (v < 0) atomicAdd(&g_aecm_check_fail[1], 1ull);
+#endif
+    return v;
+}
+
 // ---- packed-int16 primitives (a 32-bit word holds lo | hi<<16) -------------------------------------
 // Each has an exact portable definition; on gfx950 the same function is a single instruction.
 // sext(a.lo)*sext(b.lo) + sext(a.hi)*sext(b.hi) + c  (wrapping)              -> v_dot2_i32_i16
@@ -204,6 +218,8 @@ template <class I> AECM_HD I norm_u32(I a) { return sel(a == 0, I(0), clz32(a));
 #endif
 template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 1); }
 template <class I> AECM_HD I norm_w16(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 17); }
+// High 32 bits of the signed 64-bit product                                  -> v_mul_hi_i32 / s_mul_hi_i32
+AECM_HD int mulhi_i32(int a, int b) { return (int)(((int64_t)a * (int64_t)b) >> 32); }
 // High 32 bits of the unsigned 64-bit product                                -> v_mul_hi_u32
 AECM_HD int mulhi_u32(int a, int b) { return (int)(((uint64_t)(uint32_t)a * (uint64_t)(uint32_t)b) >> 32); }
 
@@ -219,6 +235,8 @@ AECM_HD void div_magic(int d, int *magic, int *shift) {
     *magic = (int)(uint32_t)((num + (uint64_t)d - 1) / (uint64_t)d);
     *shift = L - 1;
 }
+// The same for a dividend known to be non-negative: no sign handling.
+template <class I> AECM_HD I divu_by_magic(I n, I magic, I shift) { return sel(magic == 0, n, lsr(mulhi_u32(n, magic), shift)); }
 template <class I> AECM_HD I div_by_magic(I x, I magic, I shift) {
     I sign = sar(x, 31);
     I n = sub(x ^ sign, sign);                                   // |x| (2^31 for INT_MIN, still in range)

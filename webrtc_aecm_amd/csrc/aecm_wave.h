@@ -557,9 +557,11 @@ struct BlockEngine {
         I zeros_ch = norm_u32(s.ch_adapt32);
         I zeros_far = norm_u32(far);
         I shift_ch_far = imax(I(32) - zeros_ch - zeros_far, I(0));                            // :836-850: 0 when zeros_ch + zeros_far > 31
-        I u1 = mul(sel(shift_ch_far >= 32, I(0), sar(s.ch_adapt32, shift_ch_far)), far);
+        // shift_ch_far == 32 only for ch_adapt32 == 0 (norm 0 by convention) and far == 0: the product is 0 either way,
+        // and sar() takes its count modulo 32, so the reference's "shift 0 when the norms sum to 0" needs no select
+        I u1 = mul(sar(s.ch_adapt32, shift_ch_far), far);
         I zeros_num = norm_u32(u1);                                                           // :852-867
-        I zeros_dfa = sel(dfa != 0, norm_u32(dfa), I(32));
+        I zeros_dfa = clz32(dfa);                                                             // NormU32, and 32 for dfa == 0 (:856-860)
         I t16 = as_i16(zeros_dfa - 2 + dfa_noisy_q - kResChannel32 - far_q + shift_ch_far);   // |.| < 128: counts, Q values
         auto c1 = zeros_num > (t16 + 1);
         I xfa_q = sel(c1, t16, as_i16(zeros_num - 2));
@@ -571,10 +573,13 @@ struct BlockEngine {
         zeros_num = norm_w32(t1);
         auto update = (t1 != 0) & (far > shl(I(kChannelVad), far_q));                         // :873
         I shift_num = imax(I(32) - (zeros_num + zeros_far), I(0));                            // :886-902: 0 when the sum > 31
-        auto pos = t1 > 0;
-        I t2 = mul(sar(sel(pos, t1, neg(t1)), shift_num), far);
-        t2 = sel(pos, t2, neg(t2));
-        t2 = div_by_magic(t2, div_magic_k, div_shift_k);                                      // :904  / (bin + 1)
+        // |t1| < 2^30 (both aligned operands keep two bits of headroom, :852-872) and the shift above leaves the product
+        // below 2^31, so the reference's sign juggling around its unsigned multiply (:886-902) and its truncating signed
+        // division (:904) amount to: magnitude = (|t1| >> shift_num) * far, divide it, give it the sign of t1.
+        I sign = sar(t1, 31);
+        I mag = as_nonneg(mul(sar(sub(t1 ^ sign, sign), shift_num), far));
+        I t2 = divu_by_magic(mag, div_magic_k, div_shift_k);                                  // :904  / (bin + 1)
+        t2 = sub(t2 ^ sign, sign);
         I shift2res = as_i16(shift_num + shift_ch_far - xfa_q - mu - shl(I(30) - zeros_far, 1));
         t2 = sel(norm_w32(t2) < shift2res, I(0x7fffffff), shift_i(t2, shift2res));            // :906-912
         I n32 = add_sat32(s.ch_adapt32, t2);                                                  // :913-919
@@ -661,10 +666,10 @@ struct BlockEngine {
     template <class I>
     static AECM_HD I wiener_bin(BinState<I> &s, I echo_est, I dfa_clean, int sup_gain, int clean_q, int clean_q_old,
                                 int zeros_xbuf) {
-        // echoFilt += ((int64)(echoEst - echoFilt) * 50) >> 8 without 64-bit math:
-        // d = 256a + b  =>  (50 d) >> 8 = 50 a + ((50 b) >> 8)                                    :523-525
+        // echoFilt += ((int64)(echoEst - echoFilt) * 50) >> 8 (:523-525): the arithmetic shift of the 64-bit product is
+        // the upper word of d * (50 << 24), one multiply-high
         I d = sub(echo_est, s.echo_filt);
-        s.echo_filt = add(s.echo_filt, add(mul24(sar(d, 8), I(50)), sar(mul24(d & 255, I(50)), 8)));
+        s.echo_filt = add(s.echo_filt, mulhi_i32(d, I(50 << 24)));
 
         I zeros32 = norm_w32(s.echo_filt) + 1;                                                // :527-550
         int zeros16 = norm_w16(sup_gain) + 1;
