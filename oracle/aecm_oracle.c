@@ -973,7 +973,8 @@ void aecm_oracle_digest(const AecmOracle *o, uint32_t d[ORC_DIGEST_WORDS]) {
     for (int i = 0; i < ORC_HISTORY; ++i) { h = fnv_step(h, o->bin_far_hist[i]); h = fnv_step(h, (uint32_t)o->mean_bit_counts[i]); }
     d[21] = fnv_step(h, PACK16(o->far_init, o->near_init));
     h = FNV_INIT;
-    for (int i = 0; i < ORC_LOGBUF; ++i) { h = fnv_step(h, PACK16(o->near_log[i], o->echo_adapt_log[i])); h = fnv_step(h, (uint32_t)(uint16_t)o->echo_stored_log[i]); }
+    /* only entries [0, MIN_MSE_COUNT) of the log-energy histories are ever read (aecm_core.cc:943-952): the rest is dead state */
+    for (int i = 0; i < 20; ++i) { h = fnv_step(h, PACK16(o->near_log[i], o->echo_adapt_log[i])); h = fnv_step(h, (uint32_t)(uint16_t)o->echo_stored_log[i]); }
     d[22] = h;
     h = FNV_INIT;
     for (int i = 0; i < ORC_BLOCK; ++i) { h = fnv_step(h, PACK16(o->x_old[i], o->d_old[i])); h = fnv_step(h, (uint32_t)(uint16_t)o->out_ovl[i]); }

@@ -85,7 +85,8 @@ void refshim_core_digest(const AecmCore *c, uint32_t d[24]) {
     for (int i = 0; i < MAX_DELAY; ++i) { h = fnv_step(h, bf->binary_far_history[i]); h = fnv_step(h, (uint32_t)b->mean_bit_counts[i]); }
     d[21] = fnv_step(h, pack16(wf->far_spectrum_initialized, wn->near_spectrum_initialized));
     h = kFnvInit;
-    for (int i = 0; i < MAX_BUF_LEN; ++i) { h = fnv_step(h, pack16(c->nearLogEnergy[i], c->echoAdaptLogEnergy[i])); h = fnv_step(h, (uint32_t)(uint16_t)c->echoStoredLogEnergy[i]); }
+    // only entries [0, MIN_MSE_COUNT) of the log-energy histories are ever read (aecm_core.cc:943-952): the rest is dead state
+    for (int i = 0; i < MIN_MSE_COUNT; ++i) { h = fnv_step(h, pack16(c->nearLogEnergy[i], c->echoAdaptLogEnergy[i])); h = fnv_step(h, (uint32_t)(uint16_t)c->echoStoredLogEnergy[i]); }
     d[22] = h;
     h = kFnvInit;
     for (int i = 0; i < PART_LEN; ++i) { h = fnv_step(h, pack16(c->xBuf[i], c->dBufNoisy[i])); h = fnv_step(h, (uint32_t)(uint16_t)c->outBuf[i]); }

@@ -258,7 +258,7 @@ def test_state_snapshot_migrates_a_stream():
     a = aecm.AecmBatch(3, fs, 1, 2)
     a.process_host(far[:, :T1 * 64], near[:, :T1 * 64])
     blob = a.export_state(2)
-    assert len(blob) == aecm.load().WebRtcAecmBatch_state_size_bytes() == 32 + 17408        # header + vec + scal + hist
+    assert len(blob) == aecm.load().WebRtcAecmBatch_state_size_bytes() == 32 + 12 * 256 + 256 + 100 * 128   # header + vec + scal + hist
     b = aecm.AecmBatch(2, 8000, 0, 4)                      # deliberately different rate/config: all of it is state
     b.import_state(1, blob)
     out_a = a.process_host(far[:, T1 * 64:], near[:, T1 * 64:])
@@ -639,7 +639,7 @@ def test_state_snapshot_import_is_validated():
     bad = bytearray(blob)
     struct.pack_into("<I", bad, 4, 99)                                    # layout version
     assert imp(bad) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
-    scal0 = 32 + 17 * 64 * 4                                              # header + lane vectors
+    scal0 = 32 + 12 * 64 * 4                                              # header + lane vectors
     for field, value in ((3, 1000), (3, -1), (28, 100), (29, 3), (2, 7)):  # S_HISTPOS, S_LAST_DELAY, S_MULT, S_STARTUP
         bad = bytearray(blob)
         struct.pack_into("<i", bad, scal0 + 4 * field, value)
@@ -711,20 +711,24 @@ def test_single_session_abi_vs_reference_jitter_underruns_all_call_sizes():
 
 
 @_needs_ref
-@pytest.mark.parametrize("fused", ["1", "0"])
-def test_streaming_ticks_vs_reference_sessions(fused):
+@pytest.mark.parametrize("mode", ["lean", "fused", "three"])
+def test_streaming_ticks_vs_reference_sessions(mode):
     """WebRtcAecmSessions_Tick / TickPerSession / TickFlags against one reference session per stream (not against
-    our own single-session path): uniform jittering delay, then per-session delays with underruns."""
+    our own single-session path): uniform jittering delay, then per-session delays with underruns -- in each of the
+    three forms a tick can take (lean one-launch, coded one-launch, three launches)."""
     import os
     import subprocess
     import sys
-    forced = os.environ.get("AECM_TICK_FUSED")              # the tick form (one launch / three launches) is chosen once per process
-    if forced is not None and forced != fused:
-        pytest.skip("this process is pinned to the other tick form")
+    forced = os.environ.get("AECM_TICK_MODE")               # the tick form is chosen once per process
+    if forced is not None and forced != mode:
+        pytest.skip("this process is pinned to another tick form")
+    if forced is None and os.environ.get("AECM_TICK_FUSED") is not None:
+        pytest.skip("this process is pinned to a tick form through AECM_TICK_FUSED")
     if forced is None:
-        env = dict(os.environ, AECM_TICK_FUSED=fused)
+        env = {k: v for k, v in os.environ.items() if k != "AECM_TICK_FUSED"}
+        env["AECM_TICK_MODE"] = mode
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k",
-                            f"test_streaming_ticks_vs_reference_sessions and {fused}"], env=env, capture_output=True, text=True)
+                            f"test_streaming_ticks_vs_reference_sessions and {mode}"], env=env, capture_output=True, text=True)
         assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
         return
     for fs, frame, with_clean in ((16000, 160, 0), (8000, 80, 1), (8000, 160, 0)):

@@ -49,7 +49,7 @@ public:
     bool GetEchoPath(int stream, int16_t path[kBins]);
     bool Digest(int stream, uint32_t digest[kDigestWords]);
     static constexpr size_t kStateHeaderBytes = 32;
-    static constexpr uint32_t kStateLayoutVersion = 2;      // bump whenever aecm_state.h's field lists change
+    static constexpr uint32_t kStateLayoutVersion = 3;      // bump whenever aecm_state.h's field lists change
     static constexpr size_t kStateBytes = kStateHeaderBytes + kVecWordsPerStream * 4 + kNumScal * 4 + kHistWordsPerStream * 2;
     bool ExportState(int stream, void *buf);
     int32_t ImportState(int stream, const void *buf);       // 0 / AECM_BAD_PARAMETER_ERROR / AECM_UNSPECIFIED_ERROR

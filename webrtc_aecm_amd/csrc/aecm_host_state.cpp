@@ -93,10 +93,8 @@ bool BuildInitImage(int fs, StreamImage *img) {
     scal[S_HISTPOS] = kHistory;                             // :397
     scal[S_NLP] = 1;                                        // :399
     scal[S_FIXED_DELAY] = -1;                               // :400
-    for (int t = 0; t < kLanes; ++t) {                      // delay_estimator.cc:490-493
-        vec[V_M0 * kLanes + t] = 20 << 9;
-        vec[V_M1 * kLanes + t] = t < kHistory - 64 ? (20 << 9) : 0;
-    }
+    for (int t = 0; t < kLanes; ++t)                        // delay_estimator.cc:490-493
+        vec[V_M01 * kLanes + t] = Pack16(20 << 9, t < kSecondPass ? (20 << 9) : 0);
     scal[S_MIN_PROB] = 32 << 9;                             // delay_estimator.cc:494-498
     scal[S_LAST_PROB] = 32 << 9;
     scal[S_LAST_DELAY] = -2;
@@ -219,20 +217,23 @@ void ComputeDigest(const uint32_t *vec, const int32_t *scal, const uint16_t *his
     for (int i = 0; i < kLanes; ++i) {
         h = FnvStep(h, V(V_NOISE, i));
         const uint32_t w = V(V_NEARFILT, i);
-        h = FnvStep(h, Pack16((w >> 16) & 255, w >> 24));
+        h = FnvStep(h, Pack16((w >> 16) & 7, (w >> 19) & 7));
     }
     h = FnvStep(h, (uint32_t)scal[S_B64_NOISE]);
     h = FnvStep(h, Pack16(scal[S_B64_LOWCTR], scal[S_B64_HIGHCTR]));
     d[20] = FnvStep(h, (uint32_t)(uint16_t)scal[S_NOISECTR]);
     h = kFnvInit;
-    for (int i = 12; i <= 43; ++i) { h = FnvStep(h, V(V_MEANFAR, i)); h = FnvStep(h, V(V_MEANNEAR, i)); }
+    for (int i = 12; i <= 43; ++i) { h = FnvStep(h, V(V_MEAN, i)); h = FnvStep(h, V(V_MEAN, (i + 32) & 63)); }
     for (int i = 0; i < kHistory; ++i) {
         h = FnvStep(h, i < 64 ? V(V_BH0, i) : V(V_BH1, i - 64));
-        h = FnvStep(h, i < 64 ? V(V_M0, i) : V(V_M1, i - 64));
+        h = FnvStep(h, i < 64 ? (V(V_M01, i) & 0xffffu) : (V(V_M01, i - 64) >> 16));
     }
     d[21] = FnvStep(h, Pack16(scal[S_FAR_INIT], scal[S_NEAR_INIT]));
     h = kFnvInit;
-    for (int i = 0; i < kLanes; ++i) { h = FnvStep(h, V(V_LOG_NA, i)); h = FnvStep(h, V(V_LOG_S, i) & 0xffffu); }
+    for (int i = 0; i < kLogEntries; ++i) {                  // the entries the algorithm reads (aecm_core.cc:943-952)
+        h = FnvStep(h, V(V_BH1, kSecondPass + i));
+        h = FnvStep(h, V(V_HQ, kSecondPass + i) >> 16);
+    }
     d[22] = h;
     h = kFnvInit;
     for (int i = 0; i < kLanes; ++i) {
@@ -240,10 +241,10 @@ void ComputeDigest(const uint32_t *vec, const int32_t *scal, const uint16_t *his
         h = FnvStep(h, V(V_OUTBUF, BitRev6(i)) & 0xffffu);
     }
     for (int p = 0; p < kHistory; ++p) {
-        const uint32_t side = p < 64 ? V(V_HQ0, p) : V(V_HQ1, p - 64);
-        h = FnvStep(h, (uint32_t)Hi16(side));
+        const uint32_t nf = V(V_NEARFILT, p < 64 ? p : p - 64), hq = V(V_HQ, p < 64 ? p : p - 64);
+        h = FnvStep(h, p < 64 ? ((nf >> 22) & 31u) : (nf >> 27));                // far_q_domains[p]
         for (int i = 0; i < kLanes; ++i) h = FnvStep(h, (uint32_t)hist[p * kLanes + i]);
-        h = FnvStep(h, side & 0xffffu);
+        h = FnvStep(h, p < 64 ? (hq & 0xffffu) : (hq >> 16));                    // far_history[p][64]
     }
     d[23] = h;
 }

@@ -49,6 +49,7 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
 // source code per sample: -1 = zero, else (kind << 28) | index.
 constexpr int kTickMaxBlockSamples = 256;   // <= 4 blocks per tick
 constexpr int kTickMaxSamples = 160;
+constexpr int kTickFrame = 80;              // FRAME_LEN: output frames are assembled 80 samples at a time
 enum TickSource : int32_t {
     kTickFromInput = 0,      // gather: this tick's far/near input row          assemble: this tick's block outputs
     kTickFromRing = 1,       // gather: the far/near ring                       assemble: the output ring
@@ -108,6 +109,33 @@ struct TickIo {
 };
 hipError_t LaunchTick(const StatePtrs &st, const TickIo &io, int n_streams, int variant, const int32_t *class_of_stream,
                       const TickClassEntry *table, const TickClassEntry *single, hipStream_t stream);
+
+// The lean form of the one-launch tick.  The session machinery moves samples in long runs (a jitter-buffer frame, a
+// re-read of old content, a stretch of never-written zeros), so instead of one source code per sample a block's 64
+// inputs / an output frame's 80 samples are described by at most kTickMaxRuns runs of consecutive ring positions.
+// The wave appends the tick's samples to its rings FIRST, then reads everything back from the rings (one uniform base
+// + a per-lane position; workgroup-scope fences order the wave's own stores and loads), so the per-lane work of a
+// fetch is "add, mask" for the usual single run and the whole description sits in scalar registers.  A tick whose
+// description does not fit (more runs) falls back to the coded forms above.
+constexpr int kTickMaxRuns = 4;
+constexpr int32_t kTickRunZero = INT32_MIN;   // off value of a run of zeros (never-written buffer memory)
+struct TickRuns {
+    int32_t n;                       // runs in use (>= 1)
+    int32_t end[kTickMaxRuns];       // exclusive end index, within the block / frame, of run k
+    int32_t off[kTickMaxRuns];       // sample i of run k sits at ring position (i + off[k]) & (ring_len - 1); kTickRunZero: zeros
+    int32_t kind[kTickMaxRuns];      // output frames only: kTickFromRing = output ring, kTickNearRing = near (clean) ring
+};
+struct TickLeanEntry {
+    int32_t n_blocks;                // blocks of this tick (<= 4)
+    int32_t n_far;                   // how many of the tick's far samples the jitter buffer accepted (the first n_far)
+    int32_t n_frames;                // output frames of 80 samples (1 or 2)
+    int32_t reserved;
+    int64_t far_pos, out_pos;        // where the accepted far samples / this tick's block outputs go in their rings
+    TickRuns far[4], near[4];        // per block
+    TickRuns out[2];                 // per output frame
+};
+hipError_t LaunchTickLean(const StatePtrs &st, const TickIo &io, int n_streams, const int32_t *class_of_stream,
+                          const TickLeanEntry *table, const TickLeanEntry *single, hipStream_t stream);
 
 // Diagnostics: `count` independent 128-point transforms of the block kernel's fft128, one wavefront
 // each, on natural-order data (data[k] = re[128] then im[128] of transform k, in place).  variant:

@@ -433,6 +433,115 @@ hipError_t LaunchTick(const StatePtrs &st, const TickIo &io, int n_streams, int 
     return hipGetLastError();
 }
 
+// ---- lean fused tick (run-encoded sources) ------------------------------------------------------------
+// Ring position of sample i (lane-varying) of a run description (wave-uniform, in scalar registers).
+__device__ __forceinline__ int RunPosition(const TickRuns &t, int i, int mask, bool &zero, int *kind = nullptr) {
+    int off = t.off[0], k = t.kind[0];
+    const int n = __builtin_amdgcn_readfirstlane(t.n);
+    if (n > 1) {                                            // wave-uniform: the usual description is one run
+        for (int r = 1; r < kTickMaxRuns; ++r)
+            if (r < n && i >= t.end[r - 1]) { off = t.off[r]; k = t.kind[r]; }
+    }
+    zero = off == kTickRunZero;
+    if (kind) *kind = k;
+    return zero ? 0 : (i + off) & mask;
+}
+
+template <bool kHasClean>
+struct TickRunIo {
+    using E = BlockEngine<Gfx950Wave<true>, kHasClean>;
+    using Regs = typename E::Regs;
+    const TickLeanEntry *e;
+    const int16_t *fr, *nr, *cr;     // this session's far / near / clean rings (the tick's samples already appended)
+    int16_t *out_row;                // this session's output ring
+    int mask, out_pos;
+    static __device__ __forceinline__ int fetch(const TickRuns &t, int lane, const int16_t *ring, int mask) {
+        bool zero;
+        const int p = RunPosition(t, lane, mask, zero);
+        const int v = ring[p];
+        return zero ? 0 : v;
+    }
+    __device__ __forceinline__ int far(const Regs &r, int b) const { return fetch(e->far[b], r.lane, fr, mask); }
+    __device__ __forceinline__ int near(const Regs &r, int b) const { return fetch(e->near[b], r.lane, nr, mask); }
+    __device__ __forceinline__ int clean(const Regs &r, int b) const { return fetch(e->near[b], r.lane, cr, mask); }
+    __device__ __forceinline__ void out(const Regs &r, int b, int v) const {
+        out_row[(out_pos + b * kBlock + r.brev) & mask] = (int16_t)v;
+    }
+};
+
+template <bool kHasClean>
+__device__ __forceinline__ void TickSessionLean(const StatePtrs &st, const TickIo &io, int64_t s, const TickLeanEntry *e) {
+    const int lane = threadIdx.x & 63;
+    const int mask = (int)io.ring_len - 1;
+    const int16_t *fin = io.far_in + s * io.io_stride, *nin = io.near_in + s * io.io_stride;
+    const int16_t *cin = kHasClean ? io.clean_in + s * io.io_stride : nullptr;
+    int16_t *fr = io.far_ring + s * io.ring_len, *nr = io.near_ring + s * io.ring_len;
+    int16_t *cr = kHasClean ? io.clean_ring + s * io.ring_len : nullptr;
+    int16_t *orow = io.out_ring + s * io.ring_len;
+    int16_t *out = io.out + s * io.io_stride;
+    // 1. the tick's samples into the rings
+    const int far_pos = (int)e->far_pos, near_pos = (int)io.near_pos, n_far = e->n_far, n = io.n;
+    for (int j = lane; j < n; j += 64) {
+        if (j < n_far) fr[(far_pos + j) & mask] = fin[j];
+        nr[(near_pos + j) & mask] = nin[j];
+        if (kHasClean) cr[(near_pos + j) & mask] = cin[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // this wave's loads below must see this wave's stores
+    // 2. the session's blocks, inputs fetched from the rings through the run descriptions
+    const int nb = __builtin_amdgcn_readfirstlane(e->n_blocks);
+    if (nb > 0) {
+        TickRunIo<kHasClean> rio{e, fr, nr, cr, orow, mask, (int)e->out_pos};
+        TickRunIo<kHasClean>::E::run_stream_io(st, rio, s, nb);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    // 3. the tick's output frames: block outputs (this tick's or older ones) from the output ring, pass-through from the
+    //    (clean) near-end ring (reference echo_control_mobile.cc:285-291), zeros
+    const int16_t *pass = kHasClean ? cr : nr;
+    const int n_frames = __builtin_amdgcn_readfirstlane(e->n_frames);
+    for (int f = 0; f < n_frames; ++f)
+        for (int j = lane; j < kTickFrame; j += 64) {
+            bool zero;
+            int kind;
+            const int p = RunPosition(e->out[f], j, mask, zero, &kind);
+            const int v = kind == kTickNearRing ? pass[p] : orow[p];
+            out[f * kTickFrame + j] = (int16_t)(zero ? 0 : v);
+        }
+}
+
+template <bool kHasClean>
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
+void aecm_tick_lean_kernel(StatePtrs st, TickIo io, int n_streams, TickLeanEntry single) {
+    FillLdsTables(st.consts);
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (s >= n_streams) return;
+    TickSessionLean<kHasClean>(st, io, s, &single);
+}
+template <bool kHasClean>
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
+void aecm_tick_lean_classes_kernel(StatePtrs st, TickIo io, int n_streams, const int32_t *__restrict__ class_of_stream,
+                                   const TickLeanEntry *__restrict__ table) {
+    FillLdsTables(st.consts);
+    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (s >= n_streams) return;
+    TickSessionLean<kHasClean>(st, io, s, table + __builtin_amdgcn_readfirstlane(class_of_stream[s]));
+}
+
+hipError_t LaunchTickLean(const StatePtrs &st, const TickIo &io, int n_streams, const int32_t *class_of_stream,
+                          const TickLeanEntry *table, const TickLeanEntry *single, hipStream_t stream) {
+    if (n_streams <= 0) return hipSuccess;
+    const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup), block(64 * kWavesPerWorkgroup);
+    const size_t lds = sizeof(LdsTables);
+    const bool clean = io.clean_in != nullptr;
+    if (table) {
+        if (clean) hipLaunchKernelGGL((aecm_tick_lean_classes_kernel<true>), grid, block, lds, stream, st, io, n_streams, class_of_stream, table);
+        else hipLaunchKernelGGL((aecm_tick_lean_classes_kernel<false>), grid, block, lds, stream, st, io, n_streams, class_of_stream, table);
+    } else {
+        if (clean) hipLaunchKernelGGL((aecm_tick_lean_kernel<true>), grid, block, lds, stream, st, io, n_streams, *single);
+        else hipLaunchKernelGGL((aecm_tick_lean_kernel<false>), grid, block, lds, stream, st, io, n_streams, *single);
+    }
+    return hipGetLastError();
+}
+
 // ---- self test of the wave primitives ------------------------------------------------------------
 
 __device__ __forceinline__ unsigned Mix(unsigned x) {

@@ -27,7 +27,9 @@ SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
               AECM_HIP_OK(hipMalloc((void **)&b->class_of_dev_, S * sizeof(int32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&b->blocks_per_stream_dev_, S * sizeof(int32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&b->table_dev_, kMaxFlowClasses * sizeof(TickClassEntry))) &&
-              AECM_HIP_OK(hipHostMalloc((void **)&b->table_host_, kMaxFlowClasses * sizeof(TickClassEntry), hipHostMallocDefault));
+              AECM_HIP_OK(hipHostMalloc((void **)&b->table_host_, kMaxFlowClasses * sizeof(TickClassEntry), hipHostMallocDefault)) &&
+              AECM_HIP_OK(hipMalloc((void **)&b->lean_dev_, kMaxFlowClasses * sizeof(TickLeanEntry))) &&
+              AECM_HIP_OK(hipHostMalloc((void **)&b->lean_host_, kMaxFlowClasses * sizeof(TickLeanEntry), hipHostMallocDefault));
     if (!ok) {
         delete b;
         return nullptr;
@@ -48,6 +50,8 @@ SessionBatch::~SessionBatch() {
     (void)hipFree(blocks_per_stream_dev_);
     (void)hipFree(table_dev_);
     if (table_host_) (void)hipHostFree(table_host_);
+    (void)hipFree(lean_dev_);
+    if (lean_host_) (void)hipHostFree(lean_host_);
 }
 
 int32_t SessionBatch::Init(int32_t samp_freq) {
@@ -165,11 +169,50 @@ int32_t SessionBatch::SetConfig(int16_t cng_mode, int16_t echo_mode) {
     return engine_->SetConfig(cng_mode, echo_mode, 0, -1) ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
-// Fused (one launch) or three-launch tick: measured cross-over between 16 384 and 65 536 sessions
-// (65 536: 0.39 vs 0.37 ms, 8 192: 0.068 vs 0.080 ms, 1 024: 0.032 vs 0.045 ms).  AECM_TICK_FUSED=0/1 forces one.
-bool SessionBatch::FusedTick(int num_streams) {
-    static const int forced = [] { const char *e = getenv("AECM_TICK_FUSED"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
-    return forced >= 0 ? forced != 0 : num_streams < 32768;
+// Which form a tick takes.  Default: the lean one-launch form (run-encoded sources, aecm_kernels.h) whenever the
+// tick's sample movements fit its description; AECM_TICK_MODE=lean|fused|three (or the older AECM_TICK_FUSED=1|0)
+// forces the coded one-launch or the three-launch form (A/B measurements, tests of those paths).
+SessionBatch::TickMode SessionBatch::ChooseTickMode(int num_streams) {
+    static const int forced = [] {
+        if (const char *m = getenv("AECM_TICK_MODE")) {
+            if (!strcmp(m, "lean")) return (int)kTickLean;
+            if (!strcmp(m, "fused")) return (int)kTickFused;
+            if (!strcmp(m, "three")) return (int)kTickThreeLaunch;
+        }
+        if (const char *e = getenv("AECM_TICK_FUSED")) return (int)(e[0] != '0' ? kTickFused : kTickThreeLaunch);
+        return -1;
+    }();
+    (void)num_streams;
+    return forced >= 0 ? (TickMode)forced : kTickLean;
+}
+
+// Describe `count` sample tags as runs of consecutive ring positions (aecm_kernels.h: TickRuns).  tag >= 0: a sample
+// of `kind`'s ring; tag == -1: zero; tag <= -2 (outputs only): near-ring sample -(tag + 2).  False if more than
+// kTickMaxRuns runs are needed.
+static bool BuildRuns(const int64_t *tags, int count, int64_t ring_len, int32_t kind_pos, TickRuns *t) {
+    memset(t, 0, sizeof *t);
+    int n = 0;
+    for (int i = 0; i < count;) {
+        const int64_t v = tags[i];
+        const bool zero = v == -1, near = v <= -2;
+        const int64_t base = near ? -v - 2 : v;
+        int j = i + 1;
+        while (j < count) {
+            const int64_t w = tags[j];
+            const bool same = zero ? w == -1 : near ? (w <= -2 && -w - 2 == base + (j - i)) : (w >= 0 && w == base + (j - i));
+            if (!same) break;
+            ++j;
+        }
+        if (n == kTickMaxRuns) return false;
+        t->end[n] = j;
+        t->off[n] = zero ? kTickRunZero : (int32_t)((base - i) & (ring_len - 1));
+        t->kind[n] = near ? (int32_t)kTickNearRing : kind_pos;
+        ++n;
+        i = j;
+    }
+    t->n = n > 0 ? n : 1;
+    if (n == 0) { t->end[0] = count; t->off[0] = kTickRunZero; }
+    return true;
 }
 
 // Give every session the class that matches (its previous class, its msInSndCardBuf and far-end flag of this tick).
@@ -216,7 +259,13 @@ int32_t SessionBatch::Regroup(const int16_t *ms_per_session, int16_t ms_uniform,
 // a far tag counts the samples the class's jitter buffer has ACCEPTED (a saturated buffer drops what does
 // not fit, and may then re-read arbitrarily old content for ever: in accepted-sample time that content
 // is never more than the buffer's 4000 samples away, so it always sits inside the device ring).
-int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, bool *stale) {
+int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, TickLeanEntry *lean, bool *lean_ok,
+                                   bool *stale) {
+    memset(lean, 0, sizeof *lean);
+    lean->far_pos = c.far_count;
+    lean->out_pos = c.blocks_done * kBlock;
+    lean->n_frames = n / kTickFrame;
+    for (int f = 0; f < 2; ++f) { lean->out[f].n = 1; lean->out[f].end[0] = kTickFrame; lean->out[f].off[0] = kTickRunZero; }
     int64_t far_tags[kTickMaxSamples], near_tags[kTickMaxSamples], out_tags[kTickMaxSamples];
     for (int i = 0; i < n; ++i) { far_tags[i] = c.far_count + i; near_tags[i] = near_pos_ + i; }
     entry->n_block_samples = 0;
@@ -268,6 +317,15 @@ int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClas
                                            : -1;
     }
     entry->n_block_samples = nbs;
+    // the same tick as run descriptions (lean one-launch form)
+    lean->n_blocks = n_blocks;
+    lean->n_far = entry->n_far;
+    for (int b = 0; b < n_blocks; ++b)
+        if (!BuildRuns(blk_far + b * kBlock, kBlock, kRing, kTickFromRing, &lean->far[b]) ||
+            !BuildRuns(blk_near + b * kBlock, kBlock, kRing, kTickFromRing, &lean->near[b]))
+            *lean_ok = false;
+    for (int f = 0; f < n / kTickFrame; ++f)
+        if (!BuildRuns(out_tags + f * kTickFrame, kTickFrame, kRing, kTickFromRing, &lean->out[f])) *lean_ok = false;
     c.blocks_done += n_blocks;
     return rc;
 }
@@ -299,11 +357,11 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
     const int n_classes = (int)classes_.size();
     // 2. the session machinery of every class in the index domain (the table is read by the previous tick's
     //    kernels until they finish: every tick ends with a stream synchronisation)
-    bool stale = false;
+    bool stale = false, lean_ok = true;
     std::vector<int32_t> class_rc((size_t)n_classes, 0);
     int32_t first_rc = 0, max_nbs = 0;
     for (int k = 0; k < n_classes; ++k) {
-        class_rc[k] = AdvanceClass(classes_[k], n, clean != nullptr, &table_host_[k], &stale);
+        class_rc[k] = AdvanceClass(classes_[k], n, clean != nullptr, &table_host_[k], &lean_host_[k], &lean_ok, &stale);
         if (class_rc[k] != 0 && first_rc == 0) first_rc = class_rc[k];
         max_nbs = std::max(max_nbs, table_host_[k].n_block_samples);
     }
@@ -336,15 +394,27 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
     // pass-through samples come from the clean near-end when there is one (echo_control_mobile.cc:285-291)
     const int16_t *pass_ring = clean ? clean_ring_ : near_ring_, *pass_in = clean ? dclean : dnear;
     bool ok = true;
+    TickMode mode = ChooseTickMode(S);
+    if (mode == kTickLean && (!lean_ok || engine_->variant() != kVariantFast)) mode = S < 32768 ? kTickFused : kTickThreeLaunch;
     if (n_classes > 1) {
         if (class_of_dirty_) {
             ok = AECM_HIP_OK(hipMemcpyAsync(class_of_dev_, class_of_.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, st));
             class_of_dirty_ = !ok;
         }
-        ok = ok && AECM_HIP_OK(hipMemcpyAsync(table_dev_, table_host_, (size_t)n_classes * sizeof(TickClassEntry),
-                                              hipMemcpyHostToDevice, st));
+        if (mode == kTickLean)
+            ok = ok && AECM_HIP_OK(hipMemcpyAsync(lean_dev_, lean_host_, (size_t)n_classes * sizeof(TickLeanEntry), hipMemcpyHostToDevice, st));
+        else
+            ok = ok && AECM_HIP_OK(hipMemcpyAsync(table_dev_, table_host_, (size_t)n_classes * sizeof(TickClassEntry),
+                                                  hipMemcpyHostToDevice, st));
     }
-    if (ok && FusedTick(S)) {
+    if (ok && mode == kTickLean) {
+        // one launch per tick, sources as runs of ring positions: the wave appends to its rings, reads its blocks'
+        // inputs back from them, writes the block outputs to the output ring and assembles the tick's output
+        TickIo tio{dfar, dnear, dclean, dout, dstride, n, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, near_pos_};
+        ok = n_classes == 1 ? AECM_HIP_OK(LaunchTickLean(engine_->state_ptrs(), tio, S, nullptr, nullptr, &lean_host_[0], st))
+                            : AECM_HIP_OK(LaunchTickLean(engine_->state_ptrs(), tio, S, class_of_dev_, lean_dev_, nullptr, st));
+    } else
+    if (ok && mode == kTickFused) {
         // one launch per tick: every session's wave appends, runs its blocks through the source codes and
         // assembles its output (wins while the tick is launch- and latency-bound)
         TickIo tio{dfar, dnear, dclean, dout, dstride, n, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, near_pos_};

@@ -71,11 +71,12 @@ private:
         FlowClass() : flow(-1) {}
     };
     SessionBatch() {}
-    static bool FusedTick(int num_streams);
     int32_t Regroup(const int16_t *ms_per_session, int16_t ms_uniform, const uint8_t *flags_per_session);
     void DropEmptyClasses();
     int32_t CheckSession(int session) const;
-    int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, bool *stale);
+    int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, TickLeanEntry *lean, bool *lean_ok, bool *stale);
+    enum TickMode { kTickLean, kTickFused, kTickThreeLaunch };
+    static TickMode ChooseTickMode(int num_streams);
     static constexpr int64_t kRing = 8192;     // >= 4000 (jitter buffer) + 160 + 144 + stale re-reads; power of two
     std::unique_ptr<BatchEngine> engine_;
     std::vector<FlowClass> classes_;
@@ -94,6 +95,7 @@ private:
     int16_t *io_dev_ = nullptr;       // [4][S][160] staging when the caller passes host pointers
     int32_t *class_of_dev_ = nullptr, *blocks_per_stream_dev_ = nullptr;          // [S] each
     TickClassEntry *table_dev_ = nullptr, *table_host_ = nullptr;                 // [kMaxFlowClasses], host copy pinned
+    TickLeanEntry *lean_dev_ = nullptr, *lean_host_ = nullptr;                    // the same ticks as run descriptions
     int device_ = 0;
 };
 

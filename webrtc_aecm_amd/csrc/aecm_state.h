@@ -28,6 +28,13 @@ constexpr int kHistory = 100;   // MAX_DELAY  (aecm_defines.h:26)
 constexpr int kLanes = 64;
 
 // ---- lane-vector words ------------------------------------------------------------------------
+// 12 words per lane (3 072 B per stream) + the scalar block = 3 328 B round trip per launch.  Fields whose live part is
+// narrower than 64 lanes x 32 bits share a word: the 100-slot delay-estimator arrays spill 36 slots into a second
+// lane pass, the three log-energy histories are only ever read in their first 20 entries (reference
+// aecm_core.cc:943-952) and live in the unused lanes 36..55 of those second-pass words, the binary-spectrum
+// thresholds only exist for bins 12..43 so the far and near sets interleave in one word, and 5-bit / 3-bit
+// quantities ride in the spare bits of the nearFilt word.  In registers every field has its own lane vector
+// (aecm_wave.h: load_state / store_state do the packing once per launch).
 enum VecField : int {
     V_XD_OLD = 0,   // lo16: xBuf[t] (previous far block), hi16: dBufNoisy[t] (previous near block)
     V_OUTBUF,       // lo16: outBuf[bitrev6(t)] (overlap-add tail, kept in IFFT output lane order)
@@ -35,20 +42,19 @@ enum VecField : int {
     V_CH16,         // lo16: channelStored[t], hi16: channelAdapt16[t]
     V_CH32,         // channelAdapt32[t]
     V_ECHOFILT,     // echoFilt[t]
-    V_NEARFILT,     // lo16: nearFilt[t], bits 16..23: noiseEstTooLowCtr[t], bits 24..31: ...TooHighCtr[t]
+    V_NEARFILT,     // bits 0..15 nearFilt[t] | 16..18 noiseEstTooLowCtr[t] | 19..21 noiseEstTooHighCtr[t] (both < 5)
+                    // | 22..26 far_q_domains[slot t] | 27..31 far_q_domains[slot t + 64] (t < 36; Q <= 14)
     V_NOISE,        // noiseEst[t]
-    V_MEANFAR,      // mean_far_spectrum[t]  (only bins 12..43 are ever touched)
-    V_MEANNEAR,     // mean_near_spectrum[t]
+    V_MEAN,         // lanes 12..43: mean_far_spectrum[t]; the other lanes t: mean_near_spectrum[(t + 32) & 63]
+                    // (only bins 12..43 of either exist, delay_estimator_wrapper.cc:92-125)
     V_BH0,          // binary_far_history[t]        (slot 0 = newest)
-    V_BH1,          // binary_far_history[t + 64]   (t < 36)
-    V_M0,           // mean_bit_counts[t]
-    V_M1,           // mean_bit_counts[t + 64]      (t < 36)
-    V_HQ0,          // far history side band, slot t      : lo16 = far_history[slot][64], hi16 = far_q
-    V_HQ1,          // far history side band, slot t + 64
-    V_LOG_NA,       // lo16: nearLogEnergy[t], hi16: echoAdaptLogEnergy[t]
-    V_LOG_S,        // lo16: echoStoredLogEnergy[t]
+    V_BH1,          // lanes 0..35: binary_far_history[t + 64]; lanes 36..55: lo16 nearLogEnergy[t - 36], hi16 echoAdaptLogEnergy[t - 36]
+    V_M01,          // lo16: mean_bit_counts[t], hi16: mean_bit_counts[t + 64] (t < 36); Q9 values <= 32 << 9
+    V_HQ,           // lo16: far_history[slot t][64]; hi16: lanes 0..35 far_history[slot t + 64][64], lanes 36..55 echoStoredLogEnergy[t - 36]
     kNumVec
 };
+constexpr int kSecondPass = 36;      // MAX_DELAY - 64: live lanes of the second-pass words
+constexpr int kLogEntries = 20;      // MIN_MSE_COUNT: entries of the log-energy histories the algorithm reads
 
 // ---- wave-uniform scalars ---------------------------------------------------------------------
 enum ScalField : int {

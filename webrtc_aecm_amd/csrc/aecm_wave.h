@@ -740,6 +740,7 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     static AECM_HD void load_state(Regs &r, const uint32_t *vec, const int32_t *scal) {
         auto V = [&](int f) { return W::load_u32(vec + f * kLanes, r.lane); };
+        const vi up36 = (r.lane + kSecondPass) & 63;            // lane t reads what lane t + 36 holds
         vi w = V(V_XD_OLD);
         r.x_old = lo16(w); r.d_old = hi16(w);
         w = V(V_OUTBUF);
@@ -749,14 +750,22 @@ struct BlockEngine {
         r.b.ch_adapt32 = V(V_CH32);
         r.b.echo_filt = V(V_ECHOFILT);
         w = V(V_NEARFILT);
-        r.b.near_filt = lo16(w); r.b.low_ctr = lsr(w, 16) & 255; r.b.high_ctr = lsr(w, 24);
+        r.b.near_filt = lo16(w); r.b.low_ctr = lsr(w, 16) & 7; r.b.high_ctr = lsr(w, 19) & 7;
+        const vi hq = V(V_HQ);
+        r.hq0 = zext16(hq) | shl(lsr(w, 22) & 31, 16);           // far_history[slot][64] | far_q << 16 (see process_block)
+        r.hq1 = lsr(hq, 16) | shl(lsr(w, 27), 16);               // lanes >= 36 carry log entries here: never read as slots
+        r.stored_log = sext16(W::bpermute(lsr(hq, 16), up36));
         r.b.noise_est = V(V_NOISE);
-        r.mean_far = V(V_MEANFAR); r.mean_near = V(V_MEANNEAR);
-        r.bh0 = V(V_BH0); r.bh1 = V(V_BH1); r.m0 = V(V_M0); r.m1 = V(V_M1);
-        r.hq0 = V(V_HQ0); r.hq1 = V(V_HQ1);
-        w = V(V_LOG_NA);
+        w = V(V_MEAN);
+        r.mean_far = w;                                          // only lanes 12..43 of either threshold set are ever used
+        r.mean_near = W::bpermute(w, (r.lane + 32) & 63);
+        r.bh0 = V(V_BH0);
+        w = V(V_BH1);
+        r.bh1 = sel(r.lane < kSecondPass, w, vi(0));
+        w = W::bpermute(w, up36);
         r.near_log = lo16(w); r.adapt_log = hi16(w);
-        r.stored_log = lo16(V(V_LOG_S));
+        w = V(V_M01);
+        r.m0 = zext16(w); r.m1 = lsr(w, 16);
         Uniform &u = r.u;
         u.tot_count = W::uni(scal[S_TOTCOUNT]); u.seed = W::uni(scal[S_SEED]); u.startup = W::uni(scal[S_STARTUP]); u.hist_pos = W::uni(scal[S_HISTPOS]);
         u.dfa_noisy_q = W::uni(scal[S_DFANOISYQ]); u.dfa_noisy_q_old = W::uni(scal[S_DFANOISYQ_OLD]);
@@ -778,18 +787,22 @@ struct BlockEngine {
 
     static AECM_HD void store_state(const Regs &r, uint32_t *vec, int32_t *scal) {
         auto V = [&](int f, vi w) { W::store_u32(vec + f * kLanes, r.lane, w); };
+        const vb second = r.lane < kSecondPass;                  // live lanes of the second-pass words
+        const vb logs = (r.lane >= kSecondPass) & (r.lane < kSecondPass + kLogEntries);
+        const vi down36 = (r.lane - kSecondPass) & 63;           // lane t reads what lane t - 36 holds
         V(V_XD_OLD, pack(r.x_old, r.d_old));
         V(V_OUTBUF, pack(r.out_ovl, r.c_old));
         V(V_CH16, pack(r.b.ch_stored, r.b.ch_adapt16));
         V(V_CH32, r.b.ch_adapt32);
         V(V_ECHOFILT, r.b.echo_filt);
-        V(V_NEARFILT, zext16(r.b.near_filt) | shl(r.b.low_ctr & 255, 16) | shl(r.b.high_ctr, 24));
+        V(V_NEARFILT, zext16(r.b.near_filt) | shl(r.b.low_ctr & 7, 16) | shl(r.b.high_ctr & 7, 19) | shl(lsr(r.hq0, 16) & 31, 22) |
+                          sel(second, shl(lsr(r.hq1, 16), 27), vi(0)));
         V(V_NOISE, r.b.noise_est);
-        V(V_MEANFAR, r.mean_far); V(V_MEANNEAR, r.mean_near);
-        V(V_BH0, r.bh0); V(V_BH1, r.bh1); V(V_M0, r.m0); V(V_M1, r.m1);
-        V(V_HQ0, r.hq0); V(V_HQ1, r.hq1);
-        V(V_LOG_NA, pack(r.near_log, r.adapt_log));
-        V(V_LOG_S, zext16(r.stored_log));
+        V(V_MEAN, sel((r.lane >= kBandFirst) & (r.lane <= kBandLast), r.mean_far, W::bpermute(r.mean_near, (r.lane + 32) & 63)));
+        V(V_BH0, r.bh0);
+        V(V_BH1, sel(second, r.bh1, sel(logs, W::bpermute(pack(r.near_log, r.adapt_log), down36), vi(0))));
+        V(V_M01, zext16(r.m0) | sel(second, shl(r.m1, 16), vi(0)));
+        V(V_HQ, zext16(r.hq0) | shl(sel(second, r.hq1, sel(logs, W::bpermute(r.stored_log, down36), vi(0))), 16));
         if (W::is_first_lane()) {
             const Uniform &u = r.u;
             scal[S_TOTCOUNT] = u.tot_count; scal[S_SEED] = u.seed; scal[S_STARTUP] = u.startup; scal[S_HISTPOS] = u.hist_pos;
