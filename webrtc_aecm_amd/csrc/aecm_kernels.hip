@@ -508,20 +508,36 @@ __device__ __forceinline__ void TickSessionLean(const StatePtrs &st, const TickI
         }
 }
 
+// Sessions per workgroup and occupancy target of the lean tick.  A tick is only 2-3 blocks per session, so the 20 KB
+// table fill of the prologue and the launch's tail are a visible share of it: 8 sessions per workgroup halve the
+// fills, and the kernel's I/O state lives in scalar registers, so it fits 64 VGPRs = 8 waves per SIMD (4 such
+// workgroups per CU).  Measured, 65 536 sessions: 4 sessions / 7 waves 0.339 ms per tick, 8 / 7: 0.324, 4 / 8: 0.323,
+// 8 / 8: 0.306, 16 / 8: 0.312.
+#ifndef AECM_TICK_LEAN_WAVES
+#define AECM_TICK_LEAN_WAVES 8
+#endif
+constexpr int kTickLeanWaves = AECM_TICK_LEAN_WAVES;
+#ifndef AECM_TICK_LEAN_WAVES_PER_EU
+#if defined(AECM_CHECKED)
+#define AECM_TICK_LEAN_WAVES_PER_EU 4
+#else
+#define AECM_TICK_LEAN_WAVES_PER_EU 8
+#endif
+#endif
 template <bool kHasClean>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
+__global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
 void aecm_tick_lean_kernel(StatePtrs st, TickIo io, int n_streams, TickLeanEntry single) {
     FillLdsTables(st.consts);
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (s >= n_streams) return;
     TickSessionLean<kHasClean>(st, io, s, &single);
 }
 template <bool kHasClean>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
+__global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
 void aecm_tick_lean_classes_kernel(StatePtrs st, TickIo io, int n_streams, const int32_t *__restrict__ class_of_stream,
                                    const TickLeanEntry *__restrict__ table) {
     FillLdsTables(st.consts);
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (s >= n_streams) return;
     TickSessionLean<kHasClean>(st, io, s, table + __builtin_amdgcn_readfirstlane(class_of_stream[s]));
 }
@@ -529,7 +545,7 @@ void aecm_tick_lean_classes_kernel(StatePtrs st, TickIo io, int n_streams, const
 hipError_t LaunchTickLean(const StatePtrs &st, const TickIo &io, int n_streams, const int32_t *class_of_stream,
                           const TickLeanEntry *table, const TickLeanEntry *single, hipStream_t stream) {
     if (n_streams <= 0) return hipSuccess;
-    const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup), block(64 * kWavesPerWorkgroup);
+    const dim3 grid((n_streams + kTickLeanWaves - 1) / kTickLeanWaves), block(64 * kTickLeanWaves);
     const size_t lds = sizeof(LdsTables);
     const bool clean = io.clean_in != nullptr;
     if (table) {
