@@ -539,6 +539,14 @@ def test_cli_single_pair_and_batch_mode(tmp_path):
     assert np.array_equal(out[:n], g["out"]) and np.array_equal(out[n:], near[n:])
     _, outs = _read_wav(tmp_path / "ns_out.wav")
     assert np.array_equal(outs, g["out"][:48000])                         # a prefix of a recording is a valid recording
+    # the same list sharded over two device shards (two host threads, two engines; both on device 0 of this box)
+    (tmp_path / "near_out.wav").unlink()
+    (tmp_path / "ns_out.wav").unlink()
+    r = subprocess.run([str(build.CLI), "--batch", str(tmp_path / "pairs.txt"), "--devices", "0,0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "2 device shard(s)" in r.stdout, r.stdout + r.stderr
+    _, out2 = _read_wav(tmp_path / "near_out.wav")
+    _, outs2 = _read_wav(tmp_path / "ns_out.wav")
+    assert np.array_equal(out2, out) and np.array_equal(outs2, outs)
     # the 8 kHz pair ran with the CLI's echoMode 1, not the fixture's 3: check against a live session instead
     _, out8 = _read_wav(tmp_path / "n8_out.wav")
     s = aecm.Aecm()

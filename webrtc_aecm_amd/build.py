@@ -81,7 +81,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             # the command-line front end (reference main.cc equivalent + multi-file batch mode)
             tmp_cli = LIB_DIR / f".{CLI.name}.{os.getpid()}.tmp"
             cli = ["g++", "-O2", "-std=c++17", str(CSRC / "aecm_cli.cpp"), "-o", str(tmp_cli), f"-L{LIB_DIR}", "-laecm_mi355x",
-                   "-Wl,-rpath,$ORIGIN"]
+                   "-pthread", "-Wl,-rpath,$ORIGIN"]
             if verbose:
                 print(" ".join(cli), flush=True)
             subprocess.check_call(cli, cwd=str(CSRC))

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/aecm_batch.h"
@@ -129,7 +130,7 @@ int ProcessPair(Wav &far_w, Wav &near_w) {
     return 1;
 }
 
-int RunBatch(const char *list_path) {
+int RunBatch(const char *list_path, const std::vector<int> &devices) {
     FILE *f = fopen(list_path, "r");
     if (!f) { fprintf(stderr, "cannot open %s\n", list_path); return 1; }
     struct Job { std::string far_path, near_path; Wav far_w, near_w; };
@@ -165,18 +166,36 @@ int RunBatch(const char *list_path) {
             memcpy(&near_all[k * stride], j.near_w.samples.data(), n * 2);
             memcpy(&far_all[k * stride], j.far_w.samples.data(), std::min(n, j.far_w.samples.size()) * 2);
         }
-        AecmBatch *batch = WebRtcAecmBatch_Create((int32_t)ids.size(), getenv("AECM_DEVICE") ? atoi(getenv("AECM_DEVICE")) : 0);
-        if (!batch) { fprintf(stderr, "WebRtcAecmBatch_Create failed (no usable GPU?)\n"); return 1; }
-        AecmConfig cfg;
-        cfg.cngMode = AecmTrue;
-        cfg.echoMode = kEchoMode;
-        int32_t rc = WebRtcAecmBatch_Init(batch, (int32_t)rate);
-        if (rc == 0) rc = WebRtcAecmBatch_set_config(batch, cfg, 0, -1);
-        if (rc == 0)
-            rc = WebRtcAecmBatch_ProcessRecordingsHost(batch, far_all.data(), near_all.data(), /*nearendClean*/ nullptr, out_all.data(), (int64_t)stride,
-                                                       frame, (int32_t)max_calls, kMsInSndCardBuf);
-        WebRtcAecmBatch_Free(batch);
-        if (rc != 0) { fprintf(stderr, "batch at %u Hz failed: %d\n", rate, rc); return 1; }
+        // Recordings are independent: static contiguous shards, one host thread and one AecmBatch per device, no
+        // exchange between devices (the C++ form of the multi-GPU sharding of DESIGN.md section 6).
+        const size_t n_dev = devices.size();
+        std::vector<int32_t> shard_rc(n_dev, 0);
+        std::vector<std::thread> workers;
+        for (size_t d = 0; d < n_dev; ++d) {
+            const size_t base = ids.size() / n_dev, rem = ids.size() % n_dev;
+            const size_t first = d * base + std::min(d, rem), count = base + (d < rem ? 1 : 0);
+            if (count == 0) continue;
+            workers.emplace_back([&, d, first, count] {
+                AecmBatch *batch = WebRtcAecmBatch_Create((int32_t)count, devices[d]);
+                if (!batch) { shard_rc[d] = -1; return; }
+                AecmConfig cfg;
+                cfg.cngMode = AecmTrue;
+                cfg.echoMode = kEchoMode;
+                int32_t rc = WebRtcAecmBatch_Init(batch, (int32_t)rate);
+                if (rc == 0) rc = WebRtcAecmBatch_set_config(batch, cfg, 0, -1);
+                if (rc == 0)
+                    rc = WebRtcAecmBatch_ProcessRecordingsHost(batch, &far_all[first * stride], &near_all[first * stride], /*nearendClean*/ nullptr,
+                                                               &out_all[first * stride], (int64_t)stride, frame, (int32_t)max_calls,
+                                                               kMsInSndCardBuf);
+                WebRtcAecmBatch_Free(batch);
+                shard_rc[d] = rc;
+            });
+        }
+        for (std::thread &w : workers) w.join();
+        for (size_t d = 0; d < n_dev; ++d) {
+            if (shard_rc[d] == -1) { fprintf(stderr, "WebRtcAecmBatch_Create failed on device %d (no usable GPU?)\n", devices[d]); return 1; }
+            if (shard_rc[d] != 0) { fprintf(stderr, "batch at %u Hz failed on device %d: %d\n", rate, devices[d], shard_rc[d]); return 1; }
+        }
         for (size_t k = 0; k < ids.size(); ++k) {
             Job &j = jobs[ids[k]];
             const size_t n = (j.near_w.samples.size() / frame) * frame;      // tail stays untouched (main.cc:111)
@@ -184,7 +203,7 @@ int RunBatch(const char *list_path) {
         }
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    printf("time interval: %d ms (%zu recordings)\n", (int)ms, jobs.size());
+    printf("time interval: %d ms (%zu recordings on %zu device shard(s))\n", (int)ms, jobs.size(), devices.size());
     for (Job &j : jobs)
         if (!WriteWav(OutName(j.near_path), j.near_w.rate, j.near_w.samples)) { fprintf(stderr, "ERROR\n"); return 1; }
     return 0;
@@ -194,9 +213,21 @@ int RunBatch(const char *list_path) {
 
 int main(int argc, char **argv) {
     printf("WebRTC Acoustic Echo Canceller for Mobile -- MI355X engine\n");
-    printf("usage : aecm_run far_file.wav near_file.wav | aecm_run --batch pairs.txt\n");
+    printf("usage : aecm_run far_file.wav near_file.wav | aecm_run --batch pairs.txt [--devices 0,1,...]\n");
     if (argc < 3) return -1;
-    if (strcmp(argv[1], "--batch") == 0) return RunBatch(argv[2]);
+    if (strcmp(argv[1], "--batch") == 0) {
+        // --devices: HIP device ids to shard the recordings over (one host thread + one batch each); default $AECM_DEVICE or 0
+        std::vector<int> devices;
+        if (argc >= 5 && strcmp(argv[3], "--devices") == 0) {
+            for (const char *p = argv[4]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
+        }
+        if (devices.empty()) devices.push_back(getenv("AECM_DEVICE") ? atoi(getenv("AECM_DEVICE")) : 0);
+        return RunBatch(argv[2], devices);
+    }
     Wav far_w, near_w;
     if (!ReadWav(argv[2], &near_w) || !ReadWav(argv[1], &far_w)) { printf("failed to read wav files.\n"); return 1; }
     if (near_w.channels != 1 || far_w.channels != 1) { printf("mono files only.\n"); return 1; }   // main.cc:47-52
