@@ -286,6 +286,7 @@ def main():
                        "streams_per_gpu": S, "blocks_per_step": T, "fs": args.fs, "kernel_variant": args.variant,
                        "sharding": f"static, {world} x {S} independent streams, no data-path collective",
                        "timed_region_s": c["seconds"], "commit": commit},
+            "device": dict(zip(("name", "compute_units", "clock_khz"), aecm.device_info(local_rank))),
             "ranks": {"world_size": world, "ranks_seen": c["ranks_seen"], "collective_backend": c["backend"],
                       "devices_visible_to_rank0": n_dev, "share_devices": bool(args.share_devices),
                       "per_rank_frames_per_s": [p[0] / p[1] for p in c["per_rank"]],
