@@ -164,7 +164,6 @@ struct SimWave {
         for (int i = 0; i < 64; ++i) div_magic(d.v[i], &magic.v[i], &shift.v[i]);
     }
     static int uni(int x) { return x; }   // device: v_readfirstlane (value is wave-uniform)
-    template <class T> static T *uni_ptr(T *p) { return p; }
 
     static vi lut(const int16_t *t, int n, const vi &idx) {
         vi r;

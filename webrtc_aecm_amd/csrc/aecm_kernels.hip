@@ -61,8 +61,11 @@ __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
 #define AECM_WAVES_PER_EU 7
 #endif
 #endif
+#ifndef AECM_MAX_WAVES_PER_EU
+#define AECM_MAX_WAVES_PER_EU 8
+#endif
 template <bool kFast, bool kHasClean>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, 8)))
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, const int32_t *blocks_per_stream) {
     FillLdsTables(st.consts);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -869,7 +869,7 @@ struct BlockEngine {
         // UpdateFarHistory (aecm_core.cc:125-138)
         u.hist_pos = u.hist_pos + 1;
         if (u.hist_pos >= kHistory) u.hist_pos = 0;
-        W::store_u16(W::uni_ptr(hist + u.hist_pos * kLanes), r.lane, xf.mag);
+        W::store_u16(hist + u.hist_pos * kLanes, r.lane, xf.mag);
         {
             int side = zext16(xf.mag64) | shl(xf.q, 16);
             if (u.hist_pos < 64) r.hq0 = W::writelane(r.hq0, side, u.hist_pos);
@@ -897,7 +897,7 @@ struct BlockEngine {
         const int far_q = sar(side, 16);
         const int far64 = zext16(side);
         vi far = xf.mag;
-        if (AECM_STEADY_ALWAYS(delay != 0)) far = W::load_u16(W::uni_ptr(hist + pos * kLanes), r.lane);
+        if (AECM_STEADY_ALWAYS(delay != 0)) far = W::load_u16(hist + pos * kLanes, r.lane);
 
         vi echo_est;
         int echo_est64;
@@ -1017,12 +1017,10 @@ struct BlockEngine {
     struct StridedIo {
         const IoView &v;
         int64_t base;
-        // block b of this stream starts at a wave-uniform address: scalar base + lane offset
-        template <class T> AECM_HD T *at(T *p, int b) const { return W::uni_ptr(p + base + (int64_t)b * v.block_stride); }
-        AECM_HD vi far(const Regs &r, int b) const { return W::load_i16(at(v.far, b), r.lane); }
-        AECM_HD vi near(const Regs &r, int b) const { return W::load_i16(at(v.near, b), r.lane); }
-        AECM_HD vi clean(const Regs &r, int b) const { return W::load_i16(at(v.near_clean, b), r.lane); }
-        AECM_HD void out(const Regs &r, int b, vi val) const { W::store_i16(at(v.out, b), r.brev, val); }
+        AECM_HD vi far(const Regs &r, int b) const { return W::load_i16(v.far + base + (int64_t)b * v.block_stride, r.lane); }
+        AECM_HD vi near(const Regs &r, int b) const { return W::load_i16(v.near + base + (int64_t)b * v.block_stride, r.lane); }
+        AECM_HD vi clean(const Regs &r, int b) const { return W::load_i16(v.near_clean + base + (int64_t)b * v.block_stride, r.lane); }
+        AECM_HD void out(const Regs &r, int b, vi val) const { W::store_i16(v.out + base + (int64_t)b * v.block_stride, r.brev, val); }
     };
     static AECM_HD void run_stream(const StatePtrs &st, const IoView &io, int64_t stream, int n_blocks) {
         StridedIo sio{io, stream * io.stream_stride};

@@ -94,14 +94,6 @@ struct Gfx950Wave {
     static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool is_first_lane() { return lane_id() == 0; }
     static __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
-    // A wave-uniform pointer, pinned to a scalar register pair: loads / stores through it use the "scalar base +
-    // 32-bit lane offset" addressing form instead of a 64-bit address per lane (two VGPRs and a 64-bit add each).
-    template <class T>
-    static __device__ __forceinline__ T *uni_ptr(T *p) {
-        const uint64_t a = reinterpret_cast<uint64_t>(p);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-        return reinterpret_cast<T *>(((uint64_t)hi << 32) | lo);
-    }
     static __device__ __forceinline__ void div_magic_lanes(int d, int &magic, int &shift) { div_magic(d, &magic, &shift); }
 
     // ---- tables ----
