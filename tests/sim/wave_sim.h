@@ -48,6 +48,7 @@ SIM_BIN(add, add(x, y))
 SIM_BIN(sub, sub(x, y))
 SIM_BIN(imin, imin(x, y))
 SIM_BIN(imax, imax(x, y))
+SIM_BIN(min_u32, min_u32(x, y))
 SIM_BIN(divi, divi(x, y))
 SIM_BIN(divu, divu(x, y))
 SIM_BIN(pack_hi16, pack_hi16(x, y))
@@ -73,6 +74,8 @@ SIM_UN(as_nonneg, as_nonneg(x))
 SIM_UN(zext16, zext16(x))
 SIM_UN(iabs, iabs(x))
 SIM_UN(clz32, clz32(x))
+SIM_UN(ffbh_i, ffbh_i(x))
+SIM_UN(low_mask, low_mask(x))
 SIM_UN(popc, popc(x))
 SIM_UN(pk_abs_sat_i16, pk_abs_sat_i16(x))
 SIM_UN(max_halves_i16, max_halves_i16(x))
@@ -156,7 +159,8 @@ struct SimWave {
     static constexpr bool kLaneConstsInTable = false;
     template <int ROW> static vi table_lane_const(const vi &) { return vi(0); }   // never used (kLaneConstsInTable == false)
     static vi table_index_for_this_block() { return vi(0); }
-    static void begin_block(int, int) {}                                   // device: issue-priority rotation
+    static void begin_block(int, int) {}
+    static int per_block(int x) { return x; }                              // device: keeps launch-invariant conditions in the loop                                   // device: issue-priority rotation
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
     static bool is_first_lane() { return true; }

@@ -211,13 +211,25 @@ AECM_HD int max_halves_i16(int a) { return imax(sext16(a), sar(a, 16)); }
 // ---- generic (scalar or lane-vector) helpers built on the overload set above --------------------
 // WebRtcSpl_NormU32 / NormW32 / NormW16 (aecm/spl_inl.h:97-111): leading zeros of a (0 for a == 0) /
 // redundant sign bits of a (0 for a == 0, 31 resp. 15 for a == -1).
+// v_ffbh_i32 / s_flbit_i32 ("leading bits equal to the sign bit", -1 for 0 and -1) has no clang builtin in this
+// toolchain; the LLVM intrinsic is reached through its assembler name.  The norms are built on its raw result:
+//   norm_w32(a)    = a == 0 ? 0 : min_u32(ffbh_i(a) - 1, 31)        (-1 - 1 wraps to a huge unsigned -> 31 for a == -1)
+//   norm_w16(a)    = the same - 16 for a in int16 range
+//   norm_u32_nn(a) = max(ffbh_i(a), 0) for an operand known to be >= 0 as a signed number (two instructions)
 #if defined(__HIP_DEVICE_COMPILE__)
+extern "C" __device__ int aecm_llvm_amdgcn_sffbh(int) __asm("llvm.amdgcn.sffbh.i32");
+AECM_HD int ffbh_i(int a) { return aecm_llvm_amdgcn_sffbh(a); }
 AECM_HD int norm_u32(int a) { return clz32(a) & 31; }          // clz32(0) == 32: "& 31" is the a == 0 case
 #else
+AECM_HD int ffbh_i(int a) { return (a == 0 || a == -1) ? -1 : __builtin_clz((unsigned)(a < 0 ? ~a : a)); }
 template <class I> AECM_HD I norm_u32(I a) { return sel(a == 0, I(0), clz32(a)); }
 #endif
-template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 1); }
-template <class I> AECM_HD I norm_w16(I a) { return sel(a == 0, I(0), clz32(sel(a < 0, ~a, a)) - 17); }
+AECM_HD int min_u32(int a, int b) { return (unsigned)a < (unsigned)b ? a : b; }
+template <class I> AECM_HD I norm_u32_nn(I a) { return imax(ffbh_i(as_nonneg(a)), I(0)); }
+template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), min_u32(ffbh_i(a) - 1, I(31))); }
+template <class I> AECM_HD I norm_w16(I a) { return sel(a == 0, I(0), min_u32(ffbh_i(a) - 1, I(31)) - 16); }
+// norm_w32 for an operand whose zero case the caller does not care about (result for 0 is 31)
+template <class I> AECM_HD I norm_w32_nz(I a) { return min_u32(ffbh_i(a) - 1, I(31)); }
 // High 32 bits of the signed 64-bit product                                  -> v_mul_hi_i32 / s_mul_hi_i32
 AECM_HD int mulhi_i32(int a, int b) { return (int)(((int64_t)a * (int64_t)b) >> 32); }
 // High 32 bits of the unsigned 64-bit product                                -> v_mul_hi_u32
@@ -259,9 +271,12 @@ template <class I, class C> AECM_HD I shift_i(I x, C c) { return sel(c >= 0, shl
 template <class I, class C> AECM_HD I shift_u(I x, C c) { return sel(c >= 0, shl(x, c), lsr(x, neg(c))); }
 // new = mean + ((new - mean) >> factor) with the shift applied to the magnitude
 // (WebRtc_MeanEstimatorFix, aecm/delay_estimator.cc:690-702).
+// (1 << width) - 1                                                            -> v_bfm_b32 / s_bfm_b32
+AECM_HD int low_mask(int width) { return (int)((1u << (width & 31)) - 1u); }
+// The shift truncates toward zero: (diff + (diff < 0 ? 2^factor - 1 : 0)) >> factor.
 template <class I, class C> AECM_HD I mean_step(I value, C factor, I mean) {
     I diff = sub(value, mean);
-    return add(mean, sel(diff < 0, neg(sar(neg(diff), factor)), sar(diff, factor)));
+    return add(mean, sar(add(diff, sar(diff, 31) & low_mask(factor)), factor));
 }
 
 }  // namespace aecm

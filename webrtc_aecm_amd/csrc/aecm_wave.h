@@ -162,6 +162,13 @@ struct BlockEngine {
         W::div_magic_lanes(r.lane + 1, r.lc[LC_DIV_MAGIC], r.lc[LC_DIV_SHIFT]);
     }
 
+    // The lane id for conditions inside the block loop: on the device a copy the compiler cannot see through, renewed
+    // every block (table_index), so that lane masks are compared where they are used (one VALU instruction) instead of
+    // being hoisted out of the loop into scalar register pairs that then spill (two v_readlane per use).
+    static AECM_HD vi lane_now(const Regs &r) {
+        if constexpr (W::kLaneConstsInTable) return r.table_index;
+        else return r.lane;
+    }
     // Per-lane constant of row ROW (hann rows are stored sign-extended).
     template <int ROW>
     static AECM_HD vi lane_const(const Regs &r) {
@@ -554,8 +561,8 @@ struct BlockEngine {
     template <class I>
     static AECM_HD void nlms_bin(BinState<I> &s, I far, I dfa, I div_magic_k, I div_shift_k, int dfa_noisy_q, int far_q,
                                  int mu) {
-        I zeros_ch = norm_u32(s.ch_adapt32);
-        I zeros_far = norm_u32(far);
+        I zeros_ch = norm_u32(s.ch_adapt32);                                                   // may be negative right after InitEchoPath
+        I zeros_far = norm_u32_nn(far);                                                        // far is a uint16
         I shift_ch_far = imax(I(32) - zeros_ch - zeros_far, I(0));                            // :836-850: 0 when zeros_ch + zeros_far > 31
         // shift_ch_far == 32 only for ch_adapt32 == 0 (norm 0 by convention) and far == 0: the product is 0 either way,
         // and sar() takes its count modulo 32, so the reference's "shift 0 when the norms sum to 0" needs no select
@@ -570,7 +577,7 @@ struct BlockEngine {
         u1 = shift_u(u1, xfa_q);                                                              // :869-872
         I u2 = shift_u(dfa, dfa_q);
         I t1 = sub(u2, u1);
-        zeros_num = norm_w32(t1);
+        zeros_num = norm_w32_nz(t1);                                                          // t1 == 0: no update, nothing below is used
         auto update = (t1 != 0) & (far > shl(I(kChannelVad), far_q));                         // :873
         I shift_num = imax(I(32) - (zeros_num + zeros_far), I(0));                            // :886-902: 0 when the sum > 31
         // |t1| < 2^30 (both aligned operands keep two bits of headroom, :852-872) and the shift above leaves the product
@@ -608,7 +615,7 @@ struct BlockEngine {
             if (u.far_log < u.fe_mse) u.mse_cnt = 0;                                          // :931-935
             else u.mse_cnt = sext16(u.mse_cnt + 1);
             if (AECM_STEADY_NEVER(u.mse_cnt >= (kMinMseCount + 10))) {                        // :937-983
-                vb first20 = r.lane < kMinMseCount;
+                vb first20 = lane_now(r) < kMinMseCount;
                 int mse_stored = W::reduce_add(sel(first20, iabs(r.stored_log - r.near_log), vi(0)));
                 int mse_adapt = W::reduce_add(sel(first20, iabs(r.adapt_log - r.near_log), vi(0)));
                 if (((shl(mse_stored, kMseResolution)) < (kMinMseDiff * mse_adapt)) &
@@ -887,7 +894,7 @@ struct BlockEngine {
         // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
         int delay = process_binary(r, binary_spectrum(r, df.mag, df.q, r.mean_near, u.near_init));
         if (delay == -2) delay = 0;                                                   // :479-483
-        if (u.fixed_delay >= 0) delay = u.fixed_delay;                                // :485-488
+        if (W::per_block(u.fixed_delay) >= 0) delay = u.fixed_delay;                  // :485-488
 
         AECM_PHASE_MARK(4, r.m0, r.mean_near);
         // AlignedFarend (aecm_core.cc:157-172)
@@ -915,15 +922,15 @@ struct BlockEngine {
         const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
 
         AECM_PHASE_MARK(8, hnl, r.b.near_filt);
-        if (AECM_STEADY_ALWAYS(u.mult == 2)) {                                        // :618-648
+        if (AECM_STEADY_ALWAYS(W::per_block(u.mult) == 2)) {                          // :618-648
             hnl = as_i16(sar(mul24(hnl, hnl), 14));
             hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
-            int avg = W::reduce_add(sel((r.lane >= 4) & (r.lane <= 24), hnl, vi(0)));
+            int avg = W::reduce_add(sel((lane_now(r) >= 4) & (lane_now(r) <= 24), hnl, vi(0)));
             avg = sext16(divi(avg, 21));
-            hnl = sel((r.lane >= 24) & (hnl > avg), vi(avg), hnl);
+            hnl = sel((lane_now(r) >= 24) & (hnl > avg), vi(avg), hnl);
             if (hnl64 > avg) hnl64 = avg;
         }
-        if (AECM_STEADY_ALWAYS(u.nlp)) {                                              // :651-686
+        if (AECM_STEADY_ALWAYS(W::per_block(u.nlp))) {                                // :651-686
             hnl = sel(hnl > kNlpCompHigh, vi(kOneQ14), sel(hnl < kNlpCompLow, vi(0), hnl));
             hnl64 = hnl64 > kNlpCompHigh ? kOneQ14 : (hnl64 < kNlpCompLow ? 0 : hnl64);
             if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
@@ -934,7 +941,7 @@ struct BlockEngine {
         int e_im64 = 0;
 
         AECM_PHASE_MARK(9, e_re, e_im);
-        if (AECM_STEADY_ALWAYS(u.cng == 1)) {                                         // :702-705
+        if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1)) {                           // :702-705
             int shift_n = sext16(15 - u.dfa_clean_q);
             int min_track = 9;
             if (AECM_STEADY_NEVER(u.noise_ctr < 100)) { u.noise_ctr = sext16(u.noise_ctr + 1); min_track = 6; }

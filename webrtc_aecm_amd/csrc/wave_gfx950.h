@@ -81,8 +81,16 @@ struct Gfx950Wave {
     // far apart and the tail of a launch runs at low occupancy (a launch whose waves all fit on the chip
     // at once lost 10-16 % to this).  Rotating the wave's issue priority every block, with a per-workgroup
     // offset, shares the ports evenly over time; neutral for many-round launches.
+    // A wave-uniform value the compiler must look at afresh in every block.  Conditions on launch-invariant
+    // configuration (mult, nlp, cng, ...) are otherwise hoisted out of the block loop as 64-bit lane masks, and with the
+    // scalar registers as full as they are here those masks get spilled to lanes of a VGPR and read back with two
+    // v_readlane -- VALU instructions -- per use; re-evaluating the condition is one scalar compare.
+    static __device__ __forceinline__ int per_block(int x) {
+        asm volatile("" : "+s"(x));
+        return x;
+    }
     static __device__ __forceinline__ void begin_block(int blk, int n_blocks) {
-        if (n_blocks < AECM_PRIORITY_ROTATION_MIN_BLOCKS) return;   // a 2-3 block tick launch is over before shares even out
+        if (per_block(n_blocks) < AECM_PRIORITY_ROTATION_MIN_BLOCKS) return;   // a 2-3 block tick launch is over before shares even out
         const unsigned h = (blockIdx.x * 2654435761u) >> 16;
         switch (((unsigned)blk + h) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
