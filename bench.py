@@ -273,10 +273,9 @@ def main():
         traffic, issue = load_profile_record(aecm.library_path(), workload_key)
         if args.variant != "fast" or args.clean:
             traffic, issue = None, None
-        try:
-            commit = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-        except Exception:
-            commit = None
+        from webrtc_aecm_amd import build as _b
+        bi = _b.build_info()                       # written next to the library when it was built (no .git on the GPU box)
+        commit = (bi.get("commit") or "unknown") + ("+dirty" if bi.get("dirty") else "")
         res = {
             "metric": "AECM frames/sec (64-sample @16kHz) per GPU; bit-exact vs aecm_core_c.cc",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,

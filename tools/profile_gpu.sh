@@ -23,7 +23,9 @@ import webrtc_aecm_amd as aecm
 from webrtc_aecm_amd import isa_census
 lib = aecm.load()
 c = isa_census.census(aecm.library_path())
-commit = subprocess.run(["git", "-C", "$R", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+from webrtc_aecm_amd import build as _b
+bi = _b.build_info()
+commit = (bi.get("commit") or "unknown") + ("+dirty" if bi.get("dirty") else "")
 print(json.dumps({"state_size_bytes": lib.WebRtcAecmBatch_state_size_bytes(), "kernel_fingerprint": c["fingerprint"],
                   "static_counts": c["counts"], "static_valu_fast_class": c["valu_fast_class"], "commit": commit or None}))
 PY

@@ -124,12 +124,16 @@ if tick_stats.exists():
             for k, v in agg(SRC / d / "tick_counter_collection.csv", sub).items():
                 tf[f"{sub}:{k}"] = v
     tick["pmc_avg_per_launch"] = tf
-    if "aecm_process:FETCH_SIZE" in tf and "aecm_process:WRITE_SIZE" in tf:
-        rd = tf["aecm_process:FETCH_SIZE"] * 1024 * fetch_factor
-        wr = tf["aecm_process:WRITE_SIZE"] * 1024
-        avg_ns = next(float(r[3]) for r in trows[1:] if "aecm_process_kernel" in r[0])
-        tick["block_kernel"] = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "avg_ms": avg_ns / 1e6,
-                                "hbm_GBps": (rd + wr) / (avg_ns / 1e9) / 1e9, "hbm_frac_of_8TBps": (rd + wr) / (avg_ns / 1e9) / 8e12}
+    # the kernel that runs the tick's blocks: the lean one-launch tick kernel, or the block kernel of the three-launch form
+    for sub, pat in (("aecm_tick", "aecm_tick_lean"), ("aecm_process", "aecm_process_kernel")):
+        if f"{sub}:FETCH_SIZE" in tf and f"{sub}:WRITE_SIZE" in tf and any(pat in r[0] for r in trows[1:]):
+            rd = tf[f"{sub}:FETCH_SIZE"] * 1024 * fetch_factor
+            wr = tf[f"{sub}:WRITE_SIZE"] * 1024
+            avg_ns = next(float(r[3]) for r in trows[1:] if pat in r[0])
+            tick["block_kernel"] = {"kernel": pat, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "avg_ms": avg_ns / 1e6,
+                                    "hbm_GBps": (rd + wr) / (avg_ns / 1e9) / 1e9, "hbm_frac_of_8TBps": (rd + wr) / (avg_ns / 1e9) / 8e12,
+                                    "bytes_per_session_tick": (rd + wr) / 65536}
+            break
     tick["gpu_ms_per_tick_sum_of_kernels"] = per_tick_ns / 1e6
     try:
         tick["bench_sessions_line"] = json.loads([ln for ln in (SRC / "prof_tick.log").read_text().splitlines() if ln.startswith("{")][-1])

@@ -40,6 +40,31 @@ def _compile_flags():
     return [f for f in HIPCC_FLAGS if f != "-shared"]
 
 
+BUILD_INFO = LIB_DIR / "BUILD_INFO.json"
+
+
+def _write_build_info():
+    """Which commit the libraries were built from (the GPU box receives the tree without .git)."""
+    import json
+    info = {"commit": None, "dirty": None}
+    try:
+        root = PKG.parent
+        info["commit"] = subprocess.run(["git", "-C", str(root), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        info["dirty"] = bool(subprocess.run(["git", "-C", str(root), "status", "--porcelain", "--", "webrtc_aecm_amd", "include"],
+                                            capture_output=True, text=True).stdout.strip())
+    except Exception:
+        pass
+    BUILD_INFO.write_text(json.dumps(info))
+
+
+def build_info():
+    import json
+    try:
+        return json.loads(BUILD_INFO.read_text())
+    except Exception:
+        return {"commit": None, "dirty": None}
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP/C++ source of the engine for gfx950 (one hipcc -c per source, in parallel) and link the
     shipped library, its audit twin and the CLI.
@@ -86,6 +111,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                 print(" ".join(cli), flush=True)
             subprocess.check_call(cli, cwd=str(CSRC))
             os.replace(tmp_cli, CLI)
+            _write_build_info()
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
