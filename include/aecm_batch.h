@@ -140,7 +140,14 @@ int32_t WebRtcAecmSessions_TickPerSessionHost(AecmSessions *s, const int16_t *fa
  * WebRtcAecm_BufferFarend call in this tick (far-end underrun; its WebRtcAecm_Process then replays the previous
  * far frame, reference echo_control_mobile.cc:369-380) -- its far row is ignored.  Sessions with different
  * flag histories live in different flow classes, exactly like different msInSndCardBuf histories. */
-enum { AECM_SESSION_NO_FAREND = 1 };
+enum {
+    AECM_SESSION_NO_FAREND = 1,
+    /* 160-sample ticks only: this session makes TWO WebRtcAecm_BufferFarend + WebRtcAecm_Process call pairs of 80 samples
+     * in this tick (first half, then second half of its rows) instead of one pair of 160 samples -- sessions with
+     * different call sizes in one object (the reference treats the two cadences differently,
+     * echo_control_mobile.cc:282-283, 384-385).  codes_host then receives the first non-zero code of the two calls. */
+    AECM_SESSION_SPLIT_CALLS = 2
+};
 int32_t WebRtcAecmSessions_TickFlags(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
                                      const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples,
                                      const int16_t *msInSndCardBuf_host, const uint8_t *flags_host, int32_t *codes_host);

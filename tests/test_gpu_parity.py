@@ -950,3 +950,50 @@ def test_device_precondition_audit_build(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "AUDIT 0 0" in r.stdout, r.stdout[-500:]
+
+
+@_needs_ref
+def test_mixed_call_cadence_in_one_session_batch():
+    """Sessions with different call sizes in ONE streaming object (reference: every instance may use 80- or 160-sample
+    calls, echo_control_mobile.cc:268,282): on 160-sample ticks some sessions make two 80-sample BufferFarend + Process
+    pairs (AECM_SESSION_SPLIT_CALLS), the others one 160-sample pair, with per-session delays, underruns and a
+    saturating delay report; every session equals a reference session that received exactly those calls."""
+    for fs in (16000, 8000):
+        S, n = 8, 160
+        n_ticks = 3 * fs // n
+        pairs = [synth_pair(1200 + k, n_ticks * n // 64 + 1, fs, "mixed") for k in range(S)]
+        far = np.stack([p[0][:n_ticks * n] for p in pairs])
+        near = np.stack([p[1][:n_ticks * n] for p in pairs])
+        refs = [pyoracle.RefSession(fs, 1, 2) for _ in range(S)]
+        sb = aecm.AecmSessions(S, fs, 1, 2)
+        split = np.array([0, 1, 0, 1, 1, 0, 1, 0], dtype=bool)
+        base_ms = np.array([40, 40, 60, 90, 500, 500, 25, 40], dtype=np.int16)     # 500 ms: the jitter buffer saturates and drops
+        for i in range(n_ticks):
+            sl = slice(i * n, (i + 1) * n)
+            fl = np.where(split, aecm.ffi.SESSION_SPLIT_CALLS, 0).astype(np.uint8)
+            if i % 41 == 40:
+                fl[[1, 2]] |= aecm.ffi.SESSION_NO_FAREND
+            if i == n_ticks // 2:                                  # cadence changes mid-run for two sessions
+                split[0], split[1] = True, False
+            rc, out, codes = sb.tick_host_per_session(far[:, sl], near[:, sl], base_ms, flags=fl)
+            for k in range(S):
+                if fl[k] & aecm.ffi.SESSION_SPLIT_CALLS:
+                    first = 0
+                    for h in (0, 80):
+                        if not fl[k] & aecm.ffi.SESSION_NO_FAREND:
+                            assert refs[k].buffer_farend(far[k, sl][h:h + 80]) == 0
+                        rc1, o1 = refs[k].process(near[k, sl][h:h + 80], None, int(base_ms[k]))
+                        first = first or rc1
+                        assert np.array_equal(out[k, h:h + 80], o1), (fs, i, k, h)
+                    assert codes[k] == first, (fs, i, k)
+                else:
+                    if not fl[k] & aecm.ffi.SESSION_NO_FAREND:
+                        assert refs[k].buffer_farend(far[k, sl]) == 0
+                    rc1, o1 = refs[k].process(near[k, sl], None, int(base_ms[k]))
+                    assert codes[k] == rc1 and np.array_equal(out[k], o1), (fs, i, k)
+        sb.close()
+    sb = aecm.AecmSessions(2, 16000)
+    z = np.zeros((2, 80), np.int16)
+    rc, _, _ = sb.tick_host_per_session(z, z, np.array([40, 40], np.int16), flags=np.array([aecm.ffi.SESSION_SPLIT_CALLS, 0], np.uint8))
+    assert rc == aecm.ffi.AECM_BAD_PARAMETER_ERROR                  # two 80-sample calls need a 160-sample tick
+    sb.close()

@@ -129,6 +129,8 @@ struct TickLeanEntry {
     int32_t n_blocks;                // blocks of this tick (<= 4)
     int32_t n_far;                   // how many of the tick's far samples the jitter buffer accepted (the first n_far)
     int32_t n_frames;                // output frames of 80 samples (1 or 2)
+    int32_t far2_src, far2_cnt;      // a second accepted piece of the far row (two 80-sample calls, the first one cut short
+                                     // by a full jitter buffer): input samples [far2_src, far2_src + far2_cnt) follow the first n_far
     int32_t reserved;
     int64_t far_pos, out_pos;        // where the accepted far samples / this tick's block outputs go in their rings
     TickRuns far[4], near[4];        // per block

@@ -484,8 +484,10 @@ __device__ __forceinline__ void TickSessionLean(const StatePtrs &st, const TickI
     int16_t *out = io.out + s * io.io_stride;
     // 1. the tick's samples into the rings
     const int far_pos = (int)e->far_pos, near_pos = (int)io.near_pos, n_far = e->n_far, n = io.n;
+    const int far2_src = e->far2_src, far2_cnt = e->far2_cnt;
     for (int j = lane; j < n; j += 64) {
         if (j < n_far) fr[(far_pos + j) & mask] = fin[j];
+        else if (j >= far2_src && j < far2_src + far2_cnt) fr[(far_pos + n_far + (j - far2_src)) & mask] = fin[j];
         nr[(near_pos + j) & mask] = nin[j];
         if (kHasClean) cr[(near_pos + j) & mask] = cin[j];
     }

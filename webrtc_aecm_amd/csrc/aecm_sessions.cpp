@@ -221,7 +221,7 @@ int32_t SessionBatch::Regroup(const int16_t *ms_per_session, int16_t ms_uniform,
     std::vector<int32_t> key(S);
     for (size_t s = 0; s < S; ++s) {
         const int32_t ms = (uint16_t)(ms_per_session ? ms_per_session[s] : ms_uniform);
-        key[s] = ms | (flags_per_session && (flags_per_session[s] & kNoFarend) ? 1 << 16 : 0);
+        key[s] = ms | (flags_per_session ? (int32_t)(flags_per_session[s] & (kNoFarend | kSplitCalls)) << 16 : 0);
     }
     if (last_key_ == key) {                                                     // same grouping as last tick
         return 0;
@@ -240,7 +240,8 @@ int32_t SessionBatch::Regroup(const int16_t *ms_per_session, int16_t ms_uniform,
             id = (int32_t)next.size();
             next.push_back(classes_[old]);           // the flow state before this tick
             next.back().ms = (int16_t)(uint16_t)(key[s] & 0xffff);
-            next.back().no_far = (key[s] >> 16) != 0;
+            next.back().no_far = ((key[s] >> 16) & kNoFarend) != 0;
+            next.back().split_calls = ((key[s] >> 16) & kSplitCalls) != 0;
             next.back().members = 0;
             children[old].push_back({key[s], id});
         }
@@ -260,46 +261,61 @@ int32_t SessionBatch::Regroup(const int16_t *ms_per_session, int16_t ms_uniform,
 // not fit, and may then re-read arbitrarily old content for ever: in accepted-sample time that content
 // is never more than the buffer's 4000 samples away, so it always sits inside the device ring).
 int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, TickLeanEntry *lean, bool *lean_ok,
-                                   bool *stale) {
+                                   bool *coded_ok, bool *stale) {
     memset(lean, 0, sizeof *lean);
     lean->far_pos = c.far_count;
     lean->out_pos = c.blocks_done * kBlock;
     lean->n_frames = n / kTickFrame;
     for (int f = 0; f < 2; ++f) { lean->out[f].n = 1; lean->out[f].end[0] = kTickFrame; lean->out[f].off[0] = kTickRunZero; }
-    int64_t far_tags[kTickMaxSamples], near_tags[kTickMaxSamples], out_tags[kTickMaxSamples];
-    for (int i = 0; i < n; ++i) { far_tags[i] = c.far_count + i; near_tags[i] = near_pos_ + i; }
     entry->n_block_samples = 0;
     entry->n_far = 0;
     entry->far_pos = c.far_count;
     entry->out_pos = c.blocks_done * kBlock;
     for (int i = 0; i < n; ++i) entry->assemble.out[i] = -1;
-    int32_t rc = 0;
-    const int64_t far_first = c.far_count;
-    if (!c.no_far) {                                       // far-end underrun: no BufferFarend call in this tick
-        rc = c.flow.BufferFarend(far_tags, (size_t)n);
-        if (rc != 0) return rc;
-        entry->n_far = (int32_t)c.flow.last_far_accepted();
-        c.far_count += entry->n_far;
+    // The tick's calls: one BufferFarend + Process of n samples, or (split_calls, n = 160) two of 80 samples.
+    const int n_calls = c.split_calls ? 2 : 1, per_call = n / n_calls;
+    const int64_t far_first = c.far_count, out_first = c.blocks_done * kBlock;
+    int64_t out_tags[kTickMaxSamples], blk_far[kTickMaxBlockSamples], blk_near[kTickMaxBlockSamples];
+    int n_blocks = 0, accepted[2] = {0, 0};
+    int32_t rc_all = 0;
+    for (int k = 0; k < n_calls; ++k) {
+        int64_t far_tags[kTickMaxSamples], near_tags[kTickMaxSamples];
+        for (int i = 0; i < per_call; ++i) { far_tags[i] = c.far_count + i; near_tags[i] = near_pos_ + k * per_call + i; }
+        if (!c.no_far) {                                   // far-end underrun: no BufferFarend call in this tick
+            const int32_t rc = c.flow.BufferFarend(far_tags, (size_t)per_call);
+            if (rc != 0) return rc;
+            accepted[k] = (int)c.flow.last_far_accepted();
+            c.far_count += accepted[k];
+        }
+        bool passthrough = false;
+        const int64_t out_base = out_first + (int64_t)n_blocks * kBlock;
+        int got = 0;
+        int64_t *out_k = out_tags + k * per_call;
+        // the clean near-end is positioned exactly like the noisy one: it shares the near tags
+        const int32_t rc = c.flow.Process(near_tags, has_clean ? near_tags : nullptr, out_k, (size_t)per_call, c.ms,
+                                          [&](const int64_t *fb, const int64_t *nb, const int64_t *, int64_t *ob, int nblk) {
+                                              memcpy(blk_far + n_blocks * kBlock, fb, sizeof(int64_t) * nblk * kBlock);
+                                              memcpy(blk_near + n_blocks * kBlock, nb, sizeof(int64_t) * nblk * kBlock);
+                                              for (int j = 0; j < nblk * kBlock; ++j) ob[j] = out_base + j;
+                                              got = nblk;
+                                              return true;
+                                          },
+                                          &passthrough);
+        if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) return rc;   // nothing processed; the rings still take the samples
+        if (rc != 0 && rc_all == 0) rc_all = rc;
+        if (passthrough)
+            for (int i = 0; i < per_call; ++i) out_k[i] = -(out_k[i] + 2);
+        n_blocks += got;
     }
-    int64_t blk_far[kTickMaxBlockSamples], blk_near[kTickMaxBlockSamples];
-    int n_blocks = 0;
-    bool passthrough = false;
-    const int64_t out_base = c.blocks_done * kBlock;
-    // the clean near-end is positioned exactly like the noisy one: it shares the near tags
-    rc = c.flow.Process(near_tags, has_clean ? near_tags : nullptr, out_tags, (size_t)n, c.ms,
-                        [&](const int64_t *fb, const int64_t *nb, const int64_t *, int64_t *ob, int nblk) {
-                            memcpy(blk_far, fb, sizeof(int64_t) * nblk * kBlock);
-                            memcpy(blk_near, nb, sizeof(int64_t) * nblk * kBlock);
-                            for (int k = 0; k < nblk * kBlock; ++k) ob[k] = out_base + k;
-                            n_blocks = nblk;
-                            return true;
-                        },
-                        &passthrough);
-    if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) return rc;      // nothing processed; the rings still take the samples
-    if (passthrough)
-        for (int i = 0; i < n; ++i) out_tags[i] = -(out_tags[i] + 2);
+    // what the far ring takes: the accepted samples of each call (a saturated jitter buffer drops the rest)
+    lean->n_far = accepted[0];
+    if (n_calls == 2) {
+        if (accepted[0] == per_call) lean->n_far += accepted[1];                 // contiguous
+        else { lean->far2_src = per_call; lean->far2_cnt = accepted[1]; *coded_ok = false; }   // the coded forms index the input row by tag
+    }
+    entry->n_far = lean->n_far;
     const int nbs = n_blocks * kBlock;
-    const int64_t far_end = c.far_count, near_end = near_pos_ + n, out_end = out_base + nbs;
+    const int64_t far_end = c.far_count, near_end = near_pos_ + n, out_end = out_first + nbs;
     auto code = [&](int64_t tag, int64_t first_of_tick, int64_t end, int kind_now, int kind_ring) -> int32_t {
         if (tag < 0) return -1;
         if (end - tag > kRing) *stale = true;           // every tag must still be inside its ring
@@ -312,14 +328,13 @@ int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClas
     }
     for (int i = 0; i < n; ++i) {
         const int64_t v = out_tags[i];
-        entry->assemble.out[i] = v >= 0    ? code(v, out_base, out_end, kTickFromInput, kTickFromRing)
+        entry->assemble.out[i] = v >= 0    ? code(v, out_first, out_end, kTickFromInput, kTickFromRing)
                                  : v <= -2 ? code(-v - 2, near_pos_, near_end, kTickNearInput, kTickNearRing)
                                            : -1;
     }
     entry->n_block_samples = nbs;
     // the same tick as run descriptions (lean one-launch form)
     lean->n_blocks = n_blocks;
-    lean->n_far = entry->n_far;
     for (int b = 0; b < n_blocks; ++b)
         if (!BuildRuns(blk_far + b * kBlock, kBlock, kRing, kTickFromRing, &lean->far[b]) ||
             !BuildRuns(blk_near + b * kBlock, kBlock, kRing, kTickFromRing, &lean->near[b]))
@@ -327,7 +342,7 @@ int32_t SessionBatch::AdvanceClass(FlowClass &c, int n, bool has_clean, TickClas
     for (int f = 0; f < n / kTickFrame; ++f)
         if (!BuildRuns(out_tags + f * kTickFrame, kTickFrame, kRing, kTickFromRing, &lean->out[f])) *lean_ok = false;
     c.blocks_done += n_blocks;
-    return rc;
+    return rc_all;
 }
 
 int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
@@ -348,20 +363,23 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
             return AECM_UNSPECIFIED_ERROR;
     }
     // 1. which class every session is in for this tick
+    if (flags_per_session && n != 160)
+        for (int s = 0; s < S; ++s)
+            if (flags_per_session[s] & kSplitCalls) return AECM_BAD_PARAMETER_ERROR;      // two 80-sample calls need 160 samples
     if (ms_per_session || flags_per_session) {
         if (int32_t rc = Regroup(ms_per_session, ms, flags_per_session)) return rc;
     } else {
-        for (FlowClass &c : classes_) { c.ms = ms; c.no_far = false; }
+        for (FlowClass &c : classes_) { c.ms = ms; c.no_far = false; c.split_calls = false; }
         last_key_.clear();
     }
     const int n_classes = (int)classes_.size();
     // 2. the session machinery of every class in the index domain (the table is read by the previous tick's
     //    kernels until they finish: every tick ends with a stream synchronisation)
-    bool stale = false, lean_ok = true;
+    bool stale = false, lean_ok = true, coded_ok = true;
     std::vector<int32_t> class_rc((size_t)n_classes, 0);
     int32_t first_rc = 0, max_nbs = 0;
     for (int k = 0; k < n_classes; ++k) {
-        class_rc[k] = AdvanceClass(classes_[k], n, clean != nullptr, &table_host_[k], &lean_host_[k], &lean_ok, &stale);
+        class_rc[k] = AdvanceClass(classes_[k], n, clean != nullptr, &table_host_[k], &lean_host_[k], &lean_ok, &coded_ok, &stale);
         if (class_rc[k] != 0 && first_rc == 0) first_rc = class_rc[k];
         max_nbs = std::max(max_nbs, table_host_[k].n_block_samples);
     }
@@ -396,6 +414,10 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
     bool ok = true;
     TickMode mode = ChooseTickMode(S);
     if (mode == kTickLean && (!lean_ok || engine_->variant() != kVariantFast)) mode = S < 32768 ? kTickFused : kTickThreeLaunch;
+    if (mode != kTickLean && !coded_ok) {
+        if (!lean_ok || engine_->variant() != kVariantFast) return fail();     // no form can express this tick (never seen in practice)
+        mode = kTickLean;
+    }
     if (n_classes > 1) {
         if (class_of_dirty_) {
             ok = AECM_HIP_OK(hipMemcpyAsync(class_of_dev_, class_of_.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, st));

@@ -52,7 +52,10 @@ public:
     //     reference echo_control_mobile.cc:369-380); its far row is ignored.
     int32_t Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
                  int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers);
-    static constexpr uint8_t kNoFarend = 1;
+    //     bit 1 (kSplitCalls, 160-sample ticks only) = this session makes TWO BufferFarend + Process call pairs of 80
+    //     samples in this tick instead of one of 160 (the reference treats the two cadences differently:
+    //     echo_control_mobile.cc:282-283, 384-385).
+    static constexpr uint8_t kNoFarend = 1, kSplitCalls = 2;
     int num_flow_classes() const { return (int)classes_.size(); }
 
     static constexpr int kMaxFlowClasses = 1024;
@@ -66,6 +69,7 @@ private:
         int64_t far_count = 0;   // far samples its jitter buffer has accepted so far = the next far tag
         int16_t ms = 0;          // this tick's msInSndCardBuf
         bool no_far = false;     // this tick: no BufferFarend call
+        bool split_calls = false;   // this tick: two calls of 80 samples instead of one of 160
         int64_t born = -1;       // tick at which InitSession created it (-1: from Init); fresh sessions of one tick share a class
         int32_t members = 0;
         FlowClass() : flow(-1) {}
@@ -74,7 +78,7 @@ private:
     int32_t Regroup(const int16_t *ms_per_session, int16_t ms_uniform, const uint8_t *flags_per_session);
     void DropEmptyClasses();
     int32_t CheckSession(int session) const;
-    int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, TickLeanEntry *lean, bool *lean_ok, bool *stale);
+    int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, TickLeanEntry *lean, bool *lean_ok, bool *coded_ok, bool *stale);
     enum TickMode { kTickLean, kTickFused, kTickThreeLaunch };
     static TickMode ChooseTickMode(int num_streams);
     static constexpr int64_t kRing = 8192;     // >= 4000 (jitter buffer) + 160 + 144 + stale re-reads; power of two

@@ -50,6 +50,7 @@ SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_GetEchoPath", "WebRtcAecmSessions_num_flow_classes",
 ]
 SESSION_NO_FAREND = 1
+SESSION_SPLIT_CALLS = 2
 
 
 class AecmConfig(C.Structure):
