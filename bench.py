@@ -186,8 +186,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (BASELINE config 3: 65536)")
-    ap.add_argument("--blocks", type=int, default=1024,
-                    help="blocks per stream per step (one launch); 1024 makes a 20-step timed region >= 2 s at 65536 streams")
+    ap.add_argument("--blocks", type=int, default=1280,
+                    help="blocks per stream per step (one launch); 1280 makes a 20-step timed region >= 2 s at 65536 streams")
     ap.add_argument("--total-streams", type=int, default=0,
                     help="strong scaling: this many streams in total, split evenly over the GPUs (overrides --streams)")
     ap.add_argument("--clean", action="store_true",

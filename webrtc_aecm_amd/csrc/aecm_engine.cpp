@@ -33,8 +33,8 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
               AECM_HIP_OK(hipMalloc((void **)&e->consts_dev_, kConstBlobWords * sizeof(uint32_t))) &&
               true;                                   // the timing events are created on first use (ProcessBlocks)
     if (ok) {
-        std::vector<uint32_t> blob;
-        BuildKernelConstants(&blob);
+        // the 20 KB constants blob is built once per process (every WebRtcAecm_Create makes an engine of its own)
+        static const std::vector<uint32_t> blob = [] { std::vector<uint32_t> b; BuildKernelConstants(&b); return b; }();
         ok = AECM_HIP_OK(hipMemcpy(e->consts_dev_, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         e->st_.consts = e->consts_dev_;
     }
@@ -399,17 +399,19 @@ void BatchEngine::ResetTimers() {
 bool BatchEngine::SetEchoPath(int stream, const int16_t path[kBins]) {
     if (stream < 0 || stream >= num_streams_) return false;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
-    // Read-modify-write of the three touched regions of one stream (rare, host-driven).
-    std::vector<uint32_t> vec(kVecWordsPerStream);
-    std::vector<int32_t> scal(kNumScal);
+    // WebRtcAecm_InitEchoPathCore touches the two channel words of the lane-vector image and seven scalars: write
+    // exactly those (two 256-byte rows + one scalar patch), in stream order after whatever is still running.
+    std::vector<uint32_t> vec(kVecWordsPerStream, 0u);
+    int32_t scal[kNumScal] = {0};
+    aecm::SetEchoPath(vec.data(), scal, path);
     uint32_t *dvec = st_.vec + (size_t)stream * kVecWordsPerStream;
-    int32_t *dscal = st_.scal + (size_t)stream * kNumScal;
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
-    if (!AECM_HIP_OK(hipMemcpy(vec.data(), dvec, vec.size() * sizeof(uint32_t), hipMemcpyDeviceToHost))) return false;
-    if (!AECM_HIP_OK(hipMemcpy(scal.data(), dscal, scal.size() * sizeof(int32_t), hipMemcpyDeviceToHost))) return false;
-    aecm::SetEchoPath(vec.data(), scal.data(), path);
-    if (!AECM_HIP_OK(hipMemcpy(dvec, vec.data(), vec.size() * sizeof(uint32_t), hipMemcpyHostToDevice))) return false;
-    return AECM_HIP_OK(hipMemcpy(dscal, scal.data(), scal.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!AECM_HIP_OK(hipMemcpyAsync(dvec + V_CH16 * kLanes, vec.data() + V_CH16 * kLanes, kLanes * sizeof(uint32_t), hipMemcpyHostToDevice, stream_)) ||
+        !AECM_HIP_OK(hipMemcpyAsync(dvec + V_CH32 * kLanes, vec.data() + V_CH32 * kLanes, kLanes * sizeof(uint32_t), hipMemcpyHostToDevice, stream_)))
+        return false;
+    const int32_t fields[7] = {S_B64_CHSTORED, S_B64_CHADAPT16, S_B64_CHADAPT32, S_MSE_ADAPT_OLD, S_MSE_STORED_OLD, S_MSE_THRESH, S_MSECNT};
+    int32_t values[7];
+    for (int i = 0; i < 7; ++i) values[i] = scal[fields[i]];
+    return PatchScalars(fields, values, 7, stream, 1);          // synchronises the stream (vec goes out of scope)
 }
 
 bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
