@@ -49,6 +49,8 @@ SIM_BIN(sub, sub(x, y))
 SIM_BIN(imin, imin(x, y))
 SIM_BIN(imax, imax(x, y))
 SIM_BIN(min_u32, min_u32(x, y))
+SIM_BIN(shift_u31, shift_u31(x, y))
+SIM_BIN(shift_i31, shift_i31(x, y))
 SIM_BIN(divi, divi(x, y))
 SIM_BIN(divu, divu(x, y))
 SIM_BIN(pack_hi16, pack_hi16(x, y))

@@ -205,6 +205,30 @@ KERNEL_SCLOB(k_addsgpr, "v_add_u32 %0, s20, %0\n v_add_u32 %1, s20, %1\n v_add_u
                         "v_add_u32 %4, s20, %4\n v_add_u32 %5, s20, %5\n v_add_u32 %6, s20, %6\n v_add_u32 %7, s20, %7\n")        // SGPR operand
 KERNEL_SCLOB(k_nop, "s_nop 0\n v_perm_b32 %0, %0, %8, %9\n s_nop 0\n v_perm_b32 %1, %1, %8, %9\n s_nop 0\n v_perm_b32 %2, %2, %8, %9\n s_nop 0\n v_perm_b32 %3, %3, %8, %9\n")
 
+// ---- fourth batch: 64-bit shifts (candidates for "shift by a signed count" in one instruction) ------------------
+#define KERNEL64(NAME, ASM4)                                                                   \
+    __global__ __launch_bounds__(256) void NAME(int *out, int iters) {                         \
+        long long a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 ^ 5, a3 = a0 + 7;                 \
+        int c = (threadIdx.x & 7) + 1;                                                         \
+        for (int it = 0; it < iters; ++it) {                                                   \
+            _Pragma("unroll") for (int r = 0; r < 64; ++r) { asm volatile(ASM4 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c)); } \
+        }                                                                                      \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (int)(a0 + a1 + a2 + a3);                 \
+    }
+KERNEL64(k_lshr64, "v_lshrrev_b64 %0, %4, %0\n v_lshrrev_b64 %1, %4, %1\n v_lshrrev_b64 %2, %4, %2\n v_lshrrev_b64 %3, %4, %3\n"
+                   "v_lshrrev_b64 %0, %4, %0\n v_lshrrev_b64 %1, %4, %1\n v_lshrrev_b64 %2, %4, %2\n v_lshrrev_b64 %3, %4, %3\n")
+KERNEL64(k_ashr64, "v_ashrrev_i64 %0, %4, %0\n v_ashrrev_i64 %1, %4, %1\n v_ashrrev_i64 %2, %4, %2\n v_ashrrev_i64 %3, %4, %3\n"
+                   "v_ashrrev_i64 %0, %4, %0\n v_ashrrev_i64 %1, %4, %1\n v_ashrrev_i64 %2, %4, %2\n v_ashrrev_i64 %3, %4, %3\n")
+KERNEL64(k_lshl64, "v_lshlrev_b64 %0, %4, %0\n v_lshlrev_b64 %1, %4, %1\n v_lshlrev_b64 %2, %4, %2\n v_lshlrev_b64 %3, %4, %3\n"
+                   "v_lshlrev_b64 %0, %4, %0\n v_lshlrev_b64 %1, %4, %1\n v_lshlrev_b64 %2, %4, %2\n v_lshlrev_b64 %3, %4, %3\n")
+KERNEL(k_alignbit_v, "v_alignbit_b32 %0, %0, %8, %9\n v_alignbit_b32 %1, %1, %8, %9\n v_alignbit_b32 %2, %2, %8, %9\n v_alignbit_b32 %3, %3, %8, %9\n"
+                     "v_alignbit_b32 %4, %4, %8, %9\n v_alignbit_b32 %5, %5, %8, %9\n v_alignbit_b32 %6, %6, %8, %9\n v_alignbit_b32 %7, %7, %8, %9\n")
+KERNEL(k_mulhi_i, "v_mul_hi_i32 %0, %0, %8\n v_mul_hi_i32 %1, %1, %8\n v_mul_hi_i32 %2, %2, %8\n v_mul_hi_i32 %3, %3, %8\n"
+                  "v_mul_hi_i32 %4, %4, %8\n v_mul_hi_i32 %5, %5, %8\n v_mul_hi_i32 %6, %6, %8\n v_mul_hi_i32 %7, %7, %8\n")
+KERNEL(k_ffbh_i, "v_ffbh_i32 %0, %0\n v_ffbh_i32 %1, %1\n v_ffbh_i32 %2, %2\n v_ffbh_i32 %3, %3\n v_ffbh_i32 %4, %4\n v_ffbh_i32 %5, %5\n v_ffbh_i32 %6, %6\n v_ffbh_i32 %7, %7\n")
+KERNEL(k_bfm, "v_bfm_b32 %0, %0, %8\n v_bfm_b32 %1, %1, %8\n v_bfm_b32 %2, %2, %8\n v_bfm_b32 %3, %3, %8\n v_bfm_b32 %4, %4, %8\n v_bfm_b32 %5, %5, %8\n v_bfm_b32 %6, %6, %8\n v_bfm_b32 %7, %7, %8\n")
+KERNEL(k_cvtrcp, "v_cvt_f32_u32 %0, %0\n v_rcp_iflag_f32 %0, %0\n v_cvt_f32_u32 %1, %1\n v_rcp_iflag_f32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_rcp_iflag_f32 %2, %2\n v_cvt_f32_u32 %3, %3\n v_rcp_iflag_f32 %3, %3\n")
+
 typedef void (*kern_t)(int *, int);
 static void run(const char *name, kern_t fn, int waves_per_simd, double extra_per_8 = 0) {
     int *out;
@@ -253,6 +277,16 @@ int main(int argc, char **argv) {
         {"dependent v_add chain", k_dep_add, 0}, {"dependent v_lshl chain", k_dep_shl, 0}, {"s_add_u32", k_salu, 0},
         {"v_lshl + s_add interleaved (per pair)", k_valu_salu, -4},
     };
+    if (argc > 1 && !strcmp(argv[1], "--batch4")) {
+        struct { const char *n; kern_t f; double extra; } t4[] = {
+            {"v_lshrrev_b64", k_lshr64, 0}, {"v_ashrrev_i64", k_ashr64, 0}, {"v_lshlrev_b64", k_lshl64, 0},
+            {"v_alignbit_b32 (vgpr shift)", k_alignbit_v, 0}, {"v_mul_hi_i32", k_mulhi_i, 0}, {"v_ffbh_i32", k_ffbh_i, 0},
+            {"v_bfm_b32", k_bfm, 0}, {"v_cvt_f32_u32 + v_rcp_iflag_f32 (per pair)", k_cvtrcp, -4},
+        };
+        for (int w : {7})
+            for (auto &e : t4) run(e.n, e.f, w, e.extra);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "--batch3")) {
         // extra = instructions per unrolled body - 8
         struct { const char *n; kern_t f; double extra; } t3[] = {

@@ -18,6 +18,10 @@ namespace aecm {
     fprintf(stderr, "aecm: as_i16 precondition violated (%d)\n", v);
     abort();
 }
+[[noreturn]] void aecm_shift_range_violation(int c) {
+    fprintf(stderr, "aecm: shift count outside [-31, 31] (%d)\n", c);
+    abort();
+}
 [[noreturn]] void aecm_nonneg_violation(int v) {
     fprintf(stderr, "aecm: as_nonneg precondition violated (%d)\n", v);
     abort();

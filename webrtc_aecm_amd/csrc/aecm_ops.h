@@ -269,6 +269,23 @@ template <class I> AECM_HD I sat16(I v) { return imax(imin(v, I(32767)), I(-3276
 // c >= 0: x * 2^c (wrapping); c < 0: arithmetic / logical right shift by -c.
 template <class I, class C> AECM_HD I shift_i(I x, C c) { return sel(c >= 0, shl(x, c), sar(x, neg(c))); }
 template <class I, class C> AECM_HD I shift_u(I x, C c) { return sel(c >= 0, shl(x, c), lsr(x, neg(c))); }
+// The same for a count known to lie in [-31, 31] (the host build checks the claim; audit build: counter 1): the value
+// is placed in the upper half of a 64-bit word and shifted right by 32 - c, one 64-bit shift (same issue cost as a
+// 32-bit one on gfx950) instead of two shifts, a negation, a compare and a select.
+#if !defined(__HIP_DEVICE_COMPILE__)
+[[noreturn]] void aecm_shift_range_violation(int c);
+#endif
+AECM_HD int checked_shift31(int c) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (c < -31 || c > 31) aecm_shift_range_violation(c);
+#elif defined(AECM_CHECKED)
+    if (c < -31 || c > 31) atomicAdd(&g_aecm_check_fail[1], 1ull);
+#endif
+    return c;
+}
+AECM_HD int shift_u31(int x, int c) { return (int)(uint32_t)(((uint64_t)(uint32_t)x << 32) >> (32 - checked_shift31(c))); }
+AECM_HD int shift_i31(int x, int c) { return (int)(uint32_t)(uint64_t)(((int64_t)x << 32) >> (32 - checked_shift31(c))); }
+
 // new = mean + ((new - mean) >> factor) with the shift applied to the magnitude
 // (WebRtc_MeanEstimatorFix, aecm/delay_estimator.cc:690-702).
 // (1 << width) - 1                                                            -> v_bfm_b32 / s_bfm_b32

@@ -410,7 +410,7 @@ struct BlockEngine {
         // exact floor(sqrt) on the unsigned sum: floor(sqrt(x^2)) == |x|, and the only sum above
         // 2^31-1 is 2^31 (re = im = -32768), whose floor-sqrt 46340 equals that of 2^31-1.
         // (-im)^2 == im^2 also for the wrapped -32768, so the packed bin squares itself.
-        vi sq = dot2_i16(x, x, vi(0));                      // <= 2^31 as unsigned
+        vi sq = dot2_i16_c0(x, x);                          // <= 2^31 as unsigned
         sp.mag = W::isqrt31(sq);                            // <= 46340 < 2^16
         sp.mag64 = zext16(iabs(sp.re64));
         sp.q = q;
@@ -570,12 +570,14 @@ struct BlockEngine {
         I zeros_num = norm_u32(u1);                                                           // :852-867
         I zeros_dfa = clz32(dfa);                                                             // NormU32, and 32 for dfa == 0 (:856-860)
         I t16 = as_i16(zeros_dfa - 2 + dfa_noisy_q - kResChannel32 - far_q + shift_ch_far);   // |.| < 128: counts, Q values
-        auto c1 = zeros_num > (t16 + 1);
-        I xfa_q = sel(c1, t16, as_i16(zeros_num - 2));
-        I dfa_q = sel(c1, as_i16(zeros_dfa - 2),
-                      as_i16(I(kResChannel32 + far_q - dfa_noisy_q) - shift_ch_far + xfa_q));
-        u1 = shift_u(u1, xfa_q);                                                              // :869-872
-        I u2 = shift_u(dfa, dfa_q);
+        // :861-867  "if (zerosNum > tmp16no1 + 1) { xfaQ = tmp16no1; dfaQ = zerosDfa - 2; } else { xfaQ = zerosNum - 2;
+        // dfaQ = RESOLUTION_CHANNEL32 + far_q - dfaNoisyQDomain - shiftChFar + xfaQ; }".  The condition is zerosNum - 2 >= tmp16no1,
+        // so xfaQ is the smaller of the two candidates; and tmp16no1 = zerosDfa - 2 - (RESOLUTION_CHANNEL32 + far_q -
+        // dfaNoisyQDomain) + shiftChFar makes the first branch's dfaQ the second branch's formula too: no select at all.
+        I xfa_q = imin(t16, as_i16(zeros_num - 2));
+        I dfa_q = as_i16(I(kResChannel32 + far_q - dfa_noisy_q) - shift_ch_far + xfa_q);
+        u1 = shift_u31(u1, xfa_q);                                                            // :869-872; both counts lie in [-28, 30]
+        I u2 = shift_u31(dfa, dfa_q);
         I t1 = sub(u2, u1);
         zeros_num = norm_w32_nz(t1);                                                          // t1 == 0: no update, nothing below is used
         auto update = (t1 != 0) & (far > shl(I(kChannelVad), far_q));                         // :873
@@ -681,10 +683,9 @@ struct BlockEngine {
         I zeros32 = norm_w32(s.echo_filt) + 1;                                                // :527-550
         int zeros16 = norm_w16(sup_gain) + 1;
         auto safe = (zeros32 + zeros16) > 16;
-        I t16 = I(17) - zeros32 - zeros16;
+        I t16 = I(17) - zeros32 - zeros16;                                                    // safe <=> t16 <= 0
         int dq = clean_q - zeros_xbuf;
-        I res_diff = sel(safe, I(14 - kResChannel16 - kResSupgain + dq),
-                         as_i16(t16 + (14 - kResChannel16 - kResSupgain + dq)));
+        I res_diff = as_i16(imax(t16, I(0)) + (14 - kResChannel16 - kResSupgain + dq));
         // three regimes (:534,:544,:548), all "low 32 bits of a product": select the operands, multiply once
         auto shift_gain = zeros32 > t16;
         I lhs = sel(safe | shift_gain, s.echo_filt, sar(s.echo_filt, t16));
@@ -697,15 +698,16 @@ struct BlockEngine {
         I a_else = dqq < 0 ? sext16(sar(s.near_filt, -dqq)) : sext16(shl(s.near_filt, dqq));
         I q_diff = sel(c, zn - dqq, I(0));
         I t_a = sel(c, sext16(shl(s.near_filt, zn)), a_else);
-        I t_b = sel(c, sext16(lsr(dfa_clean, neg(q_diff))), sext16(dfa_clean));
+        I t_b = sext16(lsr(dfa_clean, neg(q_diff)));                                          // q_diff == 0 unless c (then < 0)
         t_b = sext16(sext16(sar(sub(t_b, t_a), 4)) + t_a);
         I z2 = norm_w16(t_b);
         auto weird = (t_b & sel(neg(q_diff) > z2, I(1), I(0))) != 0;                           // :572 literally
-        s.near_filt = sel(weird, I(32767), sel(q_diff < 0, sext16(shl(t_b, neg(q_diff))), t_b));
+        s.near_filt = sel(weird, I(32767), sext16(shl(t_b, neg(q_diff))));                     // q_diff <= 0; a shift by 0 leaves the int16 t_b
 
         I g2 = add(gained, sar(s.near_filt, 1));                                              // :582-611
-        I t32 = shift_u(divu(g2, zext16(s.near_filt)), res_diff);
-        I h = sel(t32 > kOneQ14, I(0), sel(t32 < 0, I(kOneQ14), imax(I(kOneQ14) - t32, I(0))  /* only selected when 0 <= t32 <= 2^14: (int16_t) is the identity there */));
+        I t32 = shift_u31(divu(g2, zext16(s.near_filt)), res_diff);                           // -20 <= res_diff <= 23
+        // :597-611: hnl = ONE_Q14 - t32 clipped to [0, ONE_Q14], ONE_Q14 for a t32 that wrapped negative: ONE_Q14 - clamp(t32)
+        I h = I(kOneQ14) - imax(imin(t32, I(kOneQ14)), I(0));
         return sel(gained == 0, I(kOneQ14), sel(s.near_filt == 0, I(0), h));
     }
 
@@ -977,9 +979,9 @@ struct BlockEngine {
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
         vi first = as_i16(sar(mul24(lo16(a), lane_const<LC_HANN_SYN_LO>(r)) + 8192, 14));               // :219-221
-        vi out = sat16(add(shift_i(first, sh), r.out_ovl));                           // :222-227
+        vi out = sat16(add(shift_i31(first, vi(sh)), r.out_ovl));                     // :222-227; |sh| <= 14
         vi second = sar(mul24(lo16(b), lane_const<LC_HANN_SYN_HI>(r)), 14);                             // :229-234
-        r.out_ovl = sat16(shift_i(second, sh));
+        r.out_ovl = sat16(shift_i31(second, vi(sh)));
         AECM_PHASE_MARK(12, out, r.out_ovl);
         r.x_old = far_new;                                                            // :239-245
         r.d_old = near_new;

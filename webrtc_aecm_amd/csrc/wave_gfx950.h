@@ -58,6 +58,9 @@ enum : int {
     kDppRowBcast31 = 0x143     // lane 31 -> every lane of rows 2 and 3
 };
 
+// v_writelane_b32 has no clang builtin in this toolchain: the LLVM intrinsic through its assembler name (like v_ffbh_i32, aecm_ops.h)
+extern "C" __device__ int aecm_llvm_amdgcn_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
 template <bool kFast>
 struct Gfx950Wave {
     using vi = int;
@@ -282,7 +285,7 @@ struct Gfx950Wave {
 
     static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
     static __device__ __forceinline__ int readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-    static __device__ __forceinline__ int writelane(int v, int value, int lane) { return lane_id() == lane ? value : v; }
+    static __device__ __forceinline__ int writelane(int v, int value, int lane) { return aecm_llvm_amdgcn_writelane(value, lane, v); }   // v_writelane_b32 (value and lane wave-uniform)
     static __device__ __forceinline__ int bpermute(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
     static __device__ __forceinline__ int shift_up1(int v, int fill) {
         if constexpr (kFast) {
