@@ -228,8 +228,10 @@ AECM_HD int min_u32(int a, int b) { return (unsigned)a < (unsigned)b ? a : b; }
 template <class I> AECM_HD I norm_u32_nn(I a) { return imax(ffbh_i(as_nonneg(a)), I(0)); }
 template <class I> AECM_HD I norm_w32(I a) { return sel(a == 0, I(0), min_u32(ffbh_i(a) - 1, I(31))); }
 template <class I> AECM_HD I norm_w16(I a) { return sel(a == 0, I(0), min_u32(ffbh_i(a) - 1, I(31)) - 16); }
-// norm_w32 for an operand whose zero case the caller does not care about (result for 0 is 31)
+// norm_w32 / norm_w16 for an operand whose zero case the caller does not care about, or wants to read as "as many
+// redundant sign bits as there can be" (result for 0: 31 resp. 15): no zero test
 template <class I> AECM_HD I norm_w32_nz(I a) { return min_u32(ffbh_i(a) - 1, I(31)); }
+template <class I> AECM_HD I norm_w16_nz(I a) { return min_u32(ffbh_i(a) - 1, I(31)) - 16; }
 // High 32 bits of the signed 64-bit product                                  -> v_mul_hi_i32 / s_mul_hi_i32
 AECM_HD int mulhi_i32(int a, int b) { return (int)(((int64_t)a * (int64_t)b) >> 32); }
 // High 32 bits of the unsigned 64-bit product                                -> v_mul_hi_u32

@@ -467,20 +467,20 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     // Energies / VAD / step size (reference aecm/aecm_core.cc:588-794)
     // ------------------------------------------------------------------------------------------
+    // Scalar helpers, written as straight-line selects: every value here is wave-uniform and lives on the scalar unit,
+    // where a branch costs more than the few instructions it skips.
     static AECM_HD int asym_filt(int old, int in, int step_pos, int step_neg) {      // :588-605
-        if ((old == 32767) | (old == -32768)) return in;
-        if (old > in) return sext16(old - sar(old - in, step_neg));
-        return sext16(old + sar(in - old, step_pos));
+        const int d = in - old;                                                       // old, in are int16
+        const int up = sext16(old + sar(d, step_pos)), down = sext16(old - sar(-d, step_neg));
+        const int filtered = d < 0 ? down : up;                                       // "old > in" is d < 0; d == 0: both are old
+        return ((old == 32767) | (old == -32768)) ? in : filtered;
     }
 
     static AECM_HD int log_energy_q8(int energy, int q) {                             // :612-628
-        int v = 7 << 7;
-        if (energy != 0) {
-            int zeros = clz32(energy);
-            int frac = sext16(lsr(shl(energy, zeros) & 0x7fffffff, 23));
-            v = sext16(v + ((31 - zeros) << 8) + frac - (q << 8));
-        }
-        return v;
+        const int zeros = clz32(energy);                                              // 32 for 0: harmless, the result is replaced
+        const int frac = lsr(shl(energy, zeros), 23) & 0xff;                           // bits 30..23 of the normalised energy
+        const int v = sext16((7 << 7) + ((31 - zeros) << 8) + frac - (q << 8));
+        return energy != 0 ? v : (7 << 7);
     }
 
     // CalcLinearEnergies + CalcEnergies (:267-284, :644-755).  echo_est = channelStored * far.
@@ -680,27 +680,34 @@ struct BlockEngine {
         I d = sub(echo_est, s.echo_filt);
         s.echo_filt = add(s.echo_filt, mulhi_i32(d, I(50 << 24)));
 
-        I zeros32 = norm_w32(s.echo_filt) + 1;                                                // :527-550
+        // echoFilt == 0: the product below is 0 whatever the regime and the gain is then ONE_Q14 (:582): its norm is never looked at
+        I zeros32 = norm_w32_nz(s.echo_filt) + 1;                                             // :527-550
         int zeros16 = norm_w16(sup_gain) + 1;
-        auto safe = (zeros32 + zeros16) > 16;
-        I t16 = I(17) - zeros32 - zeros16;                                                    // safe <=> t16 <= 0
+        I t16 = I(17) - zeros32 - zeros16;                                                    // :529: the "safe" regime is t16 <= 0
         int dq = clean_q - zeros_xbuf;
-        I res_diff = as_i16(imax(t16, I(0)) + (14 - kResChannel16 - kResSupgain + dq));
-        // three regimes (:534,:544,:548), all "low 32 bits of a product": select the operands, multiply once
-        auto shift_gain = zeros32 > t16;
-        I lhs = sel(safe | shift_gain, s.echo_filt, sar(s.echo_filt, t16));
-        I rhs = sel(safe, I(zext16(sup_gain)), sel(shift_gain, zext16(sar(I(sup_gain), t16)), I(sup_gain)));
+        I tpos = imax(t16, I(0));
+        I res_diff = as_i16(tpos + (14 - kResChannel16 - kResSupgain + dq));
+        // Three regimes (:534,:544,:548), all "low 32 bits of a product": echoFilt * supGain when nothing can overflow
+        // (t16 <= 0), else the t16 excess bits are shifted out of supGain (if echoFilt has more headroom than that,
+        // zeros32 > t16) or out of echoFilt.  supGain is never negative (it is a smoothed maximum of non-negative targets,
+        // aecm_core.cc:1000-1052), so the reference's (uint16_t) casts are the identity and the three regimes are
+        // one multiply of two right-shifted operands whose shift counts add up to max(t16, 0).
+        I sh_l = sel(zeros32 > t16, I(0), tpos);
+        I lhs = sar(s.echo_filt, sh_l);
+        I rhs = sar(I(as_nonneg(sup_gain)), tpos - sh_l);
         I gained = mul(lhs, rhs);
 
-        I zn = norm_w16(s.near_filt);                                                         // :552-579
+        // :552-579.  nearFilt == 0 reads as norm 15 here, which no Q-domain step (|dqq| <= 14) exceeds: the reference's
+        // "&& nearFilt" needs no test of its own.
+        I zn = norm_w16_nz(s.near_filt);
         int dqq = sext16(clean_q - clean_q_old);
-        auto c = (zn < dqq) & (s.near_filt != 0);
-        I a_else = dqq < 0 ? sext16(sar(s.near_filt, -dqq)) : sext16(shl(s.near_filt, dqq));
+        auto c = zn < dqq;
+        I a_else = sext16(shift_i31(s.near_filt, I(dqq)));
         I q_diff = sel(c, zn - dqq, I(0));
         I t_a = sel(c, sext16(shl(s.near_filt, zn)), a_else);
         I t_b = sext16(lsr(dfa_clean, neg(q_diff)));                                          // q_diff == 0 unless c (then < 0)
         t_b = sext16(sext16(sar(sub(t_b, t_a), 4)) + t_a);
-        I z2 = norm_w16(t_b);
+        I z2 = norm_w16_nz(t_b);                                                              // t_b == 0 has bit 0 clear: its norm does not matter
         auto weird = (t_b & sel(neg(q_diff) > z2, I(1), I(0))) != 0;                           // :572 literally
         s.near_filt = sel(weird, I(32767), sext16(shl(t_b, neg(q_diff))));                     // q_diff <= 0; a shift by 0 leaves the int16 t_b
 
