@@ -456,7 +456,7 @@ struct BlockEngine {
             if (u.min_prob > thr) u.min_prob = thr;
         }
         u.last_prob = add(u.last_prob, 1);                                           // :609
-        bool valid = (valley > kProbOffset) && ((best < u.min_prob) || (best < u.last_prob));
+        bool valid = (valley > kProbOffset) & (best < imax(u.min_prob, u.last_prob));           // best < min_prob || best < last_prob
         if (any_far && valid) {                                                      // :643-661
             u.last_delay = candidate;
             if (best < u.last_prob) u.last_prob = best;
@@ -473,7 +473,8 @@ struct BlockEngine {
         const int d = in - old;                                                       // old, in are int16
         const int up = sext16(old + sar(d, step_pos)), down = sext16(old - sar(-d, step_neg));
         const int filtered = d < 0 ? down : up;                                       // "old > in" is d < 0; d == 0: both are old
-        return ((old == 32767) | (old == -32768)) ? in : filtered;
+        // old == 32767 or old == -32768 (the initial values): (old + 32769) mod 2^16 is 0 or 1 exactly for those two
+        return ((old + 32769) & 0xffff) < 2 ? in : filtered;
     }
 
     static AECM_HD int log_energy_q8(int energy, int q) {                             // :612-628
@@ -737,7 +738,7 @@ struct BlockEngine {
         I ne_ge = sel(c19, mul24(sar(s.noise_est, 11), I(2049)),
                       sel(c11, sar(mul24(s.noise_est & 0x7ffff, I(2049)), 11),   // c11 && !c19: noise_est < 2^19
                           sel(inc, s.noise_est + sar(s.noise_est, 9) + 1, s.noise_est)));
-        I low_ge = sel(c19 | c11, s.low_ctr, sel(inc, I(0), low_inc));
+        I low_ge = sel(c11, s.low_ctr, sel(inc, I(0), low_inc));                                // c19 implies c11
         I ne = sel(lt, ne_lt, ne_ge);
         s.low_ctr = sel(lt, I(0), low_ge);
         s.high_ctr = sel(lt, high_lt, I(0));
