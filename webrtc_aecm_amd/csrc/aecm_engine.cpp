@@ -60,6 +60,7 @@ BatchEngine::~BatchEngine() {
     (void)hipFree(patch_dev_);
     (void)hipFree(consts_dev_);
     (void)hipFree(stage_dev_);
+    if (mapped_host_) (void)hipHostFree(mapped_host_);
     (void)hipFree(rec_maps_);
     (void)hipFree(rec_scratch_);
     if (download_stream_) (void)hipStreamDestroy(download_stream_);
@@ -181,6 +182,8 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
     const size_t per = (size_t)num_streams_ * num_blocks * kBlock;
     const int n_in = io.near_clean ? 3 : 2;
     const size_t need = per * (n_in + 1);
+    static const bool mapped = [] { const char *e = getenv("AECM_HOST_MAPPED"); return !(e && e[0] == '0'); }();
+    if (mapped && need * sizeof(int16_t) <= kMappedBytes) return ProcessBlocksHostMapped(io, num_blocks);
     if (need > stage_elems_) {
         (void)hipFree(stage_dev_);
         stage_dev_ = nullptr;
@@ -223,6 +226,35 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
         for (int b = 0; b < num_blocks; ++b)
             memcpy(io.out + s * io.stream_stride + b * io.block_stride, &tmp[((size_t)s * num_blocks + b) * kBlock],
                    kBlock * sizeof(int16_t));
+    return true;
+}
+
+bool BatchEngine::ProcessBlocksHostMapped(const IoView &io, int num_blocks) {
+    if (!mapped_host_) {
+        void *dev = nullptr;
+        if (!AECM_HIP_OK(hipHostMalloc((void **)&mapped_host_, kMappedBytes, hipHostMallocMapped))) return false;
+        if (!AECM_HIP_OK(hipHostGetDevicePointer(&dev, mapped_host_, 0))) return false;
+        mapped_dev_ = static_cast<int16_t *>(dev);
+    }
+    const size_t row = (size_t)num_blocks * kBlock, per = (size_t)num_streams_ * row;
+    const int n_in = io.near_clean ? 3 : 2;
+    auto rows = [&](const int16_t *src, int16_t *dst, bool to_mapped) {     // src / dst: the caller's side, the mapped side
+        for (int s = 0; s < num_streams_; ++s)
+            for (int b = 0; b < num_blocks; ++b) {
+                const int16_t *user = src + s * io.stream_stride + b * io.block_stride;
+                int16_t *ours = dst + (size_t)s * row + (size_t)b * kBlock;
+                if (to_mapped) memcpy(ours, user, kBlock * sizeof(int16_t));
+                else memcpy(const_cast<int16_t *>(user), ours, kBlock * sizeof(int16_t));
+            }
+    };
+    rows(io.far, mapped_host_, true);
+    rows(io.near, mapped_host_ + per, true);
+    if (io.near_clean) rows(io.near_clean, mapped_host_ + 2 * per, true);
+    IoView dev{mapped_dev_, mapped_dev_ + per, io.near_clean ? mapped_dev_ + 2 * per : nullptr, mapped_dev_ + (size_t)n_in * per,
+               (int64_t)row, kBlock};
+    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, dev, num_streams_, num_blocks, variant_, stream_))) return false;
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    rows(io.out, mapped_host_ + (size_t)n_in * per, false);
     return true;
 }
 

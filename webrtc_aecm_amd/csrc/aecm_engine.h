@@ -88,6 +88,12 @@ private:
     size_t stage_elems_ = 0;
     static constexpr int kHostChunkStreams = 8192;
     bool ProcessBlocksHostPipelined(const IoView &io_host, int num_blocks);
+    // Small host calls (the single-session ABI: one to three blocks of one stream): the kernel reads its inputs from and
+    // writes its output to a pinned host buffer mapped into the device's address space, so a call is two small host
+    // copies, one launch and one synchronisation -- no staging copies, no timing events.
+    static constexpr size_t kMappedBytes = 64 * 1024;
+    int16_t *mapped_host_ = nullptr, *mapped_dev_ = nullptr;
+    bool ProcessBlocksHostMapped(const IoView &io_host, int num_blocks);
     // scratch of ProcessRecordings (grow-only; the streams of a batch are processed in chunks that fit it)
     static constexpr size_t kRecordingScratchBytes = size_t(1) << 30;
     int32_t *rec_maps_ = nullptr;
