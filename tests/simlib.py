@@ -11,11 +11,11 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "webrtc_aecm_amd" / "csrc"
 SIM_SO = ROOT / "tests" / "_build" / "libaecm_sim.so"
-_SOURCES = [ROOT / "tests" / "sim" / "sim_lib.cpp", ROOT / "tests" / "sim" / "sim_engine.cpp",
+_SOURCES = [ROOT / "tests" / "sim" / "sim_lib.cpp", ROOT / "tests" / "sim" / "sim_engine.cpp", ROOT / "tests" / "sim" / "sim_flow.cpp",
             CSRC / "aecm_host_state.cpp", CSRC / "aecm_session.cpp", CSRC / "aecm_schedule.cpp"]
 _DEPS = _SOURCES + [ROOT / "tests" / "sim" / "wave_sim.h", CSRC / "aecm_wave.h", CSRC / "aecm_ops.h",
                     CSRC / "aecm_state.h", CSRC / "aecm_host_state.h", CSRC / "aecm_tables.h",
-                    CSRC / "aecm_session.h", CSRC / "aecm_engine.h", CSRC / "aecm_session_flow.h"]
+                    CSRC / "aecm_session.h", CSRC / "aecm_engine.h", CSRC / "aecm_session_flow.h", CSRC / "aecm_flow_plan.h"]
 _i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _lib = None
@@ -55,8 +55,18 @@ def lib():
         l.simsession_set_config.argtypes = [C.c_void_p, C.c_int16, C.c_int16]
         l.simsession_init_echo_path.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         l.simsession_get_echo_path.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        l.sim_flow_fuzz.restype = C.c_int64
+        l.sim_flow_fuzz.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_int64)]
+        l.sim_flow_tolerance_check.restype = C.c_int
         _lib = l
     return _lib
+
+
+def flow_fuzz(seed, fs, n_ticks, scenario, start_pos=0):
+    """(first differing tick or -1, [what, blocks processed, ticks past start-up, ticks with dropped far samples])."""
+    detail = (C.c_int64 * 4)()
+    tick = lib().sim_flow_fuzz(seed, fs, n_ticks, scenario, start_pos, detail)
+    return tick, list(detail)
 
 
 class SimStream:

@@ -447,32 +447,45 @@ def test_streaming_ticks_with_per_session_sound_card_delay():
                 if i % 97 != 96:
                     assert codes[k] == rc1, (fs, i, k)
                 assert np.array_equal(out[k], o1), (fs, frame, i, k)
-        assert 6 <= sb.num_flow_classes() <= aecm.AecmSessions.MAX_FLOW_CLASSES
+        assert sb.num_flow_classes() == 0 or 6 <= sb.num_flow_classes() <= aecm.AecmSessions.MAX_FLOW_CLASSES   # 0: machinery on the device
         for s in singles:
             s.close()
         sb.close()
 
 
-def test_streaming_ticks_too_many_delay_histories_is_an_error_not_a_crash():
-    """More distinct msInSndCardBuf histories than flow classes: the tick is refused with
-    AECM_UNSUPPORTED_FUNCTION_ERROR, nothing is consumed, and the object keeps working."""
+def test_streaming_ticks_more_delay_histories_than_any_class_table():
+    """Every session with its own msInSndCardBuf history.  With the session machinery on the device (the default) that is
+    just a tick; the host-side flow-class forms (AECM_TICK_MODE=lean|fused|three) refuse more histories than they have
+    classes with AECM_UNSUPPORTED_FUNCTION_ERROR, consume nothing, and keep working."""
     S, frame, fs = aecm.AecmSessions.MAX_FLOW_CLASSES + 6, 160, 16000
     far, near = synth_pair(33, 40, fs, "mixed")
     far = np.tile(far[:10 * frame], (S, 1))
     near = np.tile(near[:10 * frame], (S, 1))
     sb = aecm.AecmSessions(S, fs, 1, 1)
-    one = aecm.Aecm()
-    assert one.init(fs) == 0 and one.set_config(1, 1) == 0
+    on_device = sb.num_flow_classes() == 0
+    ones = {k: aecm.Aecm() for k in (0, 7, S - 1)}
+    for one in ones.values():
+        assert one.init(fs) == 0 and one.set_config(1, 1) == 0
     for i in range(10):
         sl = slice(i * frame, (i + 1) * frame)
         if i == 4:
-            rc, _, _ = sb.tick_host_per_session(far[:, sl], near[:, sl], np.arange(S, dtype=np.int16))      # S distinct values
+            ms = np.arange(S, dtype=np.int16)                                                               # S distinct values
+            rc, out, codes = sb.tick_host_per_session(far[:, sl], near[:, sl], ms)
+            if on_device:
+                assert rc == aecm.ffi.AECM_BAD_PARAMETER_WARNING                                            # the sessions beyond 500 ms
+                for k, one in ones.items():
+                    assert one.buffer_farend(far[k, sl]) == 0
+                    rc1, o1 = one.process(near[k, sl], None, int(ms[k]))
+                    assert codes[k] == rc1 and np.array_equal(out[k], o1), k
+                continue
             assert rc == aecm.ffi.AECM_UNSUPPORTED_FUNCTION_ERROR and sb.num_flow_classes() == 1
         rc, out = sb.tick_host(far[:, sl], near[:, sl], 40)
-        assert one.buffer_farend(far[0, sl]) == 0
-        rc1, o1 = one.process(near[0, sl], None, 40)
-        assert rc == rc1 == 0 and np.array_equal(out[0], o1) and np.array_equal(out[S - 1], o1), i
-    one.close()
+        for k, one in ones.items():
+            assert one.buffer_farend(far[k, sl]) == 0
+            rc1, o1 = one.process(near[k, sl], None, 40)
+            assert rc == rc1 == 0 and np.array_equal(out[k], o1), (i, k)
+    for one in ones.values():
+        one.close()
     sb.close()
 
 
@@ -719,11 +732,12 @@ def test_single_session_abi_vs_reference_jitter_underruns_all_call_sizes():
 
 
 @_needs_ref
-@pytest.mark.parametrize("mode", ["lean", "fused", "three"])
+@pytest.mark.parametrize("mode", ["flow", "lean", "fused", "three"])
 def test_streaming_ticks_vs_reference_sessions(mode):
     """WebRtcAecmSessions_Tick / TickPerSession / TickFlags against one reference session per stream (not against
     our own single-session path): uniform jittering delay, then per-session delays with underruns -- in each of the
-    three forms a tick can take (lean one-launch, coded one-launch, three launches)."""
+    forms a tick can take (session machinery on the device -- the default --, or on the host in flow classes with a lean
+    one-launch, a coded one-launch or a three-launch device side)."""
     import os
     import subprocess
     import sys

@@ -255,3 +255,21 @@ def test_session_jitter_goldens_on_the_host_session_logic():
         assert s.init(fs) == 0 and s.set_config(int(g["cng"]), int(g["echo_mode"])) == 0
         out, codes = drive_session(s, far, near, frame, g["ms_seq"], g["far_present"])
         assert np.array_equal(codes, g["codes"]) and np.array_equal(out, g["out"]), f.name
+
+
+@pytest.mark.parametrize("fs", [16000, 8000])
+def test_device_session_machinery_equals_the_generic_wrapper_on_sample_tags(fs):
+    """aecm_flow_plan.h (the wrapper + frame adapter as position arithmetic, what aecm_tick_flow_kernel runs per session)
+    against SessionFlow<T> on sample tags: every block's 64 far / near inputs and every output sample must have the
+    same provenance, tick by tick -- constant, jittering, stepping and out-of-range msInSndCardBuf, far-end underruns,
+    a saturated jitter buffer (16 kHz in 80-sample calls), mixed 80 / 160 / 2 x 80 call shapes, and position counters
+    that wrap around 2^32 and 2^31 during the run."""
+    assert simlib.lib().sim_flow_tolerance_check() == 0
+    saw_blocks = saw_drops = 0
+    for scenario in range(9):
+        for seed, start in ((1, 0), (2, 0xfffff000), (3, 0x7ffff800), (4, 987654321)):
+            tick, detail = simlib.flow_fuzz(seed + 10 * scenario, fs, 6000, scenario, start)
+            assert tick == -1, (fs, scenario, seed, tick, detail)
+            saw_blocks += detail[1]
+            saw_drops += detail[3]
+    assert saw_blocks > 100000 and (fs == 8000 or saw_drops > 1000)

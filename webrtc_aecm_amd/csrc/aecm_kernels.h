@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "aecm_flow_plan.h"
 #include "aecm_state.h"
 
 namespace aecm {
@@ -138,6 +139,26 @@ struct TickLeanEntry {
 };
 hipError_t LaunchTickLean(const StatePtrs &st, const TickIo &io, int n_streams, const int32_t *class_of_stream,
                           const TickLeanEntry *table, const TickLeanEntry *single, hipStream_t stream);
+
+// The device-resident session machinery: the wrapper itself (jitter buffer, start-up gating, delay compensation,
+// 80 -> 64 re-blocking, output stuffing) as position arithmetic on per-session state in HBM (aecm_flow_plan.h), so every
+// session has its own msInSndCardBuf / call pattern / age and the host does nothing per session.  A tick is two launches:
+//   aecm_flow_plan_kernel   one LANE per session: FlowTick on the session's state (field-major, coalesced) -> its plan
+//   aecm_tick_flow_kernel   one WAVEFRONT per session: plan into scalar registers, append the tick's samples to the rings,
+//                           frame the far end, run the blocks, assemble the output
+// Per session in HBM besides TickIo's rings: kFlowFieldsUsed int32 of wrapper state, kFlowPlanWords of plan, a ring of
+// kFlowFarFrameRing samples holding the framed far stream, and the two 80-sample replay rows of far-end underruns
+// (farendOld, echo_control_mobile.cc:57).
+struct TickFlowIo {
+    int32_t *state;                    // [kFlowFieldsUsed][S]
+    int32_t *plans;                    // [S][kFlowPlanWords]
+    int16_t *far_frames;               // [S][kFlowFarFrameRing]
+    int16_t *far_old;                  // [S][2 * 80]
+    const int16_t *ms_per_session;     // [S] or null: everybody gets `ms`
+    const uint8_t *flags_per_session;  // [S] or null: everybody gets `flags` (kFlowNoFarend | kFlowSplitCalls)
+    int32_t ms, flags, fs;
+};
+hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowIo &fio, int n_streams, hipStream_t stream);
 
 // Diagnostics: `count` independent 128-point transforms of the block kernel's fft128, one wavefront
 // each, on natural-order data (data[k] = re[128] then im[128] of transform k, in place).  variant:

@@ -366,6 +366,7 @@ struct TickCodedIo {
         lds_out[j] = (int16_t)v;
         out_ring_row[(e->out_pos + j) & mask] = (int16_t)v;
     }
+    __device__ __forceinline__ void ready() const {}
 };
 
 template <bool kFast, bool kHasClean>
@@ -470,6 +471,7 @@ struct TickRunIo {
     __device__ __forceinline__ void out(const Regs &r, int b, int v) const {
         out_row[(out_pos + b * kBlock + r.brev) & mask] = (int16_t)v;
     }
+    __device__ __forceinline__ void ready() const {}
 };
 
 template <bool kHasClean>
@@ -560,6 +562,134 @@ hipError_t LaunchTickLean(const StatePtrs &st, const TickIo &io, int n_streams, 
         if (clean) hipLaunchKernelGGL((aecm_tick_lean_kernel<true>), grid, block, lds, stream, st, io, n_streams, *single);
         else hipLaunchKernelGGL((aecm_tick_lean_kernel<false>), grid, block, lds, stream, st, io, n_streams, *single);
     }
+    return hipGetLastError();
+}
+
+// ---- device-resident session machinery (aecm_flow_plan.h) ---------------------------------------------
+template <bool kHasClean>
+struct TickFlowBlockIo {
+    using E = BlockEngine<Gfx950Wave<true>, kHasClean>;
+    using Regs = typename E::Regs;
+    const int16_t *ff, *nr, *cr;     // framed far stream, near / clean rings of this session
+    int16_t *out_row;                // output stream ring
+    int mask;
+    unsigned far_pos, near_pos;      // positions of the tick's first block
+    __device__ __forceinline__ int far(const Regs &r, int b) const { return ff[(far_pos + b * kBlock + r.lane) & (kFlowFarFrameRing - 1)]; }
+    __device__ __forceinline__ int near(const Regs &r, int b) const { return nr[(near_pos + b * kBlock + r.lane) & mask]; }
+    __device__ __forceinline__ int clean(const Regs &r, int b) const { return cr[(near_pos + b * kBlock + r.lane) & mask]; }
+    __device__ __forceinline__ void out(const Regs &r, int b, int v) const { out_row[(far_pos + b * kBlock + r.brev) & mask] = (int16_t)v; }
+    // this wave's fetches below must see this wave's stores (the tick's samples, the framed far end); the engine's state
+    // loads are already in flight
+    __device__ __forceinline__ void ready() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+};
+
+// One lane per session: the tick's session machinery for 64 sessions per wavefront.
+__global__ __launch_bounds__(256)
+void aecm_flow_plan_kernel(TickFlowIo fio, int n, unsigned near_pos, int n_streams) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_streams) return;
+    FlowRegs r;
+    for (int k = 0; k < kFlowFieldsUsed; ++k) r.v[k] = fio.state[(size_t)k * n_streams + s];
+    const int ms = fio.ms_per_session ? (int)fio.ms_per_session[s] : fio.ms;
+    const int flags = fio.flags_per_session ? (int)fio.flags_per_session[s] : fio.flags;
+    FlowPlan p;
+    FlowTick(r, fio.fs, n, ms, flags, near_pos, p);
+    for (int k = 0; k < kFlowFieldsUsed; ++k) fio.state[(size_t)k * n_streams + s] = r.v[k];
+    int32_t w[kFlowPlanWords];
+    FlowPackPlan(p, w);
+    int4 *dst = reinterpret_cast<int4 *>(fio.plans + (size_t)s * kFlowPlanWords);
+    for (int q = 0; q < kFlowPlanWords / 4; ++q) dst[q] = make_int4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+template <bool kHasClean>
+__global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
+void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_streams) {
+    const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    // 1. the session's plan for this tick into scalar registers; requested before the table fill so that the fill hides
+    //    the latency
+    int32_t w[kFlowPlanWords];
+    {
+        const int32_t *pw = fio.plans + (s < n_streams ? s : 0) * kFlowPlanWords;
+        for (int k = 0; k < kFlowPlanWords; ++k) w[k] = pw[k];
+    }
+    FillLdsTables(st.consts);
+    if (s >= n_streams) return;
+    FlowPlan p;
+    FlowUnpackPlan(w, p);
+    const int mask = (int)io.ring_len - 1;
+    const int n = io.n;
+    const int16_t *fin = io.far_in + s * io.io_stride, *nin = io.near_in + s * io.io_stride;
+    const int16_t *cin = kHasClean ? io.clean_in + s * io.io_stride : nullptr;
+    int16_t *fr = io.far_ring + s * io.ring_len, *nr = io.near_ring + s * io.ring_len;
+    int16_t *cr = kHasClean ? io.clean_ring + s * io.ring_len : nullptr;
+    int16_t *orow = io.out_ring + s * io.ring_len;
+    int16_t *ff = fio.far_frames + s * kFlowFarFrameRing, *old = fio.far_old + s * (2 * kFlowFrame);
+    int16_t *out = io.out + s * io.io_stride;
+    // 2. the tick's samples into the rings: what the jitter buffer accepted of the far end, all of the near end
+    auto append = [&]() {
+        for (int j = lane; j < n; j += 64) {
+            for (int c = 0; c < 2; ++c)
+                if (j >= p.far[c].src && j < p.far[c].src + p.far[c].count) fr[(p.far[c].pos + (unsigned)(j - p.far[c].src)) & mask] = fin[j];
+            nr[((unsigned)io.near_pos + j) & mask] = nin[j];
+            if (kHasClean) cr[((unsigned)io.near_pos + j) & mask] = cin[j];
+        }
+    };
+    // 3. the far frames of the tick: far stream (or replay row) -> framed far stream (and replay row).  All loads are
+    //    issued before any store (FlowTick resolved same-tick replays to stream positions, so no frame depends on another
+    //    frame's stores), and they only have to wait for the appends when a frame reaches into this very tick's samples
+    //    (a nearly empty jitter buffer).
+    bool reaches_new = false;
+    for (int f = 0; f < 2; ++f)
+        reaches_new = reaches_new || (p.frame[f].active && p.frame[f].far_from_stream && (int)(p.frame[f].far_pos + kFlowFrame - p.far[0].pos) > 0);
+    if (reaches_new) {
+        append();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // this wave's loads below must see this wave's stores
+    }
+    int16_t v0[2] = {0, 0}, v1[2] = {0, 0};                          // frame f: samples lane and 64 + lane (lanes 0..15)
+    for (int f = 0; f < 2; ++f) {
+        const FlowFrame &q = p.frame[f];
+        if (!q.active) continue;
+        const int16_t *row = old + q.old_idx * kFlowFrame;
+        v0[f] = q.far_from_stream ? fr[(q.far_pos + lane) & mask] : row[lane];
+        if (lane < kFlowFrame - 64) v1[f] = q.far_from_stream ? fr[(q.far_pos + 64 + lane) & mask] : row[64 + lane];
+    }
+    if (!reaches_new) append();
+    for (int f = 0; f < 2; ++f) {
+        const FlowFrame &q = p.frame[f];
+        if (!q.active) continue;
+        int16_t *row = old + q.old_idx * kFlowFrame;
+        ff[(q.frm_pos + lane) & (kFlowFarFrameRing - 1)] = v0[f];
+        if (q.far_from_stream == 1) row[lane] = v0[f];
+        if (lane < kFlowFrame - 64) {
+            ff[(q.frm_pos + 64 + lane) & (kFlowFarFrameRing - 1)] = v1[f];
+            if (q.far_from_stream == 1) row[64 + lane] = v1[f];
+        }
+    }
+    // 4. the blocks (the fence between the stores above and the blocks' fetches is TickFlowBlockIo::ready)
+    const int nb = p.n_blocks;
+    if (nb > 0) {
+        TickFlowBlockIo<kHasClean> bio{ff, nr, cr, orow, mask, p.blk_pos0, p.near_base + p.blk_pos0};
+        TickFlowBlockIo<kHasClean>::E::run_stream_io(st, bio, s, nb);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    // 5. the output frames: block outputs (this tick's or, when stuffing, older ones) or the start-up copy of the
+    //    (clean) near end (echo_control_mobile.cc:285-291)
+    const int16_t *pass = kHasClean ? cin : nin;
+    for (int f = 0; f < 2; ++f) {
+        if (f >= p.n_frames) continue;
+        for (int j = lane; j < kFlowFrame; j += 64)
+            out[f * kFlowFrame + j] = p.frame[f].active ? orow[(p.frame[f].out_pos + j) & mask] : pass[f * kFlowFrame + j];
+    }
+}
+
+hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowIo &fio, int n_streams, hipStream_t stream) {
+    if (n_streams <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_flow_plan_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, fio, io.n, (unsigned)io.near_pos, n_streams);
+    const dim3 grid((n_streams + kTickLeanWaves - 1) / kTickLeanWaves), block(64 * kTickLeanWaves);
+    const size_t lds = sizeof(LdsTables);
+    if (io.clean_in) hipLaunchKernelGGL((aecm_tick_flow_kernel<true>), grid, block, lds, stream, st, io, fio, n_streams);
+    else hipLaunchKernelGGL((aecm_tick_flow_kernel<false>), grid, block, lds, stream, st, io, fio, n_streams);
     return hipGetLastError();
 }
 

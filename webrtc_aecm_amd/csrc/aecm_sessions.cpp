@@ -30,6 +30,16 @@ SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
               AECM_HIP_OK(hipHostMalloc((void **)&b->table_host_, kMaxFlowClasses * sizeof(TickClassEntry), hipHostMallocDefault)) &&
               AECM_HIP_OK(hipMalloc((void **)&b->lean_dev_, kMaxFlowClasses * sizeof(TickLeanEntry))) &&
               AECM_HIP_OK(hipHostMalloc((void **)&b->lean_host_, kMaxFlowClasses * sizeof(TickLeanEntry), hipHostMallocDefault));
+    b->flow_mode_ = ChooseTickMode(num_streams) == kTickFlow;
+    if (ok && b->flow_mode_)
+        ok = AECM_HIP_OK(hipMalloc((void **)&b->flow_state_, S * kFlowFieldsUsed * sizeof(int32_t))) &&
+             AECM_HIP_OK(hipMalloc((void **)&b->flow_plans_, S * kFlowPlanWords * sizeof(int32_t))) &&
+             AECM_HIP_OK(hipMalloc((void **)&b->far_frames_, S * kFlowFarFrameRing * 2)) &&
+             AECM_HIP_OK(hipMalloc((void **)&b->far_old_, S * 2 * kFlowFrame * 2)) &&
+             AECM_HIP_OK(hipMalloc((void **)&b->ms_dev_, S * sizeof(int16_t))) &&
+             AECM_HIP_OK(hipMalloc((void **)&b->flags_dev_, S)) &&
+             AECM_HIP_OK(hipHostMalloc((void **)&b->ms_host_, S * sizeof(int16_t), hipHostMallocDefault)) &&
+             AECM_HIP_OK(hipHostMalloc((void **)&b->flags_host_, S, hipHostMallocDefault));
     if (!ok) {
         delete b;
         return nullptr;
@@ -52,6 +62,28 @@ SessionBatch::~SessionBatch() {
     if (table_host_) (void)hipHostFree(table_host_);
     (void)hipFree(lean_dev_);
     if (lean_host_) (void)hipHostFree(lean_host_);
+    (void)hipFree(flow_state_);
+    (void)hipFree(flow_plans_);
+    (void)hipFree(far_frames_);
+    (void)hipFree(far_old_);
+    (void)hipFree(ms_dev_);
+    (void)hipFree(flags_dev_);
+    if (ms_host_) (void)hipHostFree(ms_host_);
+    if (flags_host_) (void)hipHostFree(flags_host_);
+}
+
+// WebRtcAecm_Init of the wrapper state of sessions [first, first + count) on the device: all zero but the three start-up
+// flags (FlowInit), empty frame stream and replay rows.  The rings are cleared by the callers.
+bool SessionBatch::ResetFlowRows(int first, int count) {
+    hipStream_t st = engine_->stream();
+    const size_t S = (size_t)engine_->num_streams();
+    bool ok = true;
+    for (int f = 0; f < kFlowFieldsUsed; ++f) {                       // field-major: one short run per field
+        const int value = (f == F_DELAY_CHANGE || f == F_CHECK_BUFF_SIZE || f == F_EC_STARTUP) ? 1 : 0;
+        ok = ok && AECM_HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(flow_state_ + (size_t)f * S + first), value, (size_t)count, st));
+    }
+    return ok && AECM_HIP_OK(hipMemsetAsync(far_frames_ + (size_t)first * kFlowFarFrameRing, 0, (size_t)count * kFlowFarFrameRing * 2, st)) &&
+           AECM_HIP_OK(hipMemsetAsync(far_old_ + (size_t)first * 2 * kFlowFrame, 0, (size_t)count * 2 * kFlowFrame * 2, st));
 }
 
 int32_t SessionBatch::Init(int32_t samp_freq) {
@@ -64,6 +96,7 @@ int32_t SessionBatch::Init(int32_t samp_freq) {
         !AECM_HIP_OK(hipMemsetAsync(out_ring_, 0, bytes, engine_->stream())) ||
         (clean_ring_ && !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, engine_->stream()))))
         return AECM_UNSPECIFIED_ERROR;
+    if (flow_mode_ && !ResetFlowRows(0, S)) return AECM_UNSPECIFIED_ERROR;
     near_pos_ = 0;
     tick_count_ = 0;
     fs_ = samp_freq;
@@ -106,6 +139,17 @@ void SessionBatch::DropEmptyClasses() {
 // (its far / output tags restart at 0), everything older reads as "never written" = 0.
 int32_t SessionBatch::InitSession(int session) {
     if (int32_t rc = CheckSession(session)) return rc;
+    if (flow_mode_) {
+        // fresh core state, fresh wrapper state, and rings that read as never written (a fresh jitter buffer's read
+        // pointer can be moved back over never-written memory, the output ring is stuffed from it: ring_buffer.c:75-82)
+        hipStream_t st = engine_->stream();
+        const size_t row = (size_t)kRing * 2, off = (size_t)session * kRing;
+        const bool ok = AECM_HIP_OK(hipSetDevice(device_)) && engine_->InitStreams(session, 1) && ResetFlowRows(session, 1) &&
+                        AECM_HIP_OK(hipMemsetAsync(far_ring_ + off, 0, row, st)) && AECM_HIP_OK(hipMemsetAsync(out_ring_ + off, 0, row, st)) &&
+                        AECM_HIP_OK(hipStreamSynchronize(st));
+        if (!ok) { poisoned_ = true; return AECM_UNSPECIFIED_ERROR; }
+        return 0;
+    }
     int32_t id = -1;
     for (size_t k = 0; k < classes_.size(); ++k)
         if (classes_[k].born == tick_count_ && classes_[k].far_count == 0 && classes_[k].blocks_done == 0) { id = (int32_t)k; break; }
@@ -175,6 +219,7 @@ int32_t SessionBatch::SetConfig(int16_t cng_mode, int16_t echo_mode) {
 SessionBatch::TickMode SessionBatch::ChooseTickMode(int num_streams) {
     static const int forced = [] {
         if (const char *m = getenv("AECM_TICK_MODE")) {
+            if (!strcmp(m, "flow")) return (int)kTickFlow;
             if (!strcmp(m, "lean")) return (int)kTickLean;
             if (!strcmp(m, "fused")) return (int)kTickFused;
             if (!strcmp(m, "three")) return (int)kTickThreeLaunch;
@@ -183,7 +228,7 @@ SessionBatch::TickMode SessionBatch::ChooseTickMode(int num_streams) {
         return -1;
     }();
     (void)num_streams;
-    return forced >= 0 ? (TickMode)forced : kTickLean;
+    return forced >= 0 ? (TickMode)forced : kTickFlow;
 }
 
 // Describe `count` sample tags as runs of consecutive ring positions (aecm_kernels.h: TickRuns).  tag >= 0: a sample
@@ -362,10 +407,11 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st)))
             return AECM_UNSPECIFIED_ERROR;
     }
-    // 1. which class every session is in for this tick
     if (flags_per_session && n != 160)
         for (int s = 0; s < S; ++s)
             if (flags_per_session[s] & kSplitCalls) return AECM_BAD_PARAMETER_ERROR;      // two 80-sample calls need 160 samples
+    if (flow_mode_) return TickFlow(far, near, clean, out, stride, n, ms, ms_per_session, flags_per_session, codes, host_pointers);
+    // 1. which class every session is in for this tick
     if (ms_per_session || flags_per_session) {
         if (int32_t rc = Regroup(ms_per_session, ms, flags_per_session)) return rc;
     } else {
@@ -476,6 +522,65 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
     if (!ok) return fail();
     if (host_pointers &&
         !AECM_HIP_OK(hipMemcpy2DAsync(out, stride * 2, dout, 320, (size_t)n * 2, S, hipMemcpyDeviceToHost, st)))
+        return fail();
+    if (!AECM_HIP_OK(hipStreamSynchronize(st))) return fail();
+    return first_rc;
+}
+
+// The tick with the session machinery on the device: nothing per session happens on the host beyond handing over the
+// tick's msInSndCardBuf / flags.  The return codes need no device either: the only thing a call of an initialised
+// session with valid arguments can return is the warning for an out-of-range msInSndCardBuf (:258-265).
+int32_t SessionBatch::TickFlow(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, int n, int16_t ms,
+                               const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers) {
+    const int S = engine_->num_streams();
+    hipStream_t st = engine_->stream();
+    auto fail = [&]() -> int32_t {
+        poisoned_ = true;
+        (void)hipStreamSynchronize(st);
+        return AECM_UNSPECIFIED_ERROR;
+    };
+    auto code_of = [](int16_t v) -> int32_t { return (v < 0 || v > 500) ? AECM_BAD_PARAMETER_WARNING : 0; };
+    int32_t first_rc = 0;
+    if (ms_per_session) {
+        for (int s = 0; s < S; ++s) {
+            const int32_t rc = code_of(ms_per_session[s]);
+            if (codes) codes[s] = rc;
+            if (rc != 0 && first_rc == 0) first_rc = rc;
+        }
+        memcpy(ms_host_, ms_per_session, (size_t)S * sizeof(int16_t));      // pinned; the previous tick ended with a synchronisation
+        if (!AECM_HIP_OK(hipMemcpyAsync(ms_dev_, ms_host_, (size_t)S * sizeof(int16_t), hipMemcpyHostToDevice, st))) return fail();
+    } else {
+        first_rc = code_of(ms);
+        if (codes)
+            for (int s = 0; s < S; ++s) codes[s] = first_rc;
+    }
+    if (flags_per_session) {
+        memcpy(flags_host_, flags_per_session, (size_t)S);
+        if (!AECM_HIP_OK(hipMemcpyAsync(flags_dev_, flags_host_, (size_t)S, hipMemcpyHostToDevice, st))) return fail();
+    }
+    const int16_t *dfar = far, *dnear = near, *dclean = clean;
+    int16_t *dout = out;
+    int64_t dstride = stride;
+    if (host_pointers) {
+        dstride = 160;
+        int16_t *f = io_dev_, *d = io_dev_ + (size_t)S * 160, *c = io_dev_ + 3 * (size_t)S * 160;
+        if (!AECM_HIP_OK(hipMemcpy2DAsync(f, 320, far, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
+            !AECM_HIP_OK(hipMemcpy2DAsync(d, 320, near, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
+            (clean && !AECM_HIP_OK(hipMemcpy2DAsync(c, 320, clean, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st))))
+            return fail();
+        dfar = f;
+        dnear = d;
+        dout = io_dev_ + 2 * (size_t)S * 160;
+        if (clean) dclean = c;
+    }
+    TickIo tio{dfar, dnear, dclean, dout, dstride, n, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, near_pos_};
+    TickFlowIo fio{flow_state_, flow_plans_, far_frames_, far_old_, ms_per_session ? ms_dev_ : nullptr, flags_per_session ? flags_dev_ : nullptr,
+                   ms, 0, fs_};
+    const bool ok = engine_->variant() == kVariantFast && AECM_HIP_OK(LaunchTickFlow(engine_->state_ptrs(), tio, fio, S, st));
+    near_pos_ += n;
+    tick_count_ += 1;
+    if (!ok) return fail();
+    if (host_pointers && !AECM_HIP_OK(hipMemcpy2DAsync(out, stride * 2, dout, 320, (size_t)n * 2, S, hipMemcpyDeviceToHost, st)))
         return fail();
     if (!AECM_HIP_OK(hipStreamSynchronize(st))) return fail();
     return first_rc;

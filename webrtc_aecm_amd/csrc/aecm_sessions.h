@@ -56,7 +56,8 @@ public:
     //     samples in this tick instead of one of 160 (the reference treats the two cadences differently:
     //     echo_control_mobile.cc:282-283, 384-385).
     static constexpr uint8_t kNoFarend = 1, kSplitCalls = 2;
-    int num_flow_classes() const { return (int)classes_.size(); }
+    // 0: the session machinery runs on the device (the default), there are no classes and no limit on distinct histories
+    int num_flow_classes() const { return flow_mode_ ? 0 : (int)classes_.size(); }
 
     static constexpr int kMaxFlowClasses = 1024;
 
@@ -79,7 +80,10 @@ private:
     void DropEmptyClasses();
     int32_t CheckSession(int session) const;
     int32_t AdvanceClass(FlowClass &c, int n, bool has_clean, TickClassEntry *entry, TickLeanEntry *lean, bool *lean_ok, bool *coded_ok, bool *stale);
-    enum TickMode { kTickLean, kTickFused, kTickThreeLaunch };
+    enum TickMode { kTickFlow, kTickLean, kTickFused, kTickThreeLaunch };
+    int32_t TickFlow(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, int n, int16_t ms,
+                     const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers);
+    bool ResetFlowRows(int first, int count);
     static TickMode ChooseTickMode(int num_streams);
     static constexpr int64_t kRing = 8192;     // >= 4000 (jitter buffer) + 160 + 144 + stale re-reads; power of two
     std::unique_ptr<BatchEngine> engine_;
@@ -100,6 +104,15 @@ private:
     int32_t *class_of_dev_ = nullptr, *blocks_per_stream_dev_ = nullptr;          // [S] each
     TickClassEntry *table_dev_ = nullptr, *table_host_ = nullptr;                 // [kMaxFlowClasses], host copy pinned
     TickLeanEntry *lean_dev_ = nullptr, *lean_host_ = nullptr;                    // the same ticks as run descriptions
+    // Device-resident session machinery (the default tick form, aecm_flow_plan.h): per-session wrapper state, framed far
+    // stream and far-end replay rows in HBM; the classes above are then unused.
+    bool flow_mode_ = true;
+    int32_t *flow_state_ = nullptr;            // [kFlowFieldsUsed][S]
+    int32_t *flow_plans_ = nullptr;            // [S][kFlowPlanWords]: this tick's plan of every session
+    int16_t *far_frames_ = nullptr;            // [S][kFlowFarFrameRing]
+    int16_t *far_old_ = nullptr;               // [S][2 * 80]
+    int16_t *ms_dev_ = nullptr, *ms_host_ = nullptr;          // [S] per-session msInSndCardBuf of the tick (host copy pinned)
+    uint8_t *flags_dev_ = nullptr, *flags_host_ = nullptr;    // [S] per-session flags of the tick
     int device_ = 0;
 };
 

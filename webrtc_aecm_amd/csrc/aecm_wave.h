@@ -1002,6 +1002,8 @@ struct BlockEngine {
     // block b's 64 new samples come from and where its 64 output samples go:
     //   vi far(const Regs &, int b), near(...), clean(...)   lane t -> sample t of block b
     //   void out(const Regs &, int b, vi v)                  lane t holds output sample bitrev6(t) (= r.brev)
+    //   void ready()                                         called once, after the state loads have been issued and
+    //                                                        before the first sample fetch (a place to wait for the caller's own stores)
     // ------------------------------------------------------------------------------------------
     template <class Io>
     static AECM_HD void run_stream_io(const StatePtrs &st, Io &io, int64_t stream, int n_blocks) {
@@ -1011,6 +1013,7 @@ struct BlockEngine {
         int32_t *scal = st.scal + stream * (int64_t)kNumScal;
         uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
         load_state(r, vec, scal);
+        io.ready();
         vi far_next = io.far(r, 0);
         vi near_next = io.near(r, 0);
         vi clean_next = kHasClean ? io.clean(r, 0) : vi(0);
@@ -1038,6 +1041,7 @@ struct BlockEngine {
         AECM_HD vi near(const Regs &r, int b) const { return W::load_i16(v.near + base + (int64_t)b * v.block_stride, r.lane); }
         AECM_HD vi clean(const Regs &r, int b) const { return W::load_i16(v.near_clean + base + (int64_t)b * v.block_stride, r.lane); }
         AECM_HD void out(const Regs &r, int b, vi val) const { W::store_i16(v.out + base + (int64_t)b * v.block_stride, r.brev, val); }
+        AECM_HD void ready() const {}
     };
     static AECM_HD void run_stream(const StatePtrs &st, const IoView &io, int64_t stream, int n_blocks) {
         StridedIo sio{io, stream * io.stream_stride};
