@@ -1,4 +1,6 @@
 #!/bin/bash
+# Run ON THE GPU BOX: WebRtcAecmSessions tick time per tick form (AECM_TICK_MODE=flow: session machinery on the device, the default;
+# lean: host-side flow classes + run-encoded one-launch tick) for uniform and per-session msInSndCardBuf, several batch sizes.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for rep in 1; do
   for m in flow lean; do

@@ -601,10 +601,17 @@ void aecm_flow_plan_kernel(TickFlowIo fio, int n, unsigned near_pos, int n_strea
     for (int q = 0; q < kFlowPlanWords / 4; ++q) dst[q] = make_int4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
+#ifndef AECM_TICK_FLOW_WAVES_PER_EU
+#define AECM_TICK_FLOW_WAVES_PER_EU AECM_TICK_LEAN_WAVES_PER_EU
+#endif
+#ifndef AECM_TICK_FLOW_WAVES
+#define AECM_TICK_FLOW_WAVES AECM_TICK_LEAN_WAVES
+#endif
+constexpr int kTickFlowWaves = AECM_TICK_FLOW_WAVES;
 template <bool kHasClean>
-__global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
+__global__ __launch_bounds__(64 * kTickFlowWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_FLOW_WAVES_PER_EU, 8)))
 void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_streams) {
-    const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t s = (int64_t)blockIdx.x * kTickFlowWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     // 1. the session's plan for this tick into scalar registers; requested before the table fill so that the fill hides
     //    the latency
@@ -686,7 +693,7 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
 hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowIo &fio, int n_streams, hipStream_t stream) {
     if (n_streams <= 0) return hipSuccess;
     hipLaunchKernelGGL(aecm_flow_plan_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, fio, io.n, (unsigned)io.near_pos, n_streams);
-    const dim3 grid((n_streams + kTickLeanWaves - 1) / kTickLeanWaves), block(64 * kTickLeanWaves);
+    const dim3 grid((n_streams + kTickFlowWaves - 1) / kTickFlowWaves), block(64 * kTickFlowWaves);
     const size_t lds = sizeof(LdsTables);
     if (io.clean_in) hipLaunchKernelGGL((aecm_tick_flow_kernel<true>), grid, block, lds, stream, st, io, fio, n_streams);
     else hipLaunchKernelGGL((aecm_tick_flow_kernel<false>), grid, block, lds, stream, st, io, fio, n_streams);
