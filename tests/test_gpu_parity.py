@@ -830,6 +830,49 @@ def test_session_churn_slots_recycled_mid_run():
         sb.close()
 
 
+@_needs_ref
+def test_sixteen_thousand_sessions_each_with_its_own_history():
+    """The serving shape at scale: 16 384 live sessions, EVERY one with its own msInSndCardBuf walk, its own far-end
+    underruns, its own call shape (one 160-sample call or two of 80) and its own age (slots re-initialised at random
+    ticks) -- more distinct histories than any host-side bookkeeping could follow.  A sample of sessions is compared,
+    tick by tick, with reference sessions that received exactly the same calls."""
+    if aecm.AecmSessions(2, 16000).num_flow_classes() != 0:
+        pytest.skip("needs the device-resident session machinery (AECM_TICK_MODE=flow, the default)")
+    fs, frame, S, n_ticks = 16000, 160, 16384, 150
+    rs = np.random.RandomState(2024)
+    base_far, base_near = synth_pair(4242, (n_ticks * frame + 4096) // 64 + 1, fs, "mixed")
+    shift = rs.randint(0, 4096, size=S)                                  # every session hears its own cut of the recording
+    watch = sorted(set([0, 1, S - 1] + list(rs.randint(0, S, size=21))))
+    refs = {k: pyoracle.RefSession(fs, 1, 3) for k in watch}
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    ms = (20 + rs.randint(0, 80, size=S)).astype(np.int32)
+    idx = np.arange(frame)[None, :]
+    for i in range(n_ticks):
+        pos = (shift + i * frame)[:, None] + idx
+        far, near = base_far[pos], base_near[pos]
+        ms = np.clip(ms + rs.randint(-7, 8, size=S), -20, 560)           # a walk per session, now and then out of range
+        fl = np.where(rs.rand(S) < 0.04, aecm.ffi.SESSION_NO_FAREND, 0).astype(np.uint8)
+        fl |= np.where(rs.rand(S) < 0.3, aecm.ffi.SESSION_SPLIT_CALLS, 0).astype(np.uint8)
+        if i and i % 23 == 0:                                             # churn: a few slots start over (some of them watched)
+            for k in list(rs.randint(0, S, size=6)) + [watch[(i // 23) % len(watch)]]:
+                assert sb.init_session(int(k)) == 0
+                if k in refs:
+                    assert refs[k].init(fs) == 0 and refs[k].set_config(1, 3) == 0
+        rc, out, codes = sb.tick_host_per_session(far, near, ms.astype(np.int16), flags=fl)
+        assert rc in (0, aecm.ffi.AECM_BAD_PARAMETER_WARNING)
+        for k in watch:
+            halves = ((0, 80), (80, 160)) if fl[k] & aecm.ffi.SESSION_SPLIT_CALLS else ((0, 160),)
+            rc_ref = 0
+            for a, b in halves:
+                if not fl[k] & aecm.ffi.SESSION_NO_FAREND:
+                    assert refs[k].buffer_farend(far[k, a:b]) == 0
+                rc1, o1 = refs[k].process(near[k, a:b], None, int(ms[k]))
+                rc_ref = rc_ref or rc1
+                assert np.array_equal(out[k, a:b], o1), (i, k, a)
+            assert codes[k] == rc_ref, (i, k)
+    sb.close()
+
+
 def test_tick_argument_validation():
     """nrOfSamples is validated as a size_t (2^32 + 80 is not 80), strides must cover the tick."""
     import ctypes as C

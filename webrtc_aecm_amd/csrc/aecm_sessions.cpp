@@ -407,9 +407,11 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st)))
             return AECM_UNSPECIFIED_ERROR;
     }
-    if (flags_per_session && n != 160)
-        for (int s = 0; s < S; ++s)
-            if (flags_per_session[s] & kSplitCalls) return AECM_BAD_PARAMETER_ERROR;      // two 80-sample calls need 160 samples
+    if (flags_per_session && n != 160) {
+        uint8_t any = 0;
+        for (int s = 0; s < S; ++s) any |= flags_per_session[s];
+        if (any & kSplitCalls) return AECM_BAD_PARAMETER_ERROR;                           // two 80-sample calls need 160 samples
+    }
     if (flow_mode_) return TickFlow(far, near, clean, out, stride, n, ms, ms_per_session, flags_per_session, codes, host_pointers);
     // 1. which class every session is in for this tick
     if (ms_per_session || flags_per_session) {
@@ -542,10 +544,19 @@ int32_t SessionBatch::TickFlow(const int16_t *far, const int16_t *near, const in
     auto code_of = [](int16_t v) -> int32_t { return (v < 0 || v > 500) ? AECM_BAD_PARAMETER_WARNING : 0; };
     int32_t first_rc = 0;
     if (ms_per_session) {
-        for (int s = 0; s < S; ++s) {
-            const int32_t rc = code_of(ms_per_session[s]);
-            if (codes) codes[s] = rc;
-            if (rc != 0 && first_rc == 0) first_rc = rc;
+        int lo = ms_per_session[0], hi = lo;                                // one vectorisable pass; the per-session codes
+        for (int s = 1; s < S; ++s) {                                       // only need a second one when somebody is out of range
+            lo = std::min<int>(lo, ms_per_session[s]);
+            hi = std::max<int>(hi, ms_per_session[s]);
+        }
+        if (lo < 0 || hi > 500) {
+            for (int s = 0; s < S; ++s) {
+                const int32_t rc = code_of(ms_per_session[s]);
+                if (codes) codes[s] = rc;
+                if (rc != 0 && first_rc == 0) first_rc = rc;
+            }
+        } else if (codes) {
+            memset(codes, 0, (size_t)S * sizeof(int32_t));
         }
         memcpy(ms_host_, ms_per_session, (size_t)S * sizeof(int16_t));      // pinned; the previous tick ended with a synchronisation
         if (!AECM_HIP_OK(hipMemcpyAsync(ms_dev_, ms_host_, (size_t)S * sizeof(int16_t), hipMemcpyHostToDevice, st))) return fail();
