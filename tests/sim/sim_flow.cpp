@@ -33,7 +33,7 @@ struct DeviceSide {
     FlowRegs regs;
     std::vector<int64_t> far_ring, near_ring, out_ring, far_frames, far_old;
     uint32_t near_pos = 0;
-    int64_t blocks_done = 0;
+    int64_t blocks_done = 0, direct_ticks = 0, spill_ticks = 0;
     explicit DeviceSide() : far_ring(kRingLen, kNone), near_ring(kRingLen, kNone), out_ring(kRingLen, kNone), far_frames(kFlowFarFrameRing, kNone),
                             far_old(2 * kFlowFrame, kNone) {
         int32_t words[kFlowWords];
@@ -54,28 +54,36 @@ struct DeviceSide {
                 if (j >= p.far[c].src && j < p.far[c].src + p.far[c].count) far_ring[(p.far[c].pos + (uint32_t)(j - p.far[c].src)) & mask] = far_in[j];
             near_ring[(near_pos + (uint32_t)j) & mask] = near_in[j];
         }
-        // the far frames: every frame's 80 samples are fetched before any frame's are stored (the kernel issues all loads,
-        // then all stores)
-        int64_t frames[2][kFlowFrame];
-        for (int f = 0; f < p.n_frames; ++f) {
-            const FlowFrame &q = p.frame[f];
-            if (!q.active) continue;
-            for (int j = 0; j < kFlowFrame; ++j)
-                frames[f][j] = q.far_from_stream ? far_ring[(q.far_pos + (uint32_t)j) & mask] : far_old[q.old_idx * kFlowFrame + j];
-        }
-        for (int f = 0; f < p.n_frames; ++f) {
-            const FlowFrame &q = p.frame[f];
-            if (!q.active) continue;
-            for (int j = 0; j < kFlowFrame; ++j) {
-                far_frames[(q.frm_pos + (uint32_t)j) & (kFlowFarFrameRing - 1)] = frames[f][j];
-                if (q.far_from_stream == 1) far_old[q.old_idx * kFlowFrame + j] = frames[f][j];
+        // replay frames about to leave the far ring move to their rows first
+        for (int i = 0; i < 2; ++i)
+            if (p.spill[i])
+                for (int j = 0; j < kFlowFrame; ++j) far_old[i * kFlowFrame + j] = far_ring[(p.spill_pos[i] + (uint32_t)j) & mask];
+        spill_ticks += p.spill[0] + p.spill[1];
+        direct_ticks += p.direct;
+        if (!p.direct) {
+            // framing: the pending samples the direct ticks before left in the far ring, then the tick's frames; every
+            // load before any store, as in the kernel
+            int64_t left[kFlowBlock], frames[2][kFlowFrame];
+            for (int j = 0; j < p.left_count; ++j) left[j] = far_ring[(p.blk_pos0 + p.left_delta + (uint32_t)j) & mask];
+            for (int f = 0; f < p.n_frames; ++f) {
+                const FlowFrame &q = p.frame[f];
+                if (!q.active) continue;
+                for (int j = 0; j < kFlowFrame; ++j)
+                    frames[f][j] = q.far_from_stream ? far_ring[(q.far_pos + (uint32_t)j) & mask] : far_old[q.old_idx * kFlowFrame + j];
+            }
+            for (int j = 0; j < p.left_count; ++j) far_frames[(p.blk_pos0 + (uint32_t)j) & (kFlowFarFrameRing - 1)] = left[j];
+            for (int f = 0; f < p.n_frames; ++f) {
+                const FlowFrame &q = p.frame[f];
+                if (!q.active) continue;
+                for (int j = 0; j < kFlowFrame; ++j) far_frames[(q.frm_pos + (uint32_t)j) & (kFlowFarFrameRing - 1)] = frames[f][j];
             }
         }
         for (int b = 0; b < p.n_blocks; ++b, ++blocks_done)
             for (int t = 0; t < kFlowBlock; ++t) {
-                blk_far->push_back(far_frames[(p.blk_pos0 + (uint32_t)(b * kFlowBlock + t)) & (kFlowFarFrameRing - 1)]);
-                blk_near->push_back(near_ring[(p.near_base + p.blk_pos0 + (uint32_t)(b * kFlowBlock + t)) & mask]);
-                out_ring[(p.blk_pos0 + (uint32_t)(b * kFlowBlock + t)) & mask] = kOutTagBase + blocks_done * kFlowBlock + t;
+                const uint32_t x = p.blk_pos0 + (uint32_t)(b * kFlowBlock + t);
+                blk_far->push_back(p.direct ? far_ring[(x + p.far_delta) & mask] : far_frames[x & (kFlowFarFrameRing - 1)]);
+                blk_near->push_back(near_ring[(p.near_base + x) & mask]);
+                out_ring[x & mask] = kOutTagBase + blocks_done * kFlowBlock + t;
             }
         for (int f = 0; f < p.n_frames; ++f)
             for (int j = 0; j < kFlowFrame; ++j)
@@ -91,7 +99,8 @@ extern "C" {
 // Drives one session through n_ticks ticks of a call pattern drawn from `scenario` on both sides.  Returns -1 when every
 // block input and every output sample agreed, else the first tick that differed; detail[0] = what differed (1 block
 // count, 2 far block tags, 3 near block tags, 4 output, 5 return code), detail[1] = blocks processed in total,
-// detail[2] = ticks spent past the start-up phase, detail[3] = ticks in which the jitter buffer dropped far samples.
+// detail[2] = ticks spent past the start-up phase, detail[3] = ticks in which the jitter buffer dropped far samples,
+// detail[4] = ticks whose blocks fetched the far end from the far ring directly, detail[5] = replay frames moved to rows.
 int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t start_pos, int64_t *detail) {
     Rng rng{seed * 2654435761ull + 12345};
     DeviceSide dev;
@@ -103,7 +112,7 @@ int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t
     ref.Init(fs);
     int64_t far_offered = 0, near_offered = 0, ref_blocks = 0;
     int ms_walk = 40;
-    detail[0] = detail[1] = detail[2] = detail[3] = 0;
+    for (int i = 0; i < 6; ++i) detail[i] = 0;
     for (int64_t tick = 0; tick < n_ticks; ++tick) {
         int n = fs == 16000 ? 160 : 80, ms = 40, flags = 0;
         switch (scenario) {
@@ -116,6 +125,13 @@ int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t
                     if (rng.chance(8)) flags |= kFlowNoFarend; if (rng.chance(50)) flags |= kFlowSplitCalls; break;
             case 6: ms = (tick / 200) % 2 ? 480 : 10; if (rng.chance(2)) flags |= kFlowNoFarend; break;   // delay steps: stuffing and skipping
             case 7: n = 160; flags = rng.chance(70) ? kFlowSplitCalls : 0; ms = rng.range(0, 80); if (tick % 50 < 10) flags |= kFlowNoFarend; break;
+            case 9: {                                                           // replay slot 1 goes unused for so long that its frame leaves
+                const int ph = (int)(tick % 200);                               // the far ring (two 80-sample calls only use slot 0), then both
+                n = 160; ms = rng.range(35, 45);                                // slots are replayed in a run of underruns
+                if (ph >= 60 && ph < 150) flags |= kFlowSplitCalls;
+                if (ph >= 138 && ph < 160) flags |= kFlowNoFarend;
+                break;
+            }
             default: n = rng.chance(20) ? 80 : 160; ms = rng.range(0, 200); flags = rng.range(0, 3); break;
         }
         if (n != 160) flags &= ~kFlowSplitCalls;
@@ -145,6 +161,8 @@ int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t
         }
         const int32_t rc_dev = (ms < 0 || ms > 500) ? kWarnBadParameter : 0;
         detail[1] = ref_blocks;
+        detail[4] = dev.direct_ticks;
+        detail[5] = dev.spill_ticks;
         int what = 0;
         if (dfar.size() != rfar.size()) what = 1;
         else if (dfar != rfar) what = 2;

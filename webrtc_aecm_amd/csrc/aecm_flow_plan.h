@@ -49,6 +49,11 @@ enum FlowField : int {
     F_FRM_POS,                  // frame stream: samples written into the frame rings (far and near alike)
     F_BLK_POS,                  // frame stream: samples consumed as blocks = 64 * blocks processed = output stream written
     F_OUT_RP,                   // output stream: read pointer of the output frame ring (moves back when stuffing)
+    F_RUN_POS,                  // frame stream: from this position on the framed far end is ONE run of the far stream ...
+    F_RUN_DELTA,                // ... namely frame-stream position x = far-stream position x + F_RUN_DELTA
+    F_FF_VALID,                 // the framed-far ring holds the pending frame-stream samples [F_BLK_POS, F_FRM_POS)
+    F_OLD_POS0, F_OLD_POS1,     // farendOld[i] (the frame replayed on an underrun) = far stream [F_OLD_POS_i, + 80) ...
+    F_OLD_ROW0, F_OLD_ROW1,     // ... unless 1: it has been copied to replay row i (initially: the zeroed row)
     kFlowFieldsUsed,
     kFlowWords = 32
 };
@@ -58,6 +63,8 @@ constexpr int kFlowBlock = 64;                      // PART_LEN
 constexpr int kFlowJitterCapacity = 50 * 80;        // kBufSizeSamp = BUF_SIZE_FRAMES * FRAME_LEN (:29-36)
 constexpr int kFlowFarFrameRing = 256;              // ring of the framed far stream on the device (>= 143 + 80, power of two)
 constexpr int kFlowNoFarend = 1, kFlowSplitCalls = 2;   // = SessionBatch::kNoFarend / kSplitCalls
+constexpr int kFlowFarRing = 8192;                  // far ring of the device: positions older than this many accepted samples are gone
+constexpr int kFlowOldAge = kFlowFarRing - 5 * kFlowFrame;   // a replay frame this far behind the write position moves to its row
 
 struct FlowFarPiece {          // far_in[src, src + count) -> far stream positions [pos, pos + count)
     int32_t src, count;
@@ -65,9 +72,8 @@ struct FlowFarPiece {          // far_in[src, src + count) -> far stream positio
 };
 struct FlowFrame {             // one 80-sample frame of the tick (input samples [80 f, 80 f + 80))
     int32_t active;            // 0: its call was served by the start-up copy (out = clean or noisy near-end, :285-291)
-    int32_t far_from_stream;   // 1: far frame = far stream [far_pos, far_pos + 80), kept in replay row old_idx; 0: replay of that
-                               // row as it was before this tick; 2: replay of what an earlier frame of this tick put into the
-                               // row = far stream [far_pos, far_pos + 80) again (so no frame depends on another's stores)
+    int32_t far_from_stream;   // 1: far frame = far stream [far_pos, far_pos + 80) (a fresh frame, or the replay of one that is
+                               // still in the far ring); 0: replay row old_idx
     uint32_t far_pos;
     int32_t old_idx;
     uint32_t frm_pos;          // where the frame lands in the frame stream
@@ -80,6 +86,16 @@ struct FlowPlan {
     int32_t n_calls, n_frames, n_blocks;
     uint32_t blk_pos0;         // frame-stream / output-stream position of the tick's first block
     uint32_t near_base;        // frame-stream position x of the near end sits at near-ring position near_base + x
+    // direct: every far sample the tick's blocks consume belongs to one run of the far stream (no replay, re-read or skip
+    // since the oldest of them was framed): block sample x is far-stream sample x + far_delta, the blocks fetch from the
+    // far ring itself and nothing is framed.  Otherwise the tick's frames go through the framed-far ring, preceded --
+    // when the previous ticks were direct -- by the left_count pending samples [blk_pos0, ..) = far stream + left_delta.
+    int32_t direct;
+    uint32_t far_delta;
+    int32_t left_count;
+    uint32_t left_delta;
+    int32_t spill[2];          // replay frame i is about to leave the far ring: far stream [spill_pos[i], + 80) -> replay row i
+    uint32_t spill_pos[2];
 };
 
 struct FlowRegs {              // FlowField values in registers
@@ -90,12 +106,13 @@ AECM_FLOW_HD int32_t FlowAsShort(int32_t x) { return (int32_t)(int16_t)x; }
 AECM_FLOW_HD int32_t FlowMin(int32_t a, int32_t b) { return a < b ? a : b; }
 AECM_FLOW_HD int32_t FlowMax(int32_t a, int32_t b) { return a > b ? a : b; }
 
-// State after WebRtcAecm_Init (echo_control_mobile.cc:142-191): everything 0 except the three start-up flags.
+// State after WebRtcAecm_Init (echo_control_mobile.cc:142-191): everything 0 except the three start-up flags (and the
+// flags that say where the device keeps things).
+AECM_FLOW_HD bool FlowFieldStartsAtOne(int f) {
+    return f == F_DELAY_CHANGE || f == F_CHECK_BUFF_SIZE || f == F_EC_STARTUP || f == F_FF_VALID || f == F_OLD_ROW0 || f == F_OLD_ROW1;
+}
 AECM_FLOW_HD void FlowInit(int32_t words[kFlowWords]) {
-    for (int i = 0; i < kFlowWords; ++i) words[i] = 0;
-    words[F_DELAY_CHANGE] = 1;
-    words[F_CHECK_BUFF_SIZE] = 1;
-    words[F_EC_STARTUP] = 1;
+    for (int i = 0; i < kFlowWords; ++i) words[i] = i < kFlowFieldsUsed && FlowFieldStartsAtOne(i) ? 1 : 0;
 }
 
 // WebRtc_MoveReadPtr of the jitter buffer (ring_buffer.c:176-211): clamped to what is readable / free.
@@ -198,11 +215,21 @@ AECM_FLOW_HD void FlowTick(FlowRegs &s, int fs, int n, int ms, int flags, uint32
     p.n_blocks = 0;
     p.blk_pos0 = (uint32_t)s.v[F_BLK_POS];
     p.near_base = 0;
+    p.direct = 0;
+    p.far_delta = p.left_delta = 0;
+    p.left_count = 0;
+    const uint32_t frm_start = (uint32_t)s.v[F_FRM_POS], run_delta_start = (uint32_t)s.v[F_RUN_DELTA];
+    // A replay frame that still lives in the far ring only is copied to its row before the ring's write position laps it.
+    // The row takes over from the NEXT tick on: a replay in this tick still reads the ring, so nothing in the tick depends
+    // on the copy.
+    int32_t refreshed[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {
+        p.spill_pos[i] = (uint32_t)s.v[F_OLD_POS0 + i];
+        p.spill[i] = !s.v[F_OLD_ROW0 + i] && (int32_t)((uint32_t)s.v[F_FAR_WP] - (uint32_t)s.v[F_OLD_POS0 + i]) > kFlowOldAge;
+    }
     for (int f = 0; f < 2; ++f) p.frame[f] = FlowFrame{0, 0, 0u, 0, 0u, 0, 0u};
     for (int c = 0; c < 2; ++c) p.far[c] = FlowFarPiece{c * len, 0, (uint32_t)s.v[F_FAR_WP]};
     ms = ms < 0 ? 0 : ms > 500 ? 500 : ms;                                                   // :258-265 (the warning is the host's business)
-    int32_t row_fresh[2] = {0, 0};        // replay row i was refreshed in this tick, from far stream position row_pos[i]
-    uint32_t row_pos[2] = {0u, 0u};
     // Frame slot of frame i of call c: c * frames_per_call + i = c + i for the three shapes there are (1 x 1, 1 x 2,
     // 2 x 1); both loops have constant bounds so that the plan stays in registers on the device.
 #if defined(__HIPCC__)
@@ -237,16 +264,26 @@ AECM_FLOW_HD void FlowTick(FlowRegs &s, int fs, int n, int ms, int flags, uint32
             if (FlowAsShort(FlowAsShort(avail) / kFlowFrame) > 0) {                              // :369-375
                 fr.far_from_stream = 1;
                 fr.far_pos = (uint32_t)s.v[F_FAR_RP];
-                row_fresh[i] = 1;
-                row_pos[i] = fr.far_pos;
+                s.v[F_OLD_POS0 + i] = (int32_t)fr.far_pos;                                       // farendOld[i] = this frame (:373)
+                s.v[F_OLD_ROW0 + i] = 0;
+                refreshed[i] = 1;
                 s.v[F_FAR_RP] = (int32_t)((uint32_t)s.v[F_FAR_RP] + (uint32_t)kFlowFrame);
-            } else if (row_fresh[i]) {                                                        // :376-379, of a row this tick refreshed
-                fr.far_from_stream = 2;
-                fr.far_pos = row_pos[i];
+            } else if (!s.v[F_OLD_ROW0 + i]) {                                                   // :376-379: replay, still in the far ring
+                fr.far_from_stream = 1;
+                fr.far_pos = (uint32_t)s.v[F_OLD_POS0 + i];
             }
             if ((i == 0 && fs == 8000) || (i == 1 && fs == 16000)) FlowEstBufDelay(s, mult);   // :384-387
             // WebRtcAecm_ProcessFrame (aecm_core.cc:501-572); the core's far delay line is a pass-through (knownDelay 0)
             fr.frm_pos = (uint32_t)s.v[F_FRM_POS];
+            if (fr.far_from_stream) {                       // does this frame continue the run of the far stream the previous one ended?
+                const int32_t delta = (int32_t)(fr.far_pos - fr.frm_pos);
+                if (delta != s.v[F_RUN_DELTA]) {
+                    s.v[F_RUN_DELTA] = delta;
+                    s.v[F_RUN_POS] = (int32_t)fr.frm_pos;
+                }
+            } else {
+                s.v[F_RUN_POS] = (int32_t)(fr.frm_pos + (uint32_t)kFlowFrame);   // a replay row is no part of the far stream
+            }
             p.near_base = near_pos + (uint32_t)(kFlowFrame * (c + i)) - fr.frm_pos;
             s.v[F_FRM_POS] = (int32_t)(fr.frm_pos + (uint32_t)kFlowFrame);
             int nb = 0;
@@ -262,6 +299,21 @@ AECM_FLOW_HD void FlowTick(FlowRegs &s, int fs, int n, int ms, int flags, uint32
             s.v[F_OUT_RP] = (int32_t)(fr.out_pos + (uint32_t)kFlowFrame);
         }
     }
+    for (int i = 0; i < 2; ++i)
+        if (p.spill[i] && !refreshed[i]) s.v[F_OLD_ROW0 + i] = 1;
+    if (p.frame[0].active || p.frame[1].active) {          // every active frame completes at least one block
+        if ((int32_t)((uint32_t)s.v[F_RUN_POS] - p.blk_pos0) <= 0) {
+            p.direct = 1;
+            p.far_delta = (uint32_t)s.v[F_RUN_DELTA];
+            s.v[F_FF_VALID] = 0;
+        } else {
+            if (!s.v[F_FF_VALID]) {                         // the ticks before were direct: their run covers what is pending
+                p.left_count = (int32_t)(frm_start - p.blk_pos0);
+                p.left_delta = run_delta_start;
+            }
+            s.v[F_FF_VALID] = 1;
+        }
+    }
 }
 
 // The plan as the kFlowPlanWords int32 the two kernels exchange.
@@ -269,18 +321,18 @@ constexpr int kFlowPlanWords = 16;
 enum FlowPlanWord : int {
     P_FAR_COUNTS = 0,     // far[0].count | far[1].count << 16   (far[c].src = c * 80: a second piece only exists for two 80-sample calls)
     P_FAR_POS0, P_FAR_POS1,
-    P_BITS,               // frame f at bits [8 f, 8 f + 8): active | far_from_stream << 1 | old_idx << 3 | n_blocks << 4;  n_frames << 16, n_blocks << 20
+    P_BITS,               // frame f at bits [4 f, 4 f + 4): active | far_from_stream << 1 | old_idx << 2 | spill[f] << 3;
+                          // n_frames << 8, n_blocks << 12, direct << 16, left_count << 20
     P_FRAME_FAR_POS0, P_FRAME_FAR_POS1, P_FRM_POS0, P_FRM_POS1, P_OUT_POS0, P_OUT_POS1,
-    P_BLK_POS0, P_NEAR_BASE
+    P_BLK_POS0, P_NEAR_BASE, P_FAR_DELTA, P_LEFT_DELTA, P_SPILL_POS0, P_SPILL_POS1
 };
 AECM_FLOW_HD void FlowPackPlan(const FlowPlan &p, int32_t w[kFlowPlanWords]) {
-    for (int i = 0; i < kFlowPlanWords; ++i) w[i] = 0;
     w[P_FAR_COUNTS] = p.far[0].count | (p.far[1].count << 16);
     w[P_FAR_POS0] = (int32_t)p.far[0].pos;
     w[P_FAR_POS1] = (int32_t)p.far[1].pos;
-    int32_t bits = (p.n_frames << 16) | (p.n_blocks << 20);
+    int32_t bits = (p.n_frames << 8) | (p.n_blocks << 12) | (p.direct << 16) | (p.left_count << 20);
     for (int f = 0; f < 2; ++f)
-        bits |= (p.frame[f].active | (p.frame[f].far_from_stream << 1) | (p.frame[f].old_idx << 3) | (p.frame[f].n_blocks << 4)) << (8 * f);
+        bits |= (p.frame[f].active | (p.frame[f].far_from_stream << 1) | (p.frame[f].old_idx << 2) | (p.spill[f] << 3)) << (4 * f);
     w[P_BITS] = bits;
     w[P_FRAME_FAR_POS0] = (int32_t)p.frame[0].far_pos;
     w[P_FRAME_FAR_POS1] = (int32_t)p.frame[1].far_pos;
@@ -290,22 +342,32 @@ AECM_FLOW_HD void FlowPackPlan(const FlowPlan &p, int32_t w[kFlowPlanWords]) {
     w[P_OUT_POS1] = (int32_t)p.frame[1].out_pos;
     w[P_BLK_POS0] = (int32_t)p.blk_pos0;
     w[P_NEAR_BASE] = (int32_t)p.near_base;
+    w[P_FAR_DELTA] = (int32_t)p.far_delta;
+    w[P_LEFT_DELTA] = (int32_t)p.left_delta;
+    w[P_SPILL_POS0] = (int32_t)p.spill_pos[0];
+    w[P_SPILL_POS1] = (int32_t)p.spill_pos[1];
 }
-// far[1].src is the length of the first call: 80 whenever there is a second piece.
+// far[1].src is the length of the first call: 80 whenever there is a second piece.  (Per-frame block counts do not travel.)
 AECM_FLOW_HD void FlowUnpackPlan(const int32_t w[kFlowPlanWords], FlowPlan &p) {
     p.far[0] = FlowFarPiece{0, w[P_FAR_COUNTS] & 0xffff, (uint32_t)w[P_FAR_POS0]};
     p.far[1] = FlowFarPiece{kFlowFrame, (int32_t)((uint32_t)w[P_FAR_COUNTS] >> 16), (uint32_t)w[P_FAR_POS1]};
     const int32_t bits = w[P_BITS];
     p.n_calls = 0;
-    p.n_frames = (bits >> 16) & 15;
-    p.n_blocks = (bits >> 20) & 15;
+    p.n_frames = (bits >> 8) & 15;
+    p.n_blocks = (bits >> 12) & 15;
+    p.direct = (bits >> 16) & 1;
+    p.left_count = (bits >> 20) & 127;
     for (int f = 0; f < 2; ++f) {
-        const int32_t b = (bits >> (8 * f)) & 0xff;
-        p.frame[f] = FlowFrame{b & 1, (b >> 1) & 3, (uint32_t)w[P_FRAME_FAR_POS0 + f], (b >> 3) & 1, (uint32_t)w[P_FRM_POS0 + f], (b >> 4) & 15,
+        const int32_t b = (bits >> (4 * f)) & 15;
+        p.frame[f] = FlowFrame{b & 1, (b >> 1) & 1, (uint32_t)w[P_FRAME_FAR_POS0 + f], (b >> 2) & 1, (uint32_t)w[P_FRM_POS0 + f], 0,
                                (uint32_t)w[P_OUT_POS0 + f]};
+        p.spill[f] = (b >> 3) & 1;
+        p.spill_pos[f] = (uint32_t)w[P_SPILL_POS0 + f];
     }
     p.blk_pos0 = (uint32_t)w[P_BLK_POS0];
     p.near_base = (uint32_t)w[P_NEAR_BASE];
+    p.far_delta = (uint32_t)w[P_FAR_DELTA];
+    p.left_delta = (uint32_t)w[P_LEFT_DELTA];
 }
 
 }  // namespace aecm

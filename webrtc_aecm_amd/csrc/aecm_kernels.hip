@@ -44,9 +44,27 @@ hipError_t ReadCheckCounters(uint64_t counters[2], bool reset) {
 }
 
 // The LDS tables are an image inside the host-built constants blob: one coalesced copy per workgroup.
+// kThreads = the workgroup size, a compile-time constant: the copy loop then needs nothing from the dispatch packet (a
+// scalar load whose wait would also hold up every other scalar load in flight at kernel entry).
+template <int kThreads>
 __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
-    uint32_t *lds = reinterpret_cast<uint32_t *>(&g_lds[0]);
-    for (int i = threadIdx.x; i < kConstBlobWords; i += blockDim.x) lds[i] = consts[i];
+    static_assert(kConstBlobWords % 4 == 0, "the constants blob is copied 16 bytes at a time");
+    constexpr int kVecs = kConstBlobWords / 4, kPasses = (kVecs + kThreads - 1) / kThreads;
+    const int4 *src = reinterpret_cast<const int4 *>(consts);
+    int4 *dst = reinterpret_cast<int4 *>(&g_lds[0]);
+    int4 tmp[kPasses];                                   // every load in flight before the first LDS store
+    // Indices are clamped instead of predicated (the last vector is then copied by several threads, harmlessly): with
+    // predicates the compiler sinks each load next to its store and the passes wait for each other.
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+        const int i = (int)threadIdx.x + k * kThreads;
+        tmp[k] = src[i < kVecs ? i : kVecs - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+        const int i = (int)threadIdx.x + k * kThreads;
+        dst[i < kVecs ? i : kVecs - 1] = tmp[k];
+    }
     __syncthreads();
 }
 
@@ -67,7 +85,7 @@ __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
 template <bool kFast, bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, const int32_t *blocks_per_stream) {
-    FillLdsTables(st.consts);
+    FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t stream = (int64_t)blockIdx.x * kWavesPerWorkgroup + wave;
     if (stream >= n_streams) return;
@@ -403,7 +421,7 @@ __device__ __forceinline__ void TickSession(const StatePtrs &st, const TickIo &i
 template <bool kFast, bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_TICK_WAVES_PER_EU, 8)))
 void aecm_tick_kernel(StatePtrs st, TickIo io, int n_streams, TickClassEntry single) {
-    FillLdsTables(st.consts);
+    FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
     const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (s >= n_streams) return;
     TickSession<kFast, kHasClean>(st, io, s, &single);
@@ -411,7 +429,7 @@ void aecm_tick_kernel(StatePtrs st, TickIo io, int n_streams, TickClassEntry sin
 template <bool kFast, bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_TICK_WAVES_PER_EU, 8)))
 void aecm_tick_classes_kernel(StatePtrs st, TickIo io, int n_streams, const int32_t *class_of_stream, const TickClassEntry *table) {
-    FillLdsTables(st.consts);
+    FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
     const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (s >= n_streams) return;
     TickSession<kFast, kHasClean>(st, io, s, table + __builtin_amdgcn_readfirstlane(class_of_stream[s]));
@@ -534,7 +552,7 @@ constexpr int kTickLeanWaves = AECM_TICK_LEAN_WAVES;
 template <bool kHasClean>
 __global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
 void aecm_tick_lean_kernel(StatePtrs st, TickIo io, int n_streams, TickLeanEntry single) {
-    FillLdsTables(st.consts);
+    FillLdsTables<64 * kTickLeanWaves>(st.consts);
     const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (s >= n_streams) return;
     TickSessionLean<kHasClean>(st, io, s, &single);
@@ -543,7 +561,7 @@ template <bool kHasClean>
 __global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
 void aecm_tick_lean_classes_kernel(StatePtrs st, TickIo io, int n_streams, const int32_t *__restrict__ class_of_stream,
                                    const TickLeanEntry *__restrict__ table) {
-    FillLdsTables(st.consts);
+    FillLdsTables<64 * kTickLeanWaves>(st.consts);
     const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (s >= n_streams) return;
     TickSessionLean<kHasClean>(st, io, s, table + __builtin_amdgcn_readfirstlane(class_of_stream[s]));
@@ -570,14 +588,15 @@ template <bool kHasClean>
 struct TickFlowBlockIo {
     using E = BlockEngine<Gfx950Wave<true>, kHasClean>;
     using Regs = typename E::Regs;
-    const int16_t *ff, *nr, *cr;     // framed far stream, near / clean rings of this session
+    const int16_t *far_src;          // the far ring itself (direct ticks) or the framed far stream
+    const int16_t *nr, *cr;          // near / clean rings of this session
     int16_t *out_row;                // output stream ring
-    int mask;
-    unsigned far_pos, near_pos;      // positions of the tick's first block
-    __device__ __forceinline__ int far(const Regs &r, int b) const { return ff[(far_pos + b * kBlock + r.lane) & (kFlowFarFrameRing - 1)]; }
+    int far_mask, mask;
+    unsigned far_pos, near_pos, out_pos;      // positions of the tick's first block in far_src / the near rings / the output ring
+    __device__ __forceinline__ int far(const Regs &r, int b) const { return far_src[(far_pos + b * kBlock + r.lane) & far_mask]; }
     __device__ __forceinline__ int near(const Regs &r, int b) const { return nr[(near_pos + b * kBlock + r.lane) & mask]; }
     __device__ __forceinline__ int clean(const Regs &r, int b) const { return cr[(near_pos + b * kBlock + r.lane) & mask]; }
-    __device__ __forceinline__ void out(const Regs &r, int b, int v) const { out_row[(far_pos + b * kBlock + r.brev) & mask] = (int16_t)v; }
+    __device__ __forceinline__ void out(const Regs &r, int b, int v) const { out_row[(out_pos + b * kBlock + r.brev) & mask] = (int16_t)v; }
     // this wave's fetches below must see this wave's stores (the tick's samples, the framed far end); the engine's state
     // loads are already in flight
     __device__ __forceinline__ void ready() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -620,7 +639,7 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
         const int32_t *pw = fio.plans + (s < n_streams ? s : 0) * kFlowPlanWords;
         for (int k = 0; k < kFlowPlanWords; ++k) w[k] = pw[k];
     }
-    FillLdsTables(st.consts);
+    FillLdsTables<64 * kTickFlowWaves>(st.consts);
     if (s >= n_streams) return;
     FlowPlan p;
     FlowUnpackPlan(w, p);
@@ -634,49 +653,59 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
     int16_t *ff = fio.far_frames + s * kFlowFarFrameRing, *old = fio.far_old + s * (2 * kFlowFrame);
     int16_t *out = io.out + s * io.io_stride;
     // 2. the tick's samples into the rings: what the jitter buffer accepted of the far end, all of the near end
-    auto append = [&]() {
-        for (int j = lane; j < n; j += 64) {
-            for (int c = 0; c < 2; ++c)
-                if (j >= p.far[c].src && j < p.far[c].src + p.far[c].count) fr[(p.far[c].pos + (unsigned)(j - p.far[c].src)) & mask] = fin[j];
-            nr[((unsigned)io.near_pos + j) & mask] = nin[j];
-            if (kHasClean) cr[((unsigned)io.near_pos + j) & mask] = cin[j];
+    for (int j = lane; j < n; j += 64) {
+        for (int c = 0; c < 2; ++c)
+            if (j >= p.far[c].src && j < p.far[c].src + p.far[c].count) fr[(p.far[c].pos + (unsigned)(j - p.far[c].src)) & mask] = fin[j];
+        nr[((unsigned)io.near_pos + j) & mask] = nin[j];
+        if (kHasClean) cr[((unsigned)io.near_pos + j) & mask] = cin[j];
+    }
+    // 3. the far end of the tick's blocks.  Usually (p.direct) it is one run of the far stream and the blocks fetch it from
+    //    the far ring itself.  Otherwise (an underrun replay, a jump of the jitter buffer's read pointer, the first tick
+    //    after start-up) the frames are laid out in the framed-far ring first.
+    //    No fences here: a conditional fence before the engine's state loads makes the compiler fetch the scalar half of
+    //    the state with vector loads.  None is needed either: the row a spill fills is not read before the next tick, and
+    //    far samples that arrived in this very tick are taken from the input row instead of the ring.
+    if (p.spill[0] | p.spill[1]) {           // rare: a replay frame is about to be lapped in the far ring -> its row
+        for (int i = 0; i < 2; ++i) {
+            if (!p.spill[i]) continue;
+            int16_t *row = old + i * kFlowFrame;
+            const int16_t a0 = fr[(p.spill_pos[i] + lane) & mask], a1 = fr[(p.spill_pos[i] + 64 + (lane & 15)) & mask];
+            row[lane] = a0;
+            if (lane < kFlowFrame - 64) row[64 + lane] = a1;
         }
-    };
-    // 3. the far frames of the tick: far stream (or replay row) -> framed far stream (and replay row).  All loads are
-    //    issued before any store (FlowTick resolved same-tick replays to stream positions, so no frame depends on another
-    //    frame's stores), and they only have to wait for the appends when a frame reaches into this very tick's samples
-    //    (a nearly empty jitter buffer).
-    bool reaches_new = false;
-    for (int f = 0; f < 2; ++f)
-        reaches_new = reaches_new || (p.frame[f].active && p.frame[f].far_from_stream && (int)(p.frame[f].far_pos + kFlowFrame - p.far[0].pos) > 0);
-    if (reaches_new) {
-        append();
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // this wave's loads below must see this wave's stores
     }
-    int16_t v0[2] = {0, 0}, v1[2] = {0, 0};                          // frame f: samples lane and 64 + lane (lanes 0..15)
-    for (int f = 0; f < 2; ++f) {
-        const FlowFrame &q = p.frame[f];
-        if (!q.active) continue;
-        const int16_t *row = old + q.old_idx * kFlowFrame;
-        v0[f] = q.far_from_stream ? fr[(q.far_pos + lane) & mask] : row[lane];
-        if (lane < kFlowFrame - 64) v1[f] = q.far_from_stream ? fr[(q.far_pos + 64 + lane) & mask] : row[64 + lane];
-    }
-    if (!reaches_new) append();
-    for (int f = 0; f < 2; ++f) {
-        const FlowFrame &q = p.frame[f];
-        if (!q.active) continue;
-        int16_t *row = old + q.old_idx * kFlowFrame;
-        ff[(q.frm_pos + lane) & (kFlowFarFrameRing - 1)] = v0[f];
-        if (q.far_from_stream == 1) row[lane] = v0[f];
-        if (lane < kFlowFrame - 64) {
-            ff[(q.frm_pos + 64 + lane) & (kFlowFarFrameRing - 1)] = v1[f];
-            if (q.far_from_stream == 1) row[64 + lane] = v1[f];
+    if (!p.direct && (p.frame[0].active | p.frame[1].active)) {
+        // far stream position q, from the ring -- or, if it was appended in this tick (a nearly empty jitter buffer), from
+        // the piece of the input row it came from
+        auto far_stream = [&](unsigned q) -> int16_t {
+            const int r0 = (int)(q - p.far[0].pos), r1 = (int)(q - p.far[1].pos);
+            const bool in0 = r0 >= 0 && r0 < p.far[0].count, in1 = r1 >= 0 && r1 < p.far[1].count;
+            const int16_t ring = fr[q & mask], fresh = fin[in0 ? r0 : in1 ? p.far[1].src + r1 : 0];
+            return (in0 || in1) ? fresh : ring;
+        };
+        // every load before any store: what direct ticks left pending in the far ring, then the tick's frames
+        int16_t left = 0, v0[2] = {0, 0}, v1[2] = {0, 0};            // frame f: samples lane and 64 + lane (lanes 0..15)
+        if (lane < p.left_count) left = fr[(p.blk_pos0 + p.left_delta + lane) & mask];
+        for (int f = 0; f < 2; ++f) {
+            const FlowFrame &q = p.frame[f];
+            if (!q.active) continue;
+            const int16_t *row = old + q.old_idx * kFlowFrame;
+            v0[f] = q.far_from_stream ? far_stream(q.far_pos + lane) : row[lane];
+            if (lane < kFlowFrame - 64) v1[f] = q.far_from_stream ? far_stream(q.far_pos + 64 + lane) : row[64 + lane];
+        }
+        if (lane < p.left_count) ff[(p.blk_pos0 + lane) & (kFlowFarFrameRing - 1)] = left;
+        for (int f = 0; f < 2; ++f) {
+            const FlowFrame &q = p.frame[f];
+            if (!q.active) continue;
+            ff[(q.frm_pos + lane) & (kFlowFarFrameRing - 1)] = v0[f];
+            if (lane < kFlowFrame - 64) ff[(q.frm_pos + 64 + lane) & (kFlowFarFrameRing - 1)] = v1[f];
         }
     }
     // 4. the blocks (the fence between the stores above and the blocks' fetches is TickFlowBlockIo::ready)
     const int nb = p.n_blocks;
     if (nb > 0) {
-        TickFlowBlockIo<kHasClean> bio{ff, nr, cr, orow, mask, p.blk_pos0, p.near_base + p.blk_pos0};
+        TickFlowBlockIo<kHasClean> bio{p.direct ? fr : ff, nr, cr, orow, p.direct ? mask : kFlowFarFrameRing - 1, mask,
+                                       p.direct ? p.blk_pos0 + p.far_delta : p.blk_pos0, p.near_base + p.blk_pos0, p.blk_pos0};
         TickFlowBlockIo<kHasClean>::E::run_stream_io(st, bio, s, nb);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
@@ -721,7 +750,7 @@ __device__ __forceinline__ void TestExchange(int va, int vb, uint64_t *fails) {
 }
 
 __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int exhaustive, const uint32_t *consts) {
-    FillLdsTables(consts);
+    FillLdsTables<256>(consts);
     using S = Gfx950Wave<false>;
     using F = Gfx950Wave<true>;
     const int lane = threadIdx.x & 63;
@@ -852,7 +881,7 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
 template <bool kFast>
 __global__ __launch_bounds__(256) void aecm_fft128_kernel(int16_t *data, int32_t *scales, int variant, int count,
                                                           const uint32_t *consts) {
-    FillLdsTables(consts);
+    FillLdsTables<256>(consts);
     using E = BlockEngine<Gfx950Wave<kFast>, false>;
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -79,7 +79,7 @@ bool SessionBatch::ResetFlowRows(int first, int count) {
     const size_t S = (size_t)engine_->num_streams();
     bool ok = true;
     for (int f = 0; f < kFlowFieldsUsed; ++f) {                       // field-major: one short run per field
-        const int value = (f == F_DELAY_CHANGE || f == F_CHECK_BUFF_SIZE || f == F_EC_STARTUP) ? 1 : 0;
+        const int value = FlowFieldStartsAtOne(f) ? 1 : 0;
         ok = ok && AECM_HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(flow_state_ + (size_t)f * S + first), value, (size_t)count, st));
     }
     return ok && AECM_HIP_OK(hipMemsetAsync(far_frames_ + (size_t)first * kFlowFarFrameRing, 0, (size_t)count * kFlowFarFrameRing * 2, st)) &&
