@@ -108,7 +108,8 @@ int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[
  *     WebRtcAecm_Process(inst_s, near[s], near_clean ? near_clean[s] : NULL, out[s], nrOfSamples, msInSndCardBuf);
  * (reference echo_control_mobile.h:87,135) with identical results and return code.  Audio is held in
  * per-stream rings in HBM; the reference's jitter buffer / start-up gating / delay compensation /
- * 80->64 re-blocking run once on the host in the index domain (csrc/aecm_sessions.h).
+ * 80->64 re-blocking run on the device, per session, as position arithmetic on per-session state
+ * (csrc/aecm_flow_plan.h), so sessions need not have anything in common but the tick.
  * far/near/near_clean/out: [S][stream_stride] int16, device pointers (Tick) or host pointers (TickHost);
  * near_clean may be NULL, but a batch must either always or never pass it (the clean ring is only kept
  * up to date by ticks that carry it). */
@@ -127,9 +128,9 @@ int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, co
 /* The same with one msInSndCardBuf per session (host array, S entries): session s runs
  *     WebRtcAecm_Process(inst_s, ..., msInSndCardBuf_host[s]).
  * codes_host (S entries, may be NULL) receives each session's return code; the function returns 0 or the
- * first non-zero code.  Sessions with identical msInSndCardBuf histories share one host-side session flow;
- * at most 1024 distinct histories per object (AECM_UNSUPPORTED_FUNCTION_ERROR beyond that; sessions whose
- * delay reports jitter independently belong in smaller objects).  Tick and TickPerSession may be mixed. */
+ * first non-zero code.  Any number of distinct msInSndCardBuf histories per object.  (With AECM_TICK_MODE=lean|
+ * fused|three in the environment the wrapper runs on the host, one per class of identical histories, at most
+ * 1024 classes: AECM_UNSUPPORTED_FUNCTION_ERROR beyond that.)  Tick and TickPerSession may be mixed. */
 int32_t WebRtcAecmSessions_TickPerSession(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
                                           const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
                                           size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host);
@@ -138,8 +139,7 @@ int32_t WebRtcAecmSessions_TickPerSessionHost(AecmSessions *s, const int16_t *fa
                                               size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host);
 /* The same with per-session call flags (host array, S entries): AECM_SESSION_NO_FAREND = this session gets NO
  * WebRtcAecm_BufferFarend call in this tick (far-end underrun; its WebRtcAecm_Process then replays the previous
- * far frame, reference echo_control_mobile.cc:369-380) -- its far row is ignored.  Sessions with different
- * flag histories live in different flow classes, exactly like different msInSndCardBuf histories. */
+ * far frame, reference echo_control_mobile.cc:369-380) -- its far row is ignored. */
 enum {
     AECM_SESSION_NO_FAREND = 1,
     /* 160-sample ticks only: this session makes TWO WebRtcAecm_BufferFarend + WebRtcAecm_Process call pairs of 80 samples
@@ -162,13 +162,13 @@ int32_t WebRtcAecmSessions_TickFlagsHost(AecmSessions *s, const int16_t *far_hos
  *                             fresh jitter buffer / start-up phase, default config (cng on, echoMode 3)
  *   set_config_session    <-> WebRtcAecm_set_config(inst_s, config)   (:156)
  *   InitEchoPath / GetEchoPath <-> WebRtcAecm_InitEchoPath / GetEchoPath (:172, :191), 130 bytes
- * A re-initialised session starts a flow class of its own (shared with the other sessions re-initialised
- * between the same two ticks); the 1024-class limit of TickPerSession applies. */
+ * Each call synchronises the object's stream (a control operation, not a per-tick one). */
 int32_t WebRtcAecmSessions_InitSession(AecmSessions *s, int32_t session);
 int32_t WebRtcAecmSessions_set_config_session(AecmSessions *s, int32_t session, AecmConfig config);
 int32_t WebRtcAecmSessions_InitEchoPath(AecmSessions *s, int32_t session, const void *echo_path, size_t size_bytes);
 int32_t WebRtcAecmSessions_GetEchoPath(AecmSessions *s, int32_t session, void *echo_path, size_t size_bytes);
-/* Number of distinct msInSndCardBuf histories currently tracked (diagnostics). */
+/* Diagnostics: 0 = the session wrapper runs on the device (default); with AECM_TICK_MODE=lean|fused|three the number
+ * of host-side classes of identical call histories currently tracked. */
 int32_t WebRtcAecmSessions_num_flow_classes(AecmSessions *s);
 
 /* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */

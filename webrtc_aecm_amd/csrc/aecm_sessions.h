@@ -1,16 +1,21 @@
-// Streaming batch of sessions: S independent WebRtcAecm_* sessions on a common call cadence (one
-// BufferFarend + one Process of n samples per tick) -- the shape of a media server mixing many calls on a
-// 10 ms clock.  msInSndCardBuf is per tick for everybody or per session.
+// Streaming batch of sessions: S independent WebRtcAecm_* sessions ticking together (one BufferFarend + one
+// Process of n samples per tick each, or two of 80 for a session flagged so) -- the shape of a media server mixing
+// many calls on a 10 ms clock.  msInSndCardBuf and the call flags are per tick for everybody or per session.
 //
-// The session wrapper and the frame adapter only move samples (aecm_session_flow.h), so sessions with
-// the same msInSndCardBuf history share ONE SessionFlow that runs on the host in the index domain (sample
-// tags instead of samples; a "flow class") and whose decisions are applied to all its members on the
-// device: the audio lives in per-stream rings in HBM, each tick is
+// Default form (flow_mode_): the session wrapper and the frame adapter run ON THE DEVICE, per session, as position
+// arithmetic on per-session state (aecm_flow_plan.h): a planning kernel with one lane per session, then a tick kernel
+// with one wavefront per session (aecm_kernels.h: TickFlowIo).  The host does nothing per session; sessions share
+// nothing but the tick.
+//
+// Earlier form, kept for A/B and selected by AECM_TICK_MODE=lean|fused|three: sessions with the same msInSndCardBuf /
+// flag history share ONE SessionFlow that runs on the host in the index domain (sample tags instead of samples; a
+// "flow class") and whose decisions are applied to all its members on the device: the audio lives in per-stream rings
+// in HBM, each tick is
 //   prepare (append far/near to the rings + gather the tick's blocks) -> WebRtcAecm_ProcessBlock x nb
 //   -> finish (block outputs into the output ring + assemble the tick's output)
-// as three launches for large batches, or fused into one launch (one wavefront per session does all of
-// it) for batches that do not fill the GPU.  With one class the per-sample source decisions travel as
-// kernel arguments, with several they sit in a device table indexed by the session's class.
+// as three launches, or fused into one launch (one wavefront per session does all of it; "lean" with the sources as
+// runs of ring positions, "fused" with one source code per sample).  With one class the source decisions travel as
+// kernel arguments, with several they sit in a device table indexed by the session's class (at most kMaxFlowClasses).
 #ifndef AECM_AMD_SESSIONS_H_
 #define AECM_AMD_SESSIONS_H_
 
