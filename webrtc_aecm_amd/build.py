@@ -57,6 +57,22 @@ def _write_build_info():
     BUILD_INFO.write_text(json.dumps(info))
 
 
+def _refresh_build_info():
+    """The libraries are newer than every source: if the sources are exactly those of HEAD, that is the commit they were
+    built from, whatever HEAD was when the compiler last ran (commits that do not touch the sources, or a commit made
+    after the build)."""
+    try:
+        root = PKG.parent
+        if not (root / ".git").exists():
+            return
+        dirty = subprocess.run(["git", "-C", str(root), "status", "--porcelain", "--", "webrtc_aecm_amd", "include"],
+                               capture_output=True, text=True).stdout.strip()
+        if not dirty:
+            _write_build_info()
+    except Exception:
+        pass
+
+
 def build_info():
     import json
     try:
@@ -72,6 +88,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     Safe to call from several processes at once (one rank per GPU under torch.distributed.run): the
     build is serialised by a file lock and the libraries are moved into place atomically."""
     if not force and not is_stale():
+        _refresh_build_info()
         return LIB
     import fcntl
     LIB_DIR.mkdir(parents=True, exist_ok=True)
