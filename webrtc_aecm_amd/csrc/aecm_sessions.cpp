@@ -10,6 +10,8 @@
 
 namespace aecm {
 
+static_assert(kFlowFarRing == 8192, "the far ring of SessionBatch (kRing) is the one aecm_flow_plan.h ages replay frames against");
+
 #define AECM_HIP_OK(expr) ((expr) == hipSuccess)
 
 SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
@@ -36,10 +38,11 @@ SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
              AECM_HIP_OK(hipMalloc((void **)&b->flow_plans_, S * kFlowPlanWords * sizeof(int32_t))) &&
              AECM_HIP_OK(hipMalloc((void **)&b->far_frames_, S * kFlowFarFrameRing * 2)) &&
              AECM_HIP_OK(hipMalloc((void **)&b->far_old_, S * 2 * kFlowFrame * 2)) &&
-             AECM_HIP_OK(hipMalloc((void **)&b->ms_dev_, S * sizeof(int16_t))) &&
-             AECM_HIP_OK(hipMalloc((void **)&b->flags_dev_, S)) &&
-             AECM_HIP_OK(hipHostMalloc((void **)&b->ms_host_, S * sizeof(int16_t), hipHostMallocDefault)) &&
-             AECM_HIP_OK(hipHostMalloc((void **)&b->flags_host_, S, hipHostMallocDefault));
+             // per-session msInSndCardBuf / flags of a tick: pinned host arrays the planning kernel reads in place
+             AECM_HIP_OK(hipHostMalloc((void **)&b->ms_host_, S * sizeof(int16_t), hipHostMallocMapped)) &&
+             AECM_HIP_OK(hipHostMalloc((void **)&b->flags_host_, S, hipHostMallocMapped)) &&
+             AECM_HIP_OK(hipHostGetDevicePointer((void **)&b->ms_dev_, b->ms_host_, 0)) &&
+             AECM_HIP_OK(hipHostGetDevicePointer((void **)&b->flags_dev_, b->flags_host_, 0));
     if (!ok) {
         delete b;
         return nullptr;
@@ -66,8 +69,6 @@ SessionBatch::~SessionBatch() {
     (void)hipFree(flow_plans_);
     (void)hipFree(far_frames_);
     (void)hipFree(far_old_);
-    (void)hipFree(ms_dev_);
-    (void)hipFree(flags_dev_);
     if (ms_host_) (void)hipHostFree(ms_host_);
     if (flags_host_) (void)hipHostFree(flags_host_);
 }
@@ -558,8 +559,7 @@ int32_t SessionBatch::TickFlow(const int16_t *far, const int16_t *near, const in
         } else if (codes) {
             memset(codes, 0, (size_t)S * sizeof(int32_t));
         }
-        memcpy(ms_host_, ms_per_session, (size_t)S * sizeof(int16_t));      // pinned; the previous tick ended with a synchronisation
-        if (!AECM_HIP_OK(hipMemcpyAsync(ms_dev_, ms_host_, (size_t)S * sizeof(int16_t), hipMemcpyHostToDevice, st))) return fail();
+        memcpy(ms_host_, ms_per_session, (size_t)S * sizeof(int16_t));      // pinned + mapped; the previous tick ended with a synchronisation
     } else {
         first_rc = code_of(ms);
         if (codes)
@@ -567,7 +567,6 @@ int32_t SessionBatch::TickFlow(const int16_t *far, const int16_t *near, const in
     }
     if (flags_per_session) {
         memcpy(flags_host_, flags_per_session, (size_t)S);
-        if (!AECM_HIP_OK(hipMemcpyAsync(flags_dev_, flags_host_, (size_t)S, hipMemcpyHostToDevice, st))) return fail();
     }
     const int16_t *dfar = far, *dnear = near, *dclean = clean;
     int16_t *dout = out;

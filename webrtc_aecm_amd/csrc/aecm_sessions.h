@@ -116,8 +116,8 @@ private:
     int32_t *flow_plans_ = nullptr;            // [S][kFlowPlanWords]: this tick's plan of every session
     int16_t *far_frames_ = nullptr;            // [S][kFlowFarFrameRing]
     int16_t *far_old_ = nullptr;               // [S][2 * 80]
-    int16_t *ms_dev_ = nullptr, *ms_host_ = nullptr;          // [S] per-session msInSndCardBuf of the tick (host copy pinned)
-    uint8_t *flags_dev_ = nullptr, *flags_host_ = nullptr;    // [S] per-session flags of the tick
+    int16_t *ms_host_ = nullptr, *ms_dev_ = nullptr;          // [S] per-session msInSndCardBuf of the tick: pinned host memory and
+    uint8_t *flags_host_ = nullptr, *flags_dev_ = nullptr;    // [S] per-session flags          its address on the device (read in place)
     int device_ = 0;
 };
 
