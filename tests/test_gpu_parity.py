@@ -831,6 +831,44 @@ def test_session_churn_slots_recycled_mid_run():
 
 
 @_needs_ref
+@pytest.mark.parametrize("fs", [16000, 8000])
+def test_replay_frame_outlives_its_place_in_the_far_ring(fs):
+    """farendOld[1] (the frame an underrun of the second 80-sample frame of a call replays) goes unused while a session
+    makes two 80-sample calls per tick (those only ever use slot 0); on the device that frame is a position in the far
+    ring, which the ring's write position laps after 8 192 accepted samples -- it has to be moved to its replay row in
+    time.  Then a run of underruns replays both slots.  Against reference sessions, tick by tick.  (The host-class tick
+    forms cannot express this call pattern: their sample tags must stay inside the far ring, and they refuse the tick with
+    AECM_UNSPECIFIED_ERROR instead of replaying the wrong samples.)"""
+    if aecm.AecmSessions(2, fs).num_flow_classes() != 0:
+        pytest.skip("needs the device-resident session machinery (AECM_TICK_MODE=flow, the default)")
+    frame, S, n_ticks = 160, 3, 420
+    pairs = [synth_pair(5150 + k, n_ticks * frame // 64 + 1, fs, "mixed") for k in range(S)]
+    far = np.stack([p[0][:n_ticks * frame] for p in pairs])
+    near = np.stack([p[1][:n_ticks * frame] for p in pairs])
+    refs = [pyoracle.RefSession(fs, 1, 3) for _ in range(S)]
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    for i in range(n_ticks):
+        sl = slice(i * frame, (i + 1) * frame)
+        ph = i % 200
+        fl = np.zeros(S, dtype=np.uint8)
+        if 60 <= ph < 150:
+            fl[:2] |= aecm.ffi.SESSION_SPLIT_CALLS                       # session 2 keeps making one 160-sample call
+        if 138 <= ph < 160:
+            fl |= aecm.ffi.SESSION_NO_FAREND
+        ms = np.array([40, 38 + ph % 5, 40], dtype=np.int16)
+        rc, out, codes = sb.tick_host_per_session(far[:, sl], near[:, sl], ms, flags=fl)
+        assert rc == 0
+        for k in range(S):
+            halves = ((0, 80), (80, 160)) if fl[k] & aecm.ffi.SESSION_SPLIT_CALLS else ((0, 160),)
+            for a, b in halves:
+                if not fl[k] & aecm.ffi.SESSION_NO_FAREND:
+                    assert refs[k].buffer_farend(far[k, sl][a:b]) == 0
+                rc1, o1 = refs[k].process(near[k, sl][a:b], None, int(ms[k]))
+                assert rc1 == 0 and np.array_equal(out[k, a:b], o1), (fs, i, k, a)
+    sb.close()
+
+
+@_needs_ref
 def test_sixteen_thousand_sessions_each_with_its_own_history():
     """The serving shape at scale: 16 384 live sessions, EVERY one with its own msInSndCardBuf walk, its own far-end
     underruns, its own call shape (one 160-sample call or two of 80) and its own age (slots re-initialised at random
