@@ -262,14 +262,20 @@ def test_device_session_machinery_equals_the_generic_wrapper_on_sample_tags(fs):
     """aecm_flow_plan.h (the wrapper + frame adapter as position arithmetic, what aecm_tick_flow_kernel runs per session)
     against SessionFlow<T> on sample tags: every block's 64 far / near inputs and every output sample must have the
     same provenance, tick by tick -- constant, jittering, stepping and out-of-range msInSndCardBuf, far-end underruns,
-    a saturated jitter buffer (16 kHz in 80-sample calls), mixed 80 / 160 / 2 x 80 call shapes, and position counters
-    that wrap around 2^32 and 2^31 during the run."""
+    a saturated jitter buffer (16 kHz in 80-sample calls), mixed 80 / 160 / 2 x 80 call shapes, a replay frame that
+    outlives its place in the far ring, and position counters that wrap around 2^32 and 2^31 during the run."""
     assert simlib.lib().sim_flow_tolerance_check() == 0
-    saw_blocks = saw_drops = 0
-    for scenario in range(9):
+    saw_blocks = saw_drops = saw_direct = saw_framed = saw_spills = 0
+    for scenario in range(11):
         for seed, start in ((1, 0), (2, 0xfffff000), (3, 0x7ffff800), (4, 987654321)):
             tick, detail = simlib.flow_fuzz(seed + 10 * scenario, fs, 6000, scenario, start)
             assert tick == -1, (fs, scenario, seed, tick, detail)
             saw_blocks += detail[1]
             saw_drops += detail[3]
-    assert saw_blocks > 100000 and (fs == 8000 or saw_drops > 1000)
+            saw_direct += detail[4]
+            saw_framed += detail[2] - detail[4]
+            saw_spills += detail[5]
+    # both far-end paths of the tick kernel (fetch from the far ring / through the framed-far ring), a saturated jitter
+    # buffer and replay frames that had to move to their rows were all exercised
+    assert saw_blocks > 100000 and saw_direct > 50000 and saw_framed > 50000 and saw_spills > 50
+    assert fs == 8000 or saw_drops > 1000

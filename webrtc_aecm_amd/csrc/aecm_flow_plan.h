@@ -305,6 +305,7 @@ AECM_FLOW_HD void FlowTick(FlowRegs &s, int fs, int n, int ms, int flags, uint32
         if ((int32_t)((uint32_t)s.v[F_RUN_POS] - p.blk_pos0) <= 0) {
             p.direct = 1;
             p.far_delta = (uint32_t)s.v[F_RUN_DELTA];
+            s.v[F_RUN_POS] = (int32_t)p.blk_pos0;           // any position of the run will do: keep it near (the counters wrap)
             s.v[F_FF_VALID] = 0;
         } else {
             if (!s.v[F_FF_VALID]) {                         // the ticks before were direct: their run covers what is pending
