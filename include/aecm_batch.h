@@ -128,9 +128,8 @@ int32_t WebRtcAecmSessions_TickHost(AecmSessions *s, const int16_t *far_host, co
 /* The same with one msInSndCardBuf per session (host array, S entries): session s runs
  *     WebRtcAecm_Process(inst_s, ..., msInSndCardBuf_host[s]).
  * codes_host (S entries, may be NULL) receives each session's return code; the function returns 0 or the
- * first non-zero code.  Any number of distinct msInSndCardBuf histories per object.  (With AECM_TICK_MODE=lean|
- * fused|three in the environment the wrapper runs on the host, one per class of identical histories, at most
- * 1024 classes: AECM_UNSUPPORTED_FUNCTION_ERROR beyond that.)  Tick and TickPerSession may be mixed. */
+ * first non-zero code.  Any number of distinct msInSndCardBuf histories per object; Tick and TickPerSession may
+ * be mixed. */
 int32_t WebRtcAecmSessions_TickPerSession(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev,
                                           const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
                                           size_t nrOfSamples, const int16_t *msInSndCardBuf_host, int32_t *codes_host);
@@ -167,9 +166,6 @@ int32_t WebRtcAecmSessions_InitSession(AecmSessions *s, int32_t session);
 int32_t WebRtcAecmSessions_set_config_session(AecmSessions *s, int32_t session, AecmConfig config);
 int32_t WebRtcAecmSessions_InitEchoPath(AecmSessions *s, int32_t session, const void *echo_path, size_t size_bytes);
 int32_t WebRtcAecmSessions_GetEchoPath(AecmSessions *s, int32_t session, void *echo_path, size_t size_bytes);
-/* Diagnostics: 0 = the session wrapper runs on the device (default); with AECM_TICK_MODE=lean|fused|three the number
- * of host-side classes of identical call histories currently tracked. */
-int32_t WebRtcAecmSessions_num_flow_classes(AecmSessions *s);
 
 /* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */
 int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);

@@ -447,22 +447,19 @@ def test_streaming_ticks_with_per_session_sound_card_delay():
                 if i % 97 != 96:
                     assert codes[k] == rc1, (fs, i, k)
                 assert np.array_equal(out[k], o1), (fs, frame, i, k)
-        assert sb.num_flow_classes() == 0 or 6 <= sb.num_flow_classes() <= aecm.AecmSessions.MAX_FLOW_CLASSES   # 0: machinery on the device
         for s in singles:
             s.close()
         sb.close()
 
 
-def test_streaming_ticks_more_delay_histories_than_any_class_table():
-    """Every session with its own msInSndCardBuf history.  With the session machinery on the device (the default) that is
-    just a tick; the host-side flow-class forms (AECM_TICK_MODE=lean|fused|three) refuse more histories than they have
-    classes with AECM_UNSUPPORTED_FUNCTION_ERROR, consume nothing, and keep working."""
-    S, frame, fs = aecm.AecmSessions.MAX_FLOW_CLASSES + 6, 160, 16000
+def test_streaming_ticks_every_session_its_own_delay_in_one_tick():
+    """Every session of a tick with its own msInSndCardBuf (the session wrapper runs per session on the device, so
+    there is nothing to run out of), some of them out of range."""
+    S, frame, fs = 1030, 160, 16000
     far, near = synth_pair(33, 40, fs, "mixed")
     far = np.tile(far[:10 * frame], (S, 1))
     near = np.tile(near[:10 * frame], (S, 1))
     sb = aecm.AecmSessions(S, fs, 1, 1)
-    on_device = sb.num_flow_classes() == 0
     ones = {k: aecm.Aecm() for k in (0, 7, S - 1)}
     for one in ones.values():
         assert one.init(fs) == 0 and one.set_config(1, 1) == 0
@@ -471,14 +468,12 @@ def test_streaming_ticks_more_delay_histories_than_any_class_table():
         if i == 4:
             ms = np.arange(S, dtype=np.int16)                                                               # S distinct values
             rc, out, codes = sb.tick_host_per_session(far[:, sl], near[:, sl], ms)
-            if on_device:
-                assert rc == aecm.ffi.AECM_BAD_PARAMETER_WARNING                                            # the sessions beyond 500 ms
-                for k, one in ones.items():
-                    assert one.buffer_farend(far[k, sl]) == 0
-                    rc1, o1 = one.process(near[k, sl], None, int(ms[k]))
-                    assert codes[k] == rc1 and np.array_equal(out[k], o1), k
-                continue
-            assert rc == aecm.ffi.AECM_UNSUPPORTED_FUNCTION_ERROR and sb.num_flow_classes() == 1
+            assert rc == aecm.ffi.AECM_BAD_PARAMETER_WARNING                                                # the sessions beyond 500 ms
+            for k, one in ones.items():
+                assert one.buffer_farend(far[k, sl]) == 0
+                rc1, o1 = one.process(near[k, sl], None, int(ms[k]))
+                assert codes[k] == rc1 and np.array_equal(out[k], o1), k
+            continue
         rc, out = sb.tick_host(far[:, sl], near[:, sl], 40)
         for k, one in ones.items():
             assert one.buffer_farend(far[k, sl]) == 0
@@ -487,20 +482,6 @@ def test_streaming_ticks_more_delay_histories_than_any_class_table():
     for one in ones.values():
         one.close()
     sb.close()
-
-
-def test_streaming_ticks_three_launch_path():
-    """The streaming tests above run the fused one-launch tick (small batches).  Large batches use the
-    three-launch form (prepare / blocks / finish); run the same tests with that path forced."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("AECM_TICK_FUSED") is not None:
-        pytest.skip("already running with a forced tick path")
-    env = dict(os.environ, AECM_TICK_FUSED="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", "streaming_"],
-                       env=env, capture_output=True, text=True)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def _write_wav(path, rate, samples):
@@ -732,27 +713,9 @@ def test_single_session_abi_vs_reference_jitter_underruns_all_call_sizes():
 
 
 @_needs_ref
-@pytest.mark.parametrize("mode", ["flow", "lean", "fused", "three"])
-def test_streaming_ticks_vs_reference_sessions(mode):
+def test_streaming_ticks_vs_reference_sessions():
     """WebRtcAecmSessions_Tick / TickPerSession / TickFlags against one reference session per stream (not against
-    our own single-session path): uniform jittering delay, then per-session delays with underruns -- in each of the
-    forms a tick can take (session machinery on the device -- the default --, or on the host in flow classes with a lean
-    one-launch, a coded one-launch or a three-launch device side)."""
-    import os
-    import subprocess
-    import sys
-    forced = os.environ.get("AECM_TICK_MODE")               # the tick form is chosen once per process
-    if forced is not None and forced != mode:
-        pytest.skip("this process is pinned to another tick form")
-    if forced is None and os.environ.get("AECM_TICK_FUSED") is not None:
-        pytest.skip("this process is pinned to a tick form through AECM_TICK_FUSED")
-    if forced is None:
-        env = {k: v for k, v in os.environ.items() if k != "AECM_TICK_FUSED"}
-        env["AECM_TICK_MODE"] = mode
-        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k",
-                            f"test_streaming_ticks_vs_reference_sessions and {mode}"], env=env, capture_output=True, text=True)
-        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-        return
+    our own single-session path): uniform jittering delay, then per-session delays with underruns."""
     for fs, frame, with_clean in ((16000, 160, 0), (8000, 80, 1), (8000, 160, 0)):
         S = 6
         pairs = [synth_pair(640 + k, 4 * fs // 64, fs, "mixed") for k in range(S)]
@@ -826,7 +789,6 @@ def test_session_churn_slots_recycled_mid_run():
         rc3r, p3r = refs[3].get_echo_path()
         assert rc3 == rc3r == 0 and np.array_equal(p3, p3r)
         assert sb.init_session(S) == aecm.ffi.AECM_BAD_PARAMETER_ERROR and sb.set_config_session(0, 1, 7) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
-        assert sb.num_flow_classes() <= S
         sb.close()
 
 
@@ -836,11 +798,8 @@ def test_replay_frame_outlives_its_place_in_the_far_ring(fs):
     """farendOld[1] (the frame an underrun of the second 80-sample frame of a call replays) goes unused while a session
     makes two 80-sample calls per tick (those only ever use slot 0); on the device that frame is a position in the far
     ring, which the ring's write position laps after 8 192 accepted samples -- it has to be moved to its replay row in
-    time.  Then a run of underruns replays both slots.  Against reference sessions, tick by tick.  (The host-class tick
-    forms cannot express this call pattern: their sample tags must stay inside the far ring, and they refuse the tick with
-    AECM_UNSPECIFIED_ERROR instead of replaying the wrong samples.)"""
-    if aecm.AecmSessions(2, fs).num_flow_classes() != 0:
-        pytest.skip("needs the device-resident session machinery (AECM_TICK_MODE=flow, the default)")
+    time.  Then a run of underruns replays both slots.  Against reference sessions, tick by tick.  (The host-planned tick
+    forms of early round 2 could not express this call pattern: their sample tags had to stay inside the far ring.)"""
     frame, S, n_ticks = 160, 3, 420
     pairs = [synth_pair(5150 + k, n_ticks * frame // 64 + 1, fs, "mixed") for k in range(S)]
     far = np.stack([p[0][:n_ticks * frame] for p in pairs])
@@ -874,8 +833,6 @@ def test_sixteen_thousand_sessions_each_with_its_own_history():
     underruns, its own call shape (one 160-sample call or two of 80) and its own age (slots re-initialised at random
     ticks) -- more distinct histories than any host-side bookkeeping could follow.  A sample of sessions is compared,
     tick by tick, with reference sessions that received exactly the same calls."""
-    if aecm.AecmSessions(2, 16000).num_flow_classes() != 0:
-        pytest.skip("needs the device-resident session machinery (AECM_TICK_MODE=flow, the default)")
     fs, frame, S, n_ticks = 16000, 160, 16384, 150
     rs = np.random.RandomState(2024)
     base_far, base_near = synth_pair(4242, (n_ticks * frame + 4096) // 64 + 1, fs, "mixed")

@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--fs", type=int, default=16000)
     ap.add_argument("--ticks", type=int, default=300)
     ap.add_argument("--classes", type=int, default=1,
-                    help="distinct msInSndCardBuf values among the sessions (> 1: WebRtcAecmSessions_TickPerSession)")
+                    help="distinct msInSndCardBuf values among the sessions (> 1: WebRtcAecmSessions_TickPerSession, one value per session)")
     args = ap.parse_args()
     import torch
 
@@ -50,7 +50,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.ticks
     blocks_per_tick = n / 64.0
-    print(json.dumps({"streams": S, "fs": fs, "flow_classes": sess.num_flow_classes(), "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
+    print(json.dumps({"streams": S, "fs": fs, "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
                       "realtime_streams_per_gpu": int(S * 0.010 / dt)}))
 
 

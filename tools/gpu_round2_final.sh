@@ -13,8 +13,6 @@ done
 python tools/bench_host_io.py 2>&1 | tail -1
 python tools/bench_single_session.py | tail -1
 for c in 1 16 256; do python tools/bench_sessions.py --streams 65536 --ticks 300 --classes $c | tail -1; done
-for c in 16 256; do AECM_TICK_MODE=lean python tools/bench_sessions.py --streams 65536 --ticks 300 --classes $c | tail -1; done
 for s in 1024 8192; do python tools/bench_sessions.py --streams $s --ticks 300 | tail -1; done
-for m in lean three fused; do AECM_TICK_MODE=$m python tools/bench_sessions.py --streams 65536 --ticks 300 | tail -1; done
 } > gpurun_out/r2f_sweep.log 2>&1
 tail -3 gpurun_out/r2f_pytest.log; tail -1 gpurun_out/r2f_bench.log | cut -c1-300; cat gpurun_out/r2f_sweep.log

@@ -338,8 +338,6 @@ int32_t WebRtcAecmSessions_TickFlagsHost(AecmSessions *s, const int16_t *far_hos
                           msInSndCardBuf_host, flags_host, codes_host, true);
 }
 
-int32_t WebRtcAecmSessions_num_flow_classes(AecmSessions *s) { return s ? s->batch->num_flow_classes() : -1; }
-
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]) {
     if (!failures) return AECM_NULL_POINTER_ERROR;
     if (hipSetDevice(device_id) != hipSuccess) return AECM_UNSPECIFIED_ERROR;

@@ -44,62 +44,8 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
                                 const int32_t *map_dev, int64_t n, int16_t *out, int64_t out_stride, int n_streams,
                                 hipStream_t stream);
 
-// Streaming sessions (aecm_sessions.cpp): per-stream sample rings of `ring_len` (power of two) elements.
-// A tick is three launches: prepare -> LaunchProcessBlocks -> finish.  Where each sample comes from is
-// decided on the host (SessionFlow in the index domain) and travels as kernel arguments, one int32
-// source code per sample: -1 = zero, else (kind << 28) | index.
-constexpr int kTickMaxBlockSamples = 256;   // <= 4 blocks per tick
-constexpr int kTickMaxSamples = 160;
-constexpr int kTickFrame = 80;              // FRAME_LEN: output frames are assembled 80 samples at a time
-enum TickSource : int32_t {
-    kTickFromInput = 0,      // gather: this tick's far/near input row          assemble: this tick's block outputs
-    kTickFromRing = 1,       // gather: the far/near ring                       assemble: the output ring
-    kTickNearInput = 2,      //                                                 assemble: this tick's near input (pass-through)
-    kTickNearRing = 3        //                                                 assemble: the near ring (pass-through)
-};
-struct TickGatherCodes { int32_t far[kTickMaxBlockSamples], near[kTickMaxBlockSamples]; };
-struct TickAssembleCodes { int32_t out[kTickMaxSamples]; };
-// prepare: append the tick's first n_far far and all n near(/clean) samples to the rings (at far_pos /
-// near_pos) and gather the tick's nb blocks: bfar/bnear(/bclean)[s][j] for j in [0, nb*64).  The far ring
-// only takes what the session's jitter buffer accepted (a saturated one drops the rest), so a far tag is
-// the count of ACCEPTED samples and never outlives the ring.  clean_in == nullptr: no clean near-end
-// (clean_ring / bclean unused); the clean samples follow the near codes and positions.
-hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride, int n,
-                             int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
-                             int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int n_block_samples,
-                             const TickGatherCodes &codes, int n_streams, hipStream_t stream);
-// finish: append the nb*64 block outputs to the output ring (at out_pos) and assemble the tick's n
-// output samples.
-hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *out_ring, const int16_t *near_ring,
-                            int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride, int16_t *out,
-                            int n, const TickAssembleCodes &codes, int n_streams, hipStream_t stream);
-
-// Sessions whose msInSndCardBuf histories differ live in different flow classes (aecm_sessions.h): the
-// per-sample source codes then come from a device table indexed by the stream's class, and the block
-// buffers use a fixed row stride of kTickMaxBlockSamples.
-struct TickClassEntry {
-    int32_t n_block_samples;     // blocks of this tick * 64
-    int32_t n_far;               // how many of the tick's far samples the jitter buffer accepted (the first n_far)
-    int64_t far_pos;             // where they go in the far ring
-    int64_t out_pos;             // where this class's block outputs go in the output ring
-    TickGatherCodes gather;
-    TickAssembleCodes assemble;
-};
-hipError_t LaunchTickPrepareClasses(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
-                                    int n, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
-                                    int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean,
-                                    const int32_t *class_of_stream, const TickClassEntry *table, int32_t *blocks_per_stream,
-                                    int n_streams, hipStream_t stream);
-hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
-                                   const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
-                                   const int32_t *class_of_stream, const TickClassEntry *table, int n_streams,
-                                   hipStream_t stream);
-
-// One tick of S streaming sessions as ONE launch, one wavefront per session: append the tick's far / near
-// (/ clean) samples to the rings, run the session's blocks with their inputs fetched through the source
-// codes (no intermediate block buffers), write the block outputs to the output ring and assemble the
-// tick's n output samples (this tick's block outputs are kept in LDS for that).
-//   class_of_stream / table == nullptr: every session uses `single`; else session s uses table[class_of_stream[s]].
+// Streaming sessions (aecm_sessions.cpp): per-session sample rings of `ring_len` (power of two) int16 in HBM, indexed by
+// wrapping stream positions.
 struct TickIo {
     const int16_t *far_in, *near_in, *clean_in;   // [S][io_stride]; clean_in may be null
     int16_t *out;                                 // [S][io_stride]
@@ -108,37 +54,6 @@ struct TickIo {
     int16_t *far_ring, *near_ring, *clean_ring, *out_ring;   // [S][ring_len]
     int64_t ring_len, near_pos;
 };
-hipError_t LaunchTick(const StatePtrs &st, const TickIo &io, int n_streams, int variant, const int32_t *class_of_stream,
-                      const TickClassEntry *table, const TickClassEntry *single, hipStream_t stream);
-
-// The lean form of the one-launch tick.  The session machinery moves samples in long runs (a jitter-buffer frame, a
-// re-read of old content, a stretch of never-written zeros), so instead of one source code per sample a block's 64
-// inputs / an output frame's 80 samples are described by at most kTickMaxRuns runs of consecutive ring positions.
-// The wave appends the tick's samples to its rings FIRST, then reads everything back from the rings (one uniform base
-// + a per-lane position; workgroup-scope fences order the wave's own stores and loads), so the per-lane work of a
-// fetch is "add, mask" for the usual single run and the whole description sits in scalar registers.  A tick whose
-// description does not fit (more runs) falls back to the coded forms above.
-constexpr int kTickMaxRuns = 4;
-constexpr int32_t kTickRunZero = INT32_MIN;   // off value of a run of zeros (never-written buffer memory)
-struct TickRuns {
-    int32_t n;                       // runs in use (>= 1)
-    int32_t end[kTickMaxRuns];       // exclusive end index, within the block / frame, of run k
-    int32_t off[kTickMaxRuns];       // sample i of run k sits at ring position (i + off[k]) & (ring_len - 1); kTickRunZero: zeros
-    int32_t kind[kTickMaxRuns];      // output frames only: kTickFromRing = output ring, kTickNearRing = near (clean) ring
-};
-struct TickLeanEntry {
-    int32_t n_blocks;                // blocks of this tick (<= 4)
-    int32_t n_far;                   // how many of the tick's far samples the jitter buffer accepted (the first n_far)
-    int32_t n_frames;                // output frames of 80 samples (1 or 2)
-    int32_t far2_src, far2_cnt;      // a second accepted piece of the far row (two 80-sample calls, the first one cut short
-                                     // by a full jitter buffer): input samples [far2_src, far2_src + far2_cnt) follow the first n_far
-    int32_t reserved;
-    int64_t far_pos, out_pos;        // where the accepted far samples / this tick's block outputs go in their rings
-    TickRuns far[4], near[4];        // per block
-    TickRuns out[2];                 // per output frame
-};
-hipError_t LaunchTickLean(const StatePtrs &st, const TickIo &io, int n_streams, const int32_t *class_of_stream,
-                          const TickLeanEntry *table, const TickLeanEntry *single, hipStream_t stream);
 
 // The device-resident session machinery: the wrapper itself (jitter buffer, start-up gating, delay compensation,
 // 80 -> 64 re-blocking, output stuffing) as position arithmetic on per-session state in HBM (aecm_flow_plan.h), so every

@@ -200,389 +200,6 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
     return hipGetLastError();
 }
 
-// ---- streaming-session sample rings --------------------------------------------------------------------
-
-// The tick kernels move 16-bit samples selected by per-sample source codes.  Runs are long in practice
-// (a block is a contiguous piece of a ring or of the tick's input), so a lane handles a group of four
-// samples: one 8-byte access when the four codes are consecutive, 4-aligned and the rows are 8-byte
-// aligned, four 2-byte accesses otherwise.  Fetch(kind, idx) returns the address of sample idx of a source.
-template <class Fetch>
-__device__ __forceinline__ void CopyGroup4(const int32_t *codes4, int16_t *dst4, bool rows_aligned, Fetch fetch) {
-    const int4 c = *reinterpret_cast<const int4 *>(codes4);
-    if (rows_aligned && c.x >= 0 && (c.x & 3) == 0 && c.y == c.x + 1 && c.z == c.x + 2 && c.w == c.x + 3) {
-        *reinterpret_cast<int2 *>(dst4) = *reinterpret_cast<const int2 *>(fetch(c.x >> 28, c.x & 0x0fffffff));
-        return;
-    }
-    const int cc[4] = {c.x, c.y, c.z, c.w};
-    for (int k = 0; k < 4; ++k) dst4[k] = cc[k] < 0 ? (int16_t)0 : *fetch(cc[k] >> 28, cc[k] & 0x0fffffff);
-}
-// ring[(pos + j) & mask] = src[j] for j in [0, n), four samples per lane where alignment allows
-__device__ __forceinline__ void AppendRing(int16_t *ring, int64_t mask, int64_t pos, const int16_t *src, int n, bool rows_aligned) {
-    const int lane = threadIdx.x & 63;
-    if (rows_aligned && (pos & 3) == 0 && (n & 3) == 0) {
-        for (int g = lane; g < n / 4; g += 64)
-            *reinterpret_cast<int2 *>(ring + ((pos + 4 * g) & mask)) = *reinterpret_cast<const int2 *>(src + 4 * g);
-    } else {
-        for (int j = lane; j < n; j += 64) ring[(pos + j) & mask] = src[j];
-    }
-}
-
-// Body shared by the one-class (codes as kernel arguments) and many-class (codes in a device table) forms.
-__device__ __forceinline__ void TickPrepareStream(int64_t s, const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in,
-                                                  int64_t in_stride, int n, int n_far, int16_t *far_ring, int16_t *near_ring,
-                                                  int16_t *clean_ring, int64_t ring_len, int64_t far_pos, int64_t near_pos,
-                                                  int16_t *bfar, int16_t *bnear, int16_t *bclean, int nbs,
-                                                  const TickGatherCodes *codes, bool rows_aligned) {
-    const int16_t *fin = far_in + s * in_stride, *nin = near_in + s * in_stride;
-    const int16_t *cin = clean_in ? clean_in + s * in_stride : nullptr;
-    int16_t *fr = far_ring + s * ring_len, *nr = near_ring + s * ring_len;
-    int16_t *cr = clean_in ? clean_ring + s * ring_len : nullptr;
-    const int64_t mask = ring_len - 1;
-    // reads of ring entries never alias this tick's appends: in-tick samples come from the input rows
-    for (int g = threadIdx.x & 63; g < nbs / 4; g += 64) {
-        CopyGroup4(codes->far + 4 * g, bfar + 4 * g, rows_aligned, [&](int kind, int idx) { return (kind == kTickFromInput ? fin : fr) + idx; });
-        CopyGroup4(codes->near + 4 * g, bnear + 4 * g, rows_aligned, [&](int kind, int idx) { return (kind == kTickFromInput ? nin : nr) + idx; });
-        if (cin)
-            CopyGroup4(codes->near + 4 * g, bclean + 4 * g, rows_aligned, [&](int kind, int idx) { return (kind == kTickFromInput ? cin : cr) + idx; });
-    }
-    AppendRing(fr, mask, far_pos, fin, n_far, rows_aligned);
-    AppendRing(nr, mask, near_pos, nin, n, rows_aligned);
-    if (cin) AppendRing(cr, mask, near_pos, cin, n, rows_aligned);
-}
-
-__device__ __forceinline__ void TickFinishStream(int64_t s, const int16_t *bo, int nbs, int16_t *out_ring, const int16_t *pass_ring,
-                                                 int64_t ring_len, int64_t out_pos, const int16_t *pass_in, int64_t io_stride,
-                                                 int16_t *out, int n, const TickAssembleCodes *codes, bool rows_aligned) {
-    int16_t *ring = out_ring + s * ring_len;
-    const int16_t *pr = pass_ring + s * ring_len, *pi = pass_in + s * io_stride;
-    // in-tick block outputs are read from bo, so the ring reads never alias the appends below
-    for (int g = threadIdx.x & 63; g < n / 4; g += 64)
-        CopyGroup4(codes->out + 4 * g, out + s * io_stride + 4 * g, rows_aligned, [&](int kind, int idx) {
-            return (kind == kTickFromInput ? bo : kind == kTickFromRing ? (const int16_t *)ring : kind == kTickNearInput ? pi : pr) + idx;
-        });
-    AppendRing(ring, ring_len - 1, out_pos, bo, nbs, true);
-}
-
-__global__ void aecm_tick_prepare_kernel(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
-                                         int n, int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
-                                         int64_t far_pos, int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int nbs,
-                                         int n_streams, bool rows_aligned, TickGatherCodes codes) {
-    // one wavefront per stream (4 streams per workgroup)
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
-    if (s >= n_streams) return;
-    TickPrepareStream(s, far_in, near_in, clean_in, in_stride, n, n_far, far_ring, near_ring, clean_ring, ring_len, far_pos, near_pos,
-                      bfar + s * nbs, bnear + s * nbs, bclean + s * nbs, nbs, &codes, rows_aligned);
-}
-static bool RowsAligned(int64_t stride, std::initializer_list<const void *> ptrs) {
-    bool ok = (stride & 3) == 0;
-    for (const void *p : ptrs) ok = ok && (reinterpret_cast<uintptr_t>(p) & 7u) == 0;
-    return ok;
-}
-hipError_t LaunchTickPrepare(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride, int n,
-                             int n_far, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len, int64_t far_pos,
-                             int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean, int n_block_samples,
-                             const TickGatherCodes &codes, int n_streams, hipStream_t stream) {
-    if (n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_tick_prepare_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
-                       dim3(64 * kWavesPerWorkgroup), 0, stream, far_in, near_in, clean_in, in_stride, n, n_far, far_ring, near_ring,
-                       clean_ring, ring_len, far_pos, near_pos, bfar, bnear, bclean, n_block_samples, n_streams,
-                       RowsAligned(in_stride, {far_in, near_in, clean_in}), codes);
-    return hipGetLastError();
-}
-
-__global__ void aecm_tick_finish_kernel(const int16_t *bout, int nbs, int16_t *out_ring, const int16_t *near_ring,
-                                        int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride,
-                                        int16_t *out, int n, int n_streams, bool rows_aligned, TickAssembleCodes codes) {
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
-    if (s >= n_streams) return;
-    TickFinishStream(s, bout + s * nbs, nbs, out_ring, near_ring, ring_len, out_pos, near_in, io_stride, out, n, &codes, rows_aligned);
-}
-hipError_t LaunchTickFinish(const int16_t *bout, int n_block_samples, int16_t *out_ring, const int16_t *near_ring,
-                            int64_t ring_len, int64_t out_pos, const int16_t *near_in, int64_t io_stride, int16_t *out,
-                            int n, const TickAssembleCodes &codes, int n_streams, hipStream_t stream) {
-    if (n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_tick_finish_kernel, dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)),
-                       dim3(64 * kWavesPerWorkgroup), 0, stream, bout, n_block_samples, out_ring, near_ring, ring_len, out_pos,
-                       near_in, io_stride, out, n, n_streams, RowsAligned(io_stride, {near_in, out}), codes);
-    return hipGetLastError();
-}
-
-__global__ void aecm_tick_prepare_classes_kernel(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in,
-                                                 int64_t in_stride, int n, int16_t *far_ring, int16_t *near_ring,
-                                                 int16_t *clean_ring, int64_t ring_len, int64_t near_pos,
-                                                 int16_t *bfar, int16_t *bnear, int16_t *bclean, const int32_t *class_of_stream,
-                                                 const TickClassEntry *table, int32_t *blocks_per_stream, int n_streams,
-                                                 bool rows_aligned) {
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
-    if (s >= n_streams) return;
-    const TickClassEntry *e = table + class_of_stream[s];
-    const int64_t row = s * kTickMaxBlockSamples;
-    TickPrepareStream(s, far_in, near_in, clean_in, in_stride, n, e->n_far, far_ring, near_ring, clean_ring, ring_len, e->far_pos,
-                      near_pos, bfar + row, bnear + row, bclean + row, e->n_block_samples, &e->gather, rows_aligned);
-    if ((threadIdx.x & 63) == 0) blocks_per_stream[s] = e->n_block_samples / kBlock;
-}
-hipError_t LaunchTickPrepareClasses(const int16_t *far_in, const int16_t *near_in, const int16_t *clean_in, int64_t in_stride,
-                                    int n, int16_t *far_ring, int16_t *near_ring, int16_t *clean_ring, int64_t ring_len,
-                                    int64_t near_pos, int16_t *bfar, int16_t *bnear, int16_t *bclean,
-                                    const int32_t *class_of_stream, const TickClassEntry *table, int32_t *blocks_per_stream,
-                                    int n_streams, hipStream_t stream) {
-    if (n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_tick_prepare_classes_kernel,
-                       dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)), dim3(64 * kWavesPerWorkgroup), 0,
-                       stream, far_in, near_in, clean_in, in_stride, n, far_ring, near_ring, clean_ring, ring_len, near_pos,
-                       bfar, bnear, bclean, class_of_stream, table, blocks_per_stream, n_streams,
-                       RowsAligned(in_stride, {far_in, near_in, clean_in}));
-    return hipGetLastError();
-}
-
-__global__ void aecm_tick_finish_classes_kernel(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
-                                                const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
-                                                const int32_t *class_of_stream, const TickClassEntry *table, int n_streams,
-                                                bool rows_aligned) {
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + (threadIdx.x >> 6);
-    if (s >= n_streams) return;
-    const TickClassEntry *e = table + class_of_stream[s];
-    TickFinishStream(s, bout + s * kTickMaxBlockSamples, e->n_block_samples, out_ring, pass_ring, ring_len, e->out_pos, pass_in,
-                     io_stride, out, n, &e->assemble, rows_aligned);
-}
-hipError_t LaunchTickFinishClasses(const int16_t *bout, int16_t *out_ring, const int16_t *pass_ring, int64_t ring_len,
-                                   const int16_t *pass_in, int64_t io_stride, int16_t *out, int n,
-                                   const int32_t *class_of_stream, const TickClassEntry *table, int n_streams,
-                                   hipStream_t stream) {
-    if (n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aecm_tick_finish_classes_kernel,
-                       dim3((unsigned)((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup)), dim3(64 * kWavesPerWorkgroup), 0,
-                       stream, bout, out_ring, pass_ring, ring_len, pass_in, io_stride, out, n, class_of_stream, table, n_streams,
-                       RowsAligned(io_stride, {pass_in, out}));
-    return hipGetLastError();
-}
-
-// ---- fused tick -------------------------------------------------------------------------------------
-#if defined(AECM_CHECKED) && !defined(AECM_TICK_WAVES_PER_EU)
-#define AECM_TICK_WAVES_PER_EU 4
-#endif
-#ifndef AECM_TICK_WAVES_PER_EU
-#define AECM_TICK_WAVES_PER_EU 6      // the coded I/O needs a few more registers than the strided one: 7 waves would spill
-#endif
-template <bool kFast, bool kHasClean>
-struct TickCodedIo {
-    using E = BlockEngine<Gfx950Wave<kFast>, kHasClean>;
-    using Regs = typename E::Regs;
-    const TickClassEntry *e;
-    const int16_t *fin, *nin, *cin, *fr, *nr, *cr;    // this session's input rows and rings
-    int16_t *out_ring_row, *lds_out;
-    int64_t mask;
-    static __device__ __forceinline__ int fetch(const int32_t *codes, int j, const int16_t *in_row, const int16_t *ring_row) {
-        const int c = codes[j], idx = c & 0x0fffffff;
-        return c < 0 ? 0 : (int)((c >> 28) == kTickFromInput ? in_row[idx] : ring_row[idx]);
-    }
-    __device__ __forceinline__ int far(const Regs &r, int b) const { return fetch(e->gather.far, b * kBlock + r.lane, fin, fr); }
-    __device__ __forceinline__ int near(const Regs &r, int b) const { return fetch(e->gather.near, b * kBlock + r.lane, nin, nr); }
-    __device__ __forceinline__ int clean(const Regs &r, int b) const { return fetch(e->gather.near, b * kBlock + r.lane, cin, cr); }
-    __device__ __forceinline__ void out(const Regs &r, int b, int v) const {
-        const int j = b * kBlock + r.brev;
-        lds_out[j] = (int16_t)v;
-        out_ring_row[(e->out_pos + j) & mask] = (int16_t)v;
-    }
-    __device__ __forceinline__ void ready() const {}
-};
-
-template <bool kFast, bool kHasClean>
-__device__ __forceinline__ void TickSession(const StatePtrs &st, const TickIo &io, int64_t s, const TickClassEntry *e) {
-    using Io = TickCodedIo<kFast, kHasClean>;
-    const bool rows_aligned = (io.io_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(io.far_in) | reinterpret_cast<uintptr_t>(io.near_in) |
-                                                            reinterpret_cast<uintptr_t>(io.clean_in) | reinterpret_cast<uintptr_t>(io.out)) & 7u) == 0;
-    const int16_t *fin = io.far_in + s * io.io_stride, *nin = io.near_in + s * io.io_stride;
-    const int16_t *cin = kHasClean ? io.clean_in + s * io.io_stride : nullptr;
-    int16_t *fr = io.far_ring + s * io.ring_len, *nr = io.near_ring + s * io.ring_len;
-    int16_t *cr = kHasClean ? io.clean_ring + s * io.ring_len : nullptr;
-    int16_t *ring = io.out_ring + s * io.ring_len;
-    const int64_t mask = io.ring_len - 1;
-    int16_t *lds_out = reinterpret_cast<int16_t *>(&g_lds[1]) + (threadIdx.x >> 6) * kTickMaxBlockSamples;
-    // in-tick samples are always fetched from the input rows, so the appends never feed this tick's reads
-    AppendRing(fr, mask, e->far_pos, fin, e->n_far, rows_aligned);
-    AppendRing(nr, mask, io.near_pos, nin, io.n, rows_aligned);
-    if (kHasClean) AppendRing(cr, mask, io.near_pos, cin, io.n, rows_aligned);
-    const int nbs = e->n_block_samples;
-    if (nbs > 0) {
-        Io cio{e, fin, nin, cin, fr, nr, cr, ring, lds_out, mask};
-        Io::E::run_stream_io(st, cio, s, nbs / kBlock);
-    }
-    // the tick's output: this tick's block outputs from LDS, older ones from the ring, pass-through from
-    // the (clean) near-end (reference echo_control_mobile.cc:285-291)
-    const int16_t *pi = kHasClean ? cin : nin, *pr = kHasClean ? cr : nr;
-    for (int g = threadIdx.x & 63; g < io.n / 4; g += 64)
-        CopyGroup4(e->assemble.out + 4 * g, io.out + s * io.io_stride + 4 * g, rows_aligned, [&](int kind, int idx) {
-            return (kind == kTickFromInput ? (const int16_t *)lds_out : kind == kTickFromRing ? (const int16_t *)ring
-                    : kind == kTickNearInput ? pi : pr) + idx;
-        });
-}
-
-template <bool kFast, bool kHasClean>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_TICK_WAVES_PER_EU, 8)))
-void aecm_tick_kernel(StatePtrs st, TickIo io, int n_streams, TickClassEntry single) {
-    FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (s >= n_streams) return;
-    TickSession<kFast, kHasClean>(st, io, s, &single);
-}
-template <bool kFast, bool kHasClean>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_TICK_WAVES_PER_EU, 8)))
-void aecm_tick_classes_kernel(StatePtrs st, TickIo io, int n_streams, const int32_t *class_of_stream, const TickClassEntry *table) {
-    FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
-    const int64_t s = (int64_t)blockIdx.x * kWavesPerWorkgroup + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (s >= n_streams) return;
-    TickSession<kFast, kHasClean>(st, io, s, table + __builtin_amdgcn_readfirstlane(class_of_stream[s]));
-}
-
-hipError_t LaunchTick(const StatePtrs &st, const TickIo &io, int n_streams, int variant, const int32_t *class_of_stream,
-                      const TickClassEntry *table, const TickClassEntry *single, hipStream_t stream) {
-    if (n_streams <= 0) return hipSuccess;
-    const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup), block(64 * kWavesPerWorkgroup);
-    const size_t lds = sizeof(LdsTables) + kWavesPerWorkgroup * kTickMaxBlockSamples * sizeof(int16_t);
-    const bool fast = variant == kVariantFast, clean = io.clean_in != nullptr;
-#define AECM_LAUNCH_TICK(F, C)                                                                                          \
-    do {                                                                                                                \
-        if (table) hipLaunchKernelGGL((aecm_tick_classes_kernel<F, C>), grid, block, lds, stream, st, io, n_streams,   \
-                                      class_of_stream, table);                                                         \
-        else hipLaunchKernelGGL((aecm_tick_kernel<F, C>), grid, block, lds, stream, st, io, n_streams, *single);       \
-    } while (0)
-    if (fast && clean) AECM_LAUNCH_TICK(true, true);
-    else if (fast) AECM_LAUNCH_TICK(true, false);
-    else if (clean) AECM_LAUNCH_TICK(false, true);
-    else AECM_LAUNCH_TICK(false, false);
-#undef AECM_LAUNCH_TICK
-    return hipGetLastError();
-}
-
-// ---- lean fused tick (run-encoded sources) ------------------------------------------------------------
-// Ring position of sample i (lane-varying) of a run description (wave-uniform, in scalar registers).
-__device__ __forceinline__ int RunPosition(const TickRuns &t, int i, int mask, bool &zero, int *kind = nullptr) {
-    int off = t.off[0], k = t.kind[0];
-    const int n = __builtin_amdgcn_readfirstlane(t.n);
-    if (n > 1) {                                            // wave-uniform: the usual description is one run
-        for (int r = 1; r < kTickMaxRuns; ++r)
-            if (r < n && i >= t.end[r - 1]) { off = t.off[r]; k = t.kind[r]; }
-    }
-    zero = off == kTickRunZero;
-    if (kind) *kind = k;
-    return zero ? 0 : (i + off) & mask;
-}
-
-template <bool kHasClean>
-struct TickRunIo {
-    using E = BlockEngine<Gfx950Wave<true>, kHasClean>;
-    using Regs = typename E::Regs;
-    const TickLeanEntry *e;
-    const int16_t *fr, *nr, *cr;     // this session's far / near / clean rings (the tick's samples already appended)
-    int16_t *out_row;                // this session's output ring
-    int mask, out_pos;
-    static __device__ __forceinline__ int fetch(const TickRuns &t, int lane, const int16_t *ring, int mask) {
-        bool zero;
-        const int p = RunPosition(t, lane, mask, zero);
-        const int v = ring[p];
-        return zero ? 0 : v;
-    }
-    __device__ __forceinline__ int far(const Regs &r, int b) const { return fetch(e->far[b], r.lane, fr, mask); }
-    __device__ __forceinline__ int near(const Regs &r, int b) const { return fetch(e->near[b], r.lane, nr, mask); }
-    __device__ __forceinline__ int clean(const Regs &r, int b) const { return fetch(e->near[b], r.lane, cr, mask); }
-    __device__ __forceinline__ void out(const Regs &r, int b, int v) const {
-        out_row[(out_pos + b * kBlock + r.brev) & mask] = (int16_t)v;
-    }
-    __device__ __forceinline__ void ready() const {}
-};
-
-template <bool kHasClean>
-__device__ __forceinline__ void TickSessionLean(const StatePtrs &st, const TickIo &io, int64_t s, const TickLeanEntry *e) {
-    const int lane = threadIdx.x & 63;
-    const int mask = (int)io.ring_len - 1;
-    const int16_t *fin = io.far_in + s * io.io_stride, *nin = io.near_in + s * io.io_stride;
-    const int16_t *cin = kHasClean ? io.clean_in + s * io.io_stride : nullptr;
-    int16_t *fr = io.far_ring + s * io.ring_len, *nr = io.near_ring + s * io.ring_len;
-    int16_t *cr = kHasClean ? io.clean_ring + s * io.ring_len : nullptr;
-    int16_t *orow = io.out_ring + s * io.ring_len;
-    int16_t *out = io.out + s * io.io_stride;
-    // 1. the tick's samples into the rings
-    const int far_pos = (int)e->far_pos, near_pos = (int)io.near_pos, n_far = e->n_far, n = io.n;
-    const int far2_src = e->far2_src, far2_cnt = e->far2_cnt;
-    for (int j = lane; j < n; j += 64) {
-        if (j < n_far) fr[(far_pos + j) & mask] = fin[j];
-        else if (j >= far2_src && j < far2_src + far2_cnt) fr[(far_pos + n_far + (j - far2_src)) & mask] = fin[j];
-        nr[(near_pos + j) & mask] = nin[j];
-        if (kHasClean) cr[(near_pos + j) & mask] = cin[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // this wave's loads below must see this wave's stores
-    // 2. the session's blocks, inputs fetched from the rings through the run descriptions
-    const int nb = __builtin_amdgcn_readfirstlane(e->n_blocks);
-    if (nb > 0) {
-        TickRunIo<kHasClean> rio{e, fr, nr, cr, orow, mask, (int)e->out_pos};
-        TickRunIo<kHasClean>::E::run_stream_io(st, rio, s, nb);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    }
-    // 3. the tick's output frames: block outputs (this tick's or older ones) from the output ring, pass-through from the
-    //    (clean) near-end ring (reference echo_control_mobile.cc:285-291), zeros
-    const int16_t *pass = kHasClean ? cr : nr;
-    const int n_frames = __builtin_amdgcn_readfirstlane(e->n_frames);
-    for (int f = 0; f < n_frames; ++f)
-        for (int j = lane; j < kTickFrame; j += 64) {
-            bool zero;
-            int kind;
-            const int p = RunPosition(e->out[f], j, mask, zero, &kind);
-            const int v = kind == kTickNearRing ? pass[p] : orow[p];
-            out[f * kTickFrame + j] = (int16_t)(zero ? 0 : v);
-        }
-}
-
-// Sessions per workgroup and occupancy target of the lean tick.  A tick is only 2-3 blocks per session, so the 20 KB
-// table fill of the prologue and the launch's tail are a visible share of it: 8 sessions per workgroup halve the
-// fills, and the kernel's I/O state lives in scalar registers, so it fits 64 VGPRs = 8 waves per SIMD (4 such
-// workgroups per CU).  Measured, 65 536 sessions: 4 sessions / 7 waves 0.339 ms per tick, 8 / 7: 0.324, 4 / 8: 0.323,
-// 8 / 8: 0.306, 16 / 8: 0.312.
-#ifndef AECM_TICK_LEAN_WAVES
-#define AECM_TICK_LEAN_WAVES 8
-#endif
-constexpr int kTickLeanWaves = AECM_TICK_LEAN_WAVES;
-#ifndef AECM_TICK_LEAN_WAVES_PER_EU
-#if defined(AECM_CHECKED)
-#define AECM_TICK_LEAN_WAVES_PER_EU 4
-#else
-#define AECM_TICK_LEAN_WAVES_PER_EU 8
-#endif
-#endif
-template <bool kHasClean>
-__global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
-void aecm_tick_lean_kernel(StatePtrs st, TickIo io, int n_streams, TickLeanEntry single) {
-    FillLdsTables<64 * kTickLeanWaves>(st.consts);
-    const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (s >= n_streams) return;
-    TickSessionLean<kHasClean>(st, io, s, &single);
-}
-template <bool kHasClean>
-__global__ __launch_bounds__(64 * kTickLeanWaves) __attribute__((amdgpu_waves_per_eu(AECM_TICK_LEAN_WAVES_PER_EU, 8)))
-void aecm_tick_lean_classes_kernel(StatePtrs st, TickIo io, int n_streams, const int32_t *__restrict__ class_of_stream,
-                                   const TickLeanEntry *__restrict__ table) {
-    FillLdsTables<64 * kTickLeanWaves>(st.consts);
-    const int64_t s = (int64_t)blockIdx.x * kTickLeanWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (s >= n_streams) return;
-    TickSessionLean<kHasClean>(st, io, s, table + __builtin_amdgcn_readfirstlane(class_of_stream[s]));
-}
-
-hipError_t LaunchTickLean(const StatePtrs &st, const TickIo &io, int n_streams, const int32_t *class_of_stream,
-                          const TickLeanEntry *table, const TickLeanEntry *single, hipStream_t stream) {
-    if (n_streams <= 0) return hipSuccess;
-    const dim3 grid((n_streams + kTickLeanWaves - 1) / kTickLeanWaves), block(64 * kTickLeanWaves);
-    const size_t lds = sizeof(LdsTables);
-    const bool clean = io.clean_in != nullptr;
-    if (table) {
-        if (clean) hipLaunchKernelGGL((aecm_tick_lean_classes_kernel<true>), grid, block, lds, stream, st, io, n_streams, class_of_stream, table);
-        else hipLaunchKernelGGL((aecm_tick_lean_classes_kernel<false>), grid, block, lds, stream, st, io, n_streams, class_of_stream, table);
-    } else {
-        if (clean) hipLaunchKernelGGL((aecm_tick_lean_kernel<true>), grid, block, lds, stream, st, io, n_streams, *single);
-        else hipLaunchKernelGGL((aecm_tick_lean_kernel<false>), grid, block, lds, stream, st, io, n_streams, *single);
-    }
-    return hipGetLastError();
-}
-
 // ---- device-resident session machinery (aecm_flow_plan.h) ---------------------------------------------
 template <bool kHasClean>
 struct TickFlowBlockIo {
@@ -620,11 +237,20 @@ void aecm_flow_plan_kernel(TickFlowIo fio, int n, unsigned near_pos, int n_strea
     for (int q = 0; q < kFlowPlanWords / 4; ++q) dst[q] = make_int4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
-#ifndef AECM_TICK_FLOW_WAVES_PER_EU
-#define AECM_TICK_FLOW_WAVES_PER_EU AECM_TICK_LEAN_WAVES_PER_EU
-#endif
+// Sessions per workgroup and occupancy target of the tick kernel.  A tick is only 2-3 blocks per session, so the 20 KB
+// table fill of the prologue and the launch's tail are a visible share of it: 8 sessions per workgroup halve the fills
+// of 4, and the kernel's I/O state lives in scalar registers, so it fits 64 VGPRs = 8 waves per SIMD (4 such workgroups
+// per CU).  Measured, 65 536 sessions (profiles/r02_experiments.md): 4 sessions / 7 waves 0.339 ms per tick, 8 / 7:
+// 0.324, 4 / 8: 0.323, 8 / 8: 0.306, 16 / 8: 0.312 (with the earlier, host-planned tick kernel; re-checked with this one).
 #ifndef AECM_TICK_FLOW_WAVES
-#define AECM_TICK_FLOW_WAVES AECM_TICK_LEAN_WAVES
+#define AECM_TICK_FLOW_WAVES 8
+#endif
+#ifndef AECM_TICK_FLOW_WAVES_PER_EU
+#if defined(AECM_CHECKED)
+#define AECM_TICK_FLOW_WAVES_PER_EU 4
+#else
+#define AECM_TICK_FLOW_WAVES_PER_EU 8
+#endif
 #endif
 constexpr int kTickFlowWaves = AECM_TICK_FLOW_WAVES;
 template <bool kHasClean>

@@ -47,7 +47,7 @@ SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_Tick", "WebRtcAecmSessions_TickHost", "WebRtcAecmSessions_TickPerSession",
     "WebRtcAecmSessions_TickPerSessionHost", "WebRtcAecmSessions_TickFlags", "WebRtcAecmSessions_TickFlagsHost",
     "WebRtcAecmSessions_InitSession", "WebRtcAecmSessions_set_config_session", "WebRtcAecmSessions_InitEchoPath",
-    "WebRtcAecmSessions_GetEchoPath", "WebRtcAecmSessions_num_flow_classes",
+    "WebRtcAecmSessions_GetEchoPath",
 ]
 SESSION_NO_FAREND = 1
 SESSION_SPLIT_CALLS = 2
@@ -132,7 +132,6 @@ def load():
     lib.WebRtcAecmSessions_set_config_session.argtypes = [vp, C.c_int32, AecmConfig]
     lib.WebRtcAecmSessions_InitEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmSessions_GetEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
-    lib.WebRtcAecmSessions_num_flow_classes.argtypes = [vp]
     lib.WebRtcAecmBatch_GetCheckCounters.argtypes = [C.c_int32, vp, C.c_int32]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
     lib.WebRtcAecmBatch_DebugFft128.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
@@ -343,8 +342,6 @@ class AecmBatch:
 class AecmSessions:
     """S streaming sessions with a common call cadence (include/aecm_batch.h, WebRtcAecmSessions_*)."""
 
-    MAX_FLOW_CLASSES = 1024      # distinct msInSndCardBuf histories per object (csrc/aecm_sessions.h)
-
     def __init__(self, num_streams: int, fs: int = 16000, cng_mode: int = 1, echo_mode: int = 3, device: int = 0):
         self.lib = load()
         self.num_streams = num_streams
@@ -427,9 +424,6 @@ class AecmSessions:
             raise ValueError("ms_per_session must have one entry per session")
         return self.lib.WebRtcAecmSessions_TickPerSession(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n,
                                                           ms.ctypes.data, None)
-
-    def num_flow_classes(self) -> int:
-        return self.lib.WebRtcAecmSessions_num_flow_classes(self.h)
 
     def close(self):
         if getattr(self, "h", None):
