@@ -124,9 +124,8 @@ if tick_stats.exists():
             for k, v in agg(SRC / d / "tick_counter_collection.csv", sub).items():
                 tf[f"{sub}:{k}"] = v
     tick["pmc_avg_per_launch"] = tf
-    # the kernel that runs the tick's blocks: the tick kernel of the device-resident session machinery (default), the lean
-    # one-launch tick kernel of the host-side flow classes, or the block kernel of the three-launch form
-    for sub, pat in (("aecm_tick", "aecm_tick_flow"), ("aecm_tick", "aecm_tick_lean"), ("aecm_process", "aecm_process_kernel")):
+    # the kernel that runs the tick's blocks
+    for sub, pat in (("aecm_tick", "aecm_tick_flow"),):
         if f"{sub}:FETCH_SIZE" in tf and f"{sub}:WRITE_SIZE" in tf and any(pat in r[0] for r in trows[1:]):
             rd = tf[f"{sub}:FETCH_SIZE"] * 1024 * fetch_factor
             wr = tf[f"{sub}:WRITE_SIZE"] * 1024

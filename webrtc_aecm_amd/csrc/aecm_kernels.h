@@ -22,7 +22,7 @@ enum KernelVariant : int {
 
 // Process n_blocks consecutive blocks of streams [0, n_streams) -- one wavefront per stream.
 // blocks_per_stream (device, may be null): stream s processes blocks_per_stream[s] <= n_blocks blocks
-// instead (streaming sessions whose flow classes are out of phase).
+// instead (batches whose streams have different amounts of audio pending).
 hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
                                hipStream_t stream, const int32_t *blocks_per_stream = nullptr);
 
