@@ -51,6 +51,7 @@ if has tick; then    # the streaming path: 65 536 sessions on a 10 ms clock
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_tick" -o tick -- $TICK > "$OUT/prof_tick.log" 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_tick_fetch" -o tick -- $TICK > "$OUT/prof_tick_fetch.log" 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/prof_tick_write" -o tick -- $TICK > "$OUT/prof_tick_write.log" 2>&1
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/prof_tick_sq" -o tick -- $TICK > "$OUT/prof_tick_sq.log" 2>&1
 fi
 if has pcs; then     # PC sampling of the block kernel (beta feature; bounded by a short timeout of its own)
   ROCPROFILER_PC_SAMPLING_BETA_ENABLED=1 timeout 180 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-unit time --pc-sampling-method host_trap \

@@ -134,6 +134,11 @@ if tick_stats.exists():
                                     "hbm_GBps": (rd + wr) / (avg_ns / 1e9) / 1e9, "hbm_frac_of_8TBps": (rd + wr) / (avg_ns / 1e9) / 8e12,
                                     "bytes_per_session_tick": (rd + wr) / 65536}
             break
+    sq = agg(SRC / "prof_tick_sq" / "tick_counter_collection.csv", "aecm_tick")
+    if sq:
+        # instruction issue of the tick kernel per session-tick (2.5 blocks per 16 kHz tick): what a tick costs on top of
+        # its blocks (state unpack / pack, table fill, ring appends, output assembly)
+        tick["insts_per_session_tick"] = {k: v / 65536 for k, v in sq.items()}
     tick["gpu_ms_per_tick_sum_of_kernels"] = per_tick_ns / 1e6
     try:
         tick["bench_sessions_line"] = json.loads([ln for ln in (SRC / "prof_tick.log").read_text().splitlines() if ln.startswith("{")][-1])
