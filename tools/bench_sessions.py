@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--ticks", type=int, default=300)
     ap.add_argument("--classes", type=int, default=1,
                     help="distinct msInSndCardBuf values among the sessions (> 1: WebRtcAecmSessions_TickPerSession, one value per session)")
+    ap.add_argument("--host", action="store_true", help="audio in host memory (WebRtcAecmSessions_TickHost): the PCIe-inclusive tick")
     args = ap.parse_args()
     import torch
 
@@ -34,7 +35,15 @@ def main():
     import numpy as np
     ms = (40 + (np.arange(S) % args.classes)).astype(np.int16)          # distinct values in [40, 40 + classes)
 
+    if args.host:
+        hfar = np.ascontiguousarray(far.cpu().numpy()[:, :n])
+        hnear = np.ascontiguousarray(near.cpu().numpy()[:, :n])
+
     def tick(i):
+        if args.host:
+            rc = sess.tick_host_per_session(hfar, hnear, ms)[0] if args.classes > 1 else sess.tick_host(hfar, hnear, 40)[0]
+            assert rc == 0, rc
+            return
         off = (i % 8) * n * 2
         if args.classes > 1:
             rc = sess.tick_device_per_session(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, ms)
@@ -50,7 +59,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.ticks
     blocks_per_tick = n / 64.0
-    print(json.dumps({"streams": S, "fs": fs, "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
+    print(json.dumps({"streams": S, "fs": fs, "audio": "host" if args.host else "device", "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
                       "realtime_streams_per_gpu": int(S * 0.010 / dt)}))
 
 

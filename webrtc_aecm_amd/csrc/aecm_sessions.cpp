@@ -54,8 +54,8 @@ SessionBatch::~SessionBatch() {
     if (flags_host_) (void)hipHostFree(flags_host_);
 }
 
-// WebRtcAecm_Init of the wrapper state of sessions [first, first + count) on the device: all zero but the three start-up
-// flags (FlowInit), empty frame stream and replay rows.  The rings are cleared by the callers.
+// WebRtcAecm_Init of the wrapper state of sessions [first, first + count) on the device (FlowFieldStartsAtOne says which
+// fields start at 1), empty frame stream and replay rows.  The rings are cleared by the callers.
 bool SessionBatch::ResetFlowRows(int first, int count) {
     hipStream_t st = engine_->stream();
     const size_t S = (size_t)engine_->num_streams();
@@ -205,16 +205,23 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
     const int16_t *dfar = far, *dnear = near, *dclean = clean;
     int16_t *dout = out;
     int64_t dstride = stride;
+    // Host audio: staged in device rows of n samples; rows that are dense on the host too travel as one copy each way.
+    auto copy_rows = [&](void *dst, size_t dpitch, const void *src, size_t spitch, hipMemcpyKind kind) {
+        const size_t width = (size_t)n * 2;
+        if (dpitch == width && spitch == width) return AECM_HIP_OK(hipMemcpyAsync(dst, src, width * S, kind, st));
+        return AECM_HIP_OK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, S, kind, st));
+    };
     if (host_pointers) {
-        dstride = 160;
-        int16_t *f = io_dev_, *d = io_dev_ + (size_t)S * 160, *c = io_dev_ + 3 * (size_t)S * 160;
-        if (!AECM_HIP_OK(hipMemcpy2DAsync(f, 320, far, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
-            !AECM_HIP_OK(hipMemcpy2DAsync(d, 320, near, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st)) ||
-            (clean && !AECM_HIP_OK(hipMemcpy2DAsync(c, 320, clean, stride * 2, (size_t)n * 2, S, hipMemcpyHostToDevice, st))))
+        dstride = n;
+        const size_t plane = (size_t)S * 160;
+        int16_t *f = io_dev_, *d = io_dev_ + plane, *c = io_dev_ + 3 * plane;
+        if (!copy_rows(f, (size_t)n * 2, far, (size_t)stride * 2, hipMemcpyHostToDevice) ||
+            !copy_rows(d, (size_t)n * 2, near, (size_t)stride * 2, hipMemcpyHostToDevice) ||
+            (clean && !copy_rows(c, (size_t)n * 2, clean, (size_t)stride * 2, hipMemcpyHostToDevice)))
             return fail();
         dfar = f;
         dnear = d;
-        dout = io_dev_ + 2 * (size_t)S * 160;
+        dout = io_dev_ + 2 * plane;
         if (clean) dclean = c;
     }
     TickIo tio{dfar, dnear, dclean, dout, dstride, n, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, near_pos_};
@@ -223,8 +230,7 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
     const bool ok = engine_->variant() == kVariantFast && AECM_HIP_OK(LaunchTickFlow(engine_->state_ptrs(), tio, fio, S, st));
     near_pos_ += n;
     if (!ok) return fail();
-    if (host_pointers && !AECM_HIP_OK(hipMemcpy2DAsync(out, stride * 2, dout, 320, (size_t)n * 2, S, hipMemcpyDeviceToHost, st)))
-        return fail();
+    if (host_pointers && !copy_rows(out, (size_t)stride * 2, dout, (size_t)n * 2, hipMemcpyDeviceToHost)) return fail();
     if (!AECM_HIP_OK(hipStreamSynchronize(st))) return fail();
     return first_rc;
 }
