@@ -161,7 +161,8 @@ int32_t WebRtcAecmSessions_TickFlagsHost(AecmSessions *s, const int16_t *far_hos
  *                             fresh jitter buffer / start-up phase, default config (cng on, echoMode 3)
  *   set_config_session    <-> WebRtcAecm_set_config(inst_s, config)   (:156)
  *   InitEchoPath / GetEchoPath <-> WebRtcAecm_InitEchoPath / GetEchoPath (:172, :191), 130 bytes
- * Each call synchronises the object's stream (a control operation, not a per-tick one). */
+ * InitSession and set_config_session are kernel launches ordered before the next tick on the object's stream (no
+ * synchronisation with the host); InitEchoPath / GetEchoPath synchronise. */
 int32_t WebRtcAecmSessions_InitSession(AecmSessions *s, int32_t session);
 int32_t WebRtcAecmSessions_set_config_session(AecmSessions *s, int32_t session, AecmConfig config);
 int32_t WebRtcAecmSessions_InitEchoPath(AecmSessions *s, int32_t session, const void *echo_path, size_t size_bytes);

@@ -29,7 +29,6 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
               AECM_HIP_OK(hipMalloc((void **)&e->st_.hist, S * kHistWordsPerStream * sizeof(uint16_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&e->image_vec_dev_, kVecWordsPerStream * sizeof(uint32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&e->image_scal_dev_, kNumScal * sizeof(int32_t))) &&
-              AECM_HIP_OK(hipMalloc((void **)&e->patch_dev_, 32 * sizeof(int32_t))) &&
               AECM_HIP_OK(hipMalloc((void **)&e->consts_dev_, kConstBlobWords * sizeof(uint32_t))) &&
               true;                                   // the timing events are created on first use (ProcessBlocks)
     if (ok) {
@@ -57,7 +56,6 @@ BatchEngine::~BatchEngine() {
     (void)hipFree(st_.hist);
     (void)hipFree(image_vec_dev_);
     (void)hipFree(image_scal_dev_);
-    (void)hipFree(patch_dev_);
     (void)hipFree(consts_dev_);
     (void)hipFree(stage_dev_);
     if (mapped_host_) (void)hipHostFree(mapped_host_);
@@ -92,17 +90,17 @@ bool BatchEngine::InitStreams(int first, int count) {
     return AECM_HIP_OK(LaunchBroadcastImage(st_, image_vec_dev_, image_scal_dev_, first, count, stream_));
 }
 
+// Stream-ordered, no synchronisation: the next launch on the engine's stream sees the new values.
 bool BatchEngine::PatchScalars(const int32_t *fields, const int32_t *values, int n, int first, int count) {
-    if (n > 16) return false;
+    if (n > kMaxPatchFields) return false;
     if (count < 0) count = num_streams_ - first;
     if (first < 0 || count < 0 || first + count > num_streams_) return false;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
-    int32_t host[32];
-    memcpy(host, fields, n * sizeof(int32_t));
-    memcpy(host + 16, values, n * sizeof(int32_t));
-    if (!AECM_HIP_OK(hipMemcpyAsync(patch_dev_, host, sizeof host, hipMemcpyHostToDevice, stream_))) return false;
-    if (!AECM_HIP_OK(LaunchPatchScalars(st_, patch_dev_, patch_dev_ + 16, n, first, count, stream_))) return false;
-    return AECM_HIP_OK(hipStreamSynchronize(stream_));               // host[] is on the stack
+    ScalarPatch patch{};
+    patch.n = n;
+    memcpy(patch.field, fields, n * sizeof(int32_t));
+    memcpy(patch.value, values, n * sizeof(int32_t));
+    return AECM_HIP_OK(LaunchPatchScalars(st_, patch, first, count, stream_));
 }
 
 bool BatchEngine::SetConfig(int cng_mode, int echo_mode, int first, int count) {
@@ -443,7 +441,7 @@ bool BatchEngine::SetEchoPath(int stream, const int16_t path[kBins]) {
     const int32_t fields[7] = {S_B64_CHSTORED, S_B64_CHADAPT16, S_B64_CHADAPT32, S_MSE_ADAPT_OLD, S_MSE_STORED_OLD, S_MSE_THRESH, S_MSECNT};
     int32_t values[7];
     for (int i = 0; i < 7; ++i) values[i] = scal[fields[i]];
-    return PatchScalars(fields, values, 7, stream, 1);          // synchronises the stream (vec goes out of scope)
+    return PatchScalars(fields, values, 7, stream, 1) && AECM_HIP_OK(hipStreamSynchronize(stream_));   // vec goes out of scope
 }
 
 bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {

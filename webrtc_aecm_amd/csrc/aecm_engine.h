@@ -72,7 +72,6 @@ private:
     uint32_t *consts_dev_ = nullptr;     // kernel constants blob (aecm_state.h)
     uint32_t *image_vec_dev_ = nullptr;
     int32_t *image_scal_dev_ = nullptr;
-    int32_t *patch_dev_ = nullptr;       // 2 x 16 ints
     // Launch timing: a small ring of HIP event pairs recorded around every block-kernel launch on stream_.
     // ProcessBlocks only harvests pairs that have already completed (hipEventQuery) and waits for the oldest
     // one only when the ring is full, so launches queue back to back; the getters harvest everything.

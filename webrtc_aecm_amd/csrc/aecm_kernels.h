@@ -31,9 +31,14 @@ hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_stre
 hipError_t LaunchBroadcastImage(const StatePtrs &st, const uint32_t *image_vec, const int32_t *image_scal,
                                 int first, int count, hipStream_t stream);
 
-// Overwrite a few scalar fields (field ids from ScalField) of streams [first, first + count).
-hipError_t LaunchPatchScalars(const StatePtrs &st, const int32_t *fields_dev, const int32_t *values_dev, int n_fields,
-                              int first, int count, hipStream_t stream);
+// Overwrite a few scalar fields (field ids from ScalField) of streams [first, first + count).  The fields travel as a
+// kernel argument: no staging copy, nothing for the host to wait for.
+constexpr int kMaxPatchFields = 16;
+struct ScalarPatch {
+    int32_t n;
+    int32_t field[kMaxPatchFields], value[kMaxPatchFields];
+};
+hipError_t LaunchPatchScalars(const StatePtrs &st, const ScalarPatch &patch, int first, int count, hipStream_t stream);
 
 // Session-schedule gather / scatter (aecm_session_flow.h: RecordingSchedule), all streams at once.
 //   dst[s][j] = map[j] >= 0 ? src[s*src_stride + map[j]] : 0            j in [0, n)
@@ -74,6 +79,10 @@ struct TickFlowIo {
     int32_t ms, flags, fs;
 };
 hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowIo &fio, int n_streams, hipStream_t stream);
+// WebRtcAecm_Init of the wrapper side of sessions [first, first + count): wrapper state as after Init (aecm_flow_plan.h:
+// FlowFieldStartsAtOne), far / output rings, framed-far ring and replay rows reading as never written (zero).  Only the
+// ring pointers, ring_len and the state / far_frames / far_old pointers of io / fio are used.
+hipError_t LaunchResetSessions(const TickIo &io, const TickFlowIo &fio, int n_streams, int first, int count, hipStream_t stream);
 
 // Diagnostics: `count` independent 128-point transforms of the block kernel's fft128, one wavefront
 // each, on natural-order data (data[k] = re[128] then im[128] of transform k, in place).  variant:

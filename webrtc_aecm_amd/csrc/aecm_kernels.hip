@@ -135,21 +135,18 @@ hipError_t LaunchBroadcastImage(const StatePtrs &st, const uint32_t *image_vec, 
     return hipGetLastError();
 }
 
-__global__ void aecm_patch_scalars_kernel(StatePtrs st, const int32_t *fields, const int32_t *values, int n_fields,
-                                          int first, int count) {
+__global__ void aecm_patch_scalars_kernel(StatePtrs st, ScalarPatch patch, int first, int count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)count * n_fields) return;
-    const int64_t s = first + i / n_fields;
-    const int f = (int)(i % n_fields);
-    st.scal[s * (int64_t)kNumScal + fields[f]] = values[f];
+    if (i >= (int64_t)count * patch.n) return;
+    const int64_t s = first + i / patch.n;
+    const int f = (int)(i % patch.n);
+    st.scal[s * (int64_t)kNumScal + patch.field[f]] = patch.value[f];
 }
 
-hipError_t LaunchPatchScalars(const StatePtrs &st, const int32_t *fields_dev, const int32_t *values_dev, int n_fields,
-                              int first, int count, hipStream_t stream) {
-    if (count <= 0 || n_fields <= 0) return hipSuccess;
-    const int64_t total = (int64_t)count * n_fields;
-    hipLaunchKernelGGL(aecm_patch_scalars_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, st,
-                       fields_dev, values_dev, n_fields, first, count);
+hipError_t LaunchPatchScalars(const StatePtrs &st, const ScalarPatch &patch, int first, int count, hipStream_t stream) {
+    if (count <= 0 || patch.n <= 0) return hipSuccess;
+    const int64_t total = (int64_t)count * patch.n;
+    hipLaunchKernelGGL(aecm_patch_scalars_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, st, patch, first, count);
     return hipGetLastError();
 }
 
@@ -352,6 +349,26 @@ hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowI
     const size_t lds = sizeof(LdsTables);
     if (io.clean_in) hipLaunchKernelGGL((aecm_tick_flow_kernel<true>), grid, block, lds, stream, st, io, fio, n_streams);
     else hipLaunchKernelGGL((aecm_tick_flow_kernel<false>), grid, block, lds, stream, st, io, fio, n_streams);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256)
+void aecm_reset_sessions_kernel(TickIo io, TickFlowIo fio, int n_streams, int first) {
+    const int64_t s = (int64_t)first + blockIdx.x;
+    auto zero = [&](int16_t *row, int64_t n_samples) {                       // rows are 4-byte aligned and even-sized
+        uint32_t *w = reinterpret_cast<uint32_t *>(row);
+        for (int64_t i = threadIdx.x; i < n_samples / 2; i += 256) w[i] = 0u;
+    };
+    zero(io.far_ring + s * io.ring_len, io.ring_len);
+    zero(io.out_ring + s * io.ring_len, io.ring_len);
+    zero(fio.far_frames + s * kFlowFarFrameRing, kFlowFarFrameRing);
+    zero(fio.far_old + s * (2 * kFlowFrame), 2 * kFlowFrame);
+    if (threadIdx.x < kFlowFieldsUsed) fio.state[(size_t)threadIdx.x * n_streams + s] = FlowFieldStartsAtOne((int)threadIdx.x) ? 1 : 0;
+}
+
+hipError_t LaunchResetSessions(const TickIo &io, const TickFlowIo &fio, int n_streams, int first, int count, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_reset_sessions_kernel, dim3(count), dim3(256), 0, stream, io, fio, n_streams, first);
     return hipGetLastError();
 }
 

@@ -54,18 +54,11 @@ SessionBatch::~SessionBatch() {
     if (flags_host_) (void)hipHostFree(flags_host_);
 }
 
-// WebRtcAecm_Init of the wrapper state of sessions [first, first + count) on the device (FlowFieldStartsAtOne says which
-// fields start at 1), empty frame stream and replay rows.  The rings are cleared by the callers.
+// WebRtcAecm_Init of the wrapper side of sessions [first, first + count): one launch (aecm_kernels.h).
 bool SessionBatch::ResetFlowRows(int first, int count) {
-    hipStream_t st = engine_->stream();
-    const size_t S = (size_t)engine_->num_streams();
-    bool ok = true;
-    for (int f = 0; f < kFlowFieldsUsed; ++f) {                       // field-major: one short run per field
-        const int value = FlowFieldStartsAtOne(f) ? 1 : 0;
-        ok = ok && AECM_HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(flow_state_ + (size_t)f * S + first), value, (size_t)count, st));
-    }
-    return ok && AECM_HIP_OK(hipMemsetAsync(far_frames_ + (size_t)first * kFlowFarFrameRing, 0, (size_t)count * kFlowFarFrameRing * 2, st)) &&
-           AECM_HIP_OK(hipMemsetAsync(far_old_ + (size_t)first * 2 * kFlowFrame, 0, (size_t)count * 2 * kFlowFrame * 2, st));
+    TickIo tio{nullptr, nullptr, nullptr, nullptr, 0, 0, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, 0};
+    TickFlowIo fio{flow_state_, flow_plans_, far_frames_, far_old_, nullptr, nullptr, 0, 0, fs_};
+    return AECM_HIP_OK(LaunchResetSessions(tio, fio, engine_->num_streams(), first, count, engine_->stream()));
 }
 
 int32_t SessionBatch::Init(int32_t samp_freq) {
@@ -73,9 +66,7 @@ int32_t SessionBatch::Init(int32_t samp_freq) {
     if (!engine_->Init(samp_freq)) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
     const size_t bytes = (size_t)S * kRing * 2;
-    if (!AECM_HIP_OK(hipMemsetAsync(far_ring_, 0, bytes, engine_->stream())) ||
-        !AECM_HIP_OK(hipMemsetAsync(near_ring_, 0, bytes, engine_->stream())) ||
-        !AECM_HIP_OK(hipMemsetAsync(out_ring_, 0, bytes, engine_->stream())) ||
+    if (!AECM_HIP_OK(hipMemsetAsync(near_ring_, 0, bytes, engine_->stream())) ||
         (clean_ring_ && !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, engine_->stream()))) || !ResetFlowRows(0, S))
         return AECM_UNSPECIFIED_ERROR;
     near_pos_ = 0;
@@ -96,11 +87,8 @@ int32_t SessionBatch::CheckSession(int session) const {
 // output ring is stuffed from it: ring_buffer.c:75-82).
 int32_t SessionBatch::InitSession(int session) {
     if (int32_t rc = CheckSession(session)) return rc;
-    hipStream_t st = engine_->stream();
-    const size_t row = (size_t)kRing * 2, off = (size_t)session * kRing;
-    const bool ok = AECM_HIP_OK(hipSetDevice(device_)) && engine_->InitStreams(session, 1) && ResetFlowRows(session, 1) &&
-                    AECM_HIP_OK(hipMemsetAsync(far_ring_ + off, 0, row, st)) && AECM_HIP_OK(hipMemsetAsync(out_ring_ + off, 0, row, st)) &&
-                    AECM_HIP_OK(hipStreamSynchronize(st));
+    // two launches, ordered before the next tick on the object's stream: no synchronisation with the host
+    const bool ok = AECM_HIP_OK(hipSetDevice(device_)) && engine_->InitStreams(session, 1) && ResetFlowRows(session, 1);
     if (!ok) { poisoned_ = true; return AECM_UNSPECIFIED_ERROR; }
     return 0;
 }
