@@ -30,7 +30,6 @@ namespace {
 
 inline uint32_t Pack16(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | (((uint32_t)(uint16_t)hi) << 16); }
 inline int Lo16(uint32_t w) { return (int16_t)(w & 0xffff); }
-inline int Hi16(uint32_t w) { return (int16_t)(w >> 16); }
 inline uint32_t FnvStep(uint32_t h, uint32_t w) { return (h ^ w) * 16777619u; }
 constexpr uint32_t kFnvInit = 2166136261u;
 inline int BitRev6(int t) {
