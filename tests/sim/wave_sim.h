@@ -162,6 +162,7 @@ struct SimWave {
     template <int ROW> static vi table_lane_const(const vi &) { return vi(0); }   // never used (kLaneConstsInTable == false)
     static vi table_index_for_this_block() { return vi(0); }
     static void begin_block(int, int) {}
+    static int pin_uniform(int x) { return x; }                            // device: a uniform value pinned to a scalar register
     static int per_block(int x) { return x; }                              // device: keeps launch-invariant conditions in the loop                                   // device: issue-priority rotation
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }

@@ -546,9 +546,29 @@ struct BlockEngine {
             if (u.fe_min >= u.fe_max) {
                 mu = kMuMin;
             } else {
-                int t16 = sext16(u.far_log - u.fe_min);
-                int t32 = divi(t16 * kMuDiff, u.fe_maxmin);
-                mu = sext16(kMuMin - 1 - sext16(t32));
+                // mu = MU_MIN - 1 - (int16)(9 * t16 / farEnergyMaxMin), then clamped to >= MU_MAX = 1: every quotient in
+                // [8, 32767] gives 1.  The usual case -- far energy at or above its tracked minimum, a tracked range of
+                // at least 9 (so that the quotient of a numerator <= 9 * 32767 stays below 2^15 and the int16 cast is
+                // the identity) -- therefore needs no division: three compare-subtract steps on the scalar unit instead
+                // of a float-reciprocal division on the vector unit.
+                const int t16 = sext16(u.far_log - u.fe_min);
+                const int num = t16 * kMuDiff, den = u.fe_maxmin;
+                int q;
+                if (AECM_LIKELY(num >= 0 && den >= kMuDiff)) {
+                    int rem = num;
+                    q = 8;
+                    if (rem < 8 * den) {
+                        q = 0;
+                        if (rem >= 4 * den) { q = 4; rem -= 4 * den; }
+                        if (rem >= 2 * den) { q += 2; rem -= 2 * den; }
+                        // 0 <= rem < 2 den here: +1 iff rem >= den.  As sign arithmetic on a pinned scalar: written as a
+                        // comparison, the compiler turns the uniform boolean into an integer on the vector unit.
+                        q += 1 + W::pin_uniform(sar(rem - den, 31));
+                    }
+                } else {
+                    q = sext16(divi(num, den));
+                }
+                mu = sext16(kMuMin - 1 - q);
             }
             if (mu < kMuMax) mu = kMuMax;
         }
@@ -673,7 +693,13 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     // Wiener gain of one bin (reference aecm/aecm_core_c.cc:517-615)
     // ------------------------------------------------------------------------------------------
-    template <class I>
+    // kUni: the instantiation for bin 64, whose operands are wave-uniform (on the device I is int for both).
+    template <bool kUni, class I>
+    static AECM_HD I uniform_hint(I x) {
+        if constexpr (kUni) return I(W::pin_uniform((int)x));
+        else return x;
+    }
+    template <class I, bool kUni = false>
     static AECM_HD I wiener_bin(BinState<I> &s, I echo_est, I dfa_clean, int sup_gain, int clean_q, int clean_q_old,
                                 int zeros_xbuf) {
         // echoFilt += ((int64)(echoEst - echoFilt) * 50) >> 8 (:523-525): the arithmetic shift of the 64-bit product is
@@ -715,7 +741,14 @@ struct BlockEngine {
         I g2 = add(gained, sar(s.near_filt, 1));                                              // :582-611
         I t32 = shift_u31(divu(g2, zext16(s.near_filt)), res_diff);                           // -20 <= res_diff <= 23
         // :597-611: hnl = ONE_Q14 - t32 clipped to [0, ONE_Q14], ONE_Q14 for a t32 that wrapped negative: ONE_Q14 - clamp(t32)
-        I h = I(kOneQ14) - imax(imin(t32, I(kOneQ14)), I(0));
+        I h;
+        if constexpr (kUni) {
+            // the same value as max(ONE_Q14 - max(t32, 0), 0) (no overflow: t32 >= -2^31), with the difference pinned to a
+            // scalar register: fused, the expression is a saturating subtract, which only the vector unit has
+            h = imax(uniform_hint<kUni>(I(kOneQ14) - imax(t32, I(0))), I(0));
+        } else {
+            h = I(kOneQ14) - imax(imin(t32, I(kOneQ14)), I(0));
+        }
         return sel(gained == 0, I(kOneQ14), sel(s.near_filt == 0, I(0), h));
     }
 
@@ -738,7 +771,7 @@ struct BlockEngine {
         I ne_ge = sel(c19, mul24(sar(s.noise_est, 11), I(2049)),
                       sel(c11, sar(mul24(s.noise_est & 0x7ffff, I(2049)), 11),   // c11 && !c19: noise_est < 2^19
                           sel(inc, s.noise_est + sar(s.noise_est, 9) + 1, s.noise_est)));
-        I low_ge = sel(c11, s.low_ctr, sel(inc, I(0), low_inc));                                // c19 implies c11
+        I low_ge = sel(c11, s.low_ctr, sel(inc, I(0), low_inc));              // c19 implies c11
         I ne = sel(lt, ne_lt, ne_ge);
         s.low_ctr = sel(lt, I(0), low_ge);
         s.high_ctr = sel(lt, high_lt, I(0));
@@ -928,7 +961,7 @@ struct BlockEngine {
         const int sup_gain = calc_suppression_gain(r);                                // :514
 
         vi hnl = wiener_bin<vi>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
-        int hnl64 = wiener_bin<int>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+        int hnl64 = wiener_bin<int, true>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
         const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
 
         AECM_PHASE_MARK(8, hnl, r.b.near_filt);

@@ -88,6 +88,15 @@ struct Gfx950Wave {
     // configuration (mult, nlp, cng, ...) are otherwise hoisted out of the block loop as 64-bit lane masks, and with the
     // scalar registers as full as they are here those masks get spilled to lanes of a VGPR and read back with two
     // v_readlane -- VALU instructions -- per use; re-evaluating the condition is one scalar compare.
+    // x, behind an addition of a scalar zero the compiler cannot see through.  For wave-uniform values, where the
+    // compiler would otherwise fuse scalar arithmetic into an operation only the vector unit has (a saturating subtract,
+    // a boolean turned into an integer through v_cndmask) and pay VALU slots plus a v_readfirstlane for ONE value.  (Not
+    // an asm register constraint on x itself: where the compiler happens to hold x in a VGPR that is a hard error.)
+    static __device__ __forceinline__ int pin_uniform(int x) {
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        return x + zero;
+    }
     static __device__ __forceinline__ int per_block(int x) {
         asm volatile("" : "+s"(x));
         return x;
