@@ -435,7 +435,7 @@ struct BlockEngine {
 
     static AECM_HD int process_binary(Regs &r, int near_word) {
         Uniform &u = r.u;
-        vb valid1 = r.lane < (kHistory - 64);
+        vb valid1 = lane_now(r) < (kHistory - 64);       // compared here (one instruction), not hoisted into a spilled mask
         vi fb0 = popc(r.bh0), fb1 = popc(r.bh1);
         vi bc0 = shl(popc(r.bh0 ^ vi(near_word)), 9), bc1 = shl(popc(r.bh1 ^ vi(near_word)), 9);
         vb upd0 = fb0 > 0, upd1 = valid1 & (fb1 > 0);
