@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "aecm_flow_plan.h"
+#include "aecm_ops.h"
 #include "aecm_session_flow.h"
 
 namespace {
@@ -189,6 +190,30 @@ int sim_flow_tolerance_check(void) {
             const bool ours = d < 8 || 5 * d < ms;
             bad += ref != ours;
         }
+    return bad;
+}
+
+// divu_by_magic (aecm_ops.h: the NLMS step's division by bin + 1 through a 33-bit reciprocal) against n / d for every
+// divisor the kernel uses and dividends around every multiple boundary plus a pseudo-random sweep of [0, 2^31].
+// Returns the number of disagreements.
+int sim_div_magic_check(void) {
+    int bad = 0;
+    uint64_t x = 88172645463325252ull;
+    for (int d = 1; d <= 65; ++d) {
+        int magic, shift;
+        div_magic(d, &magic, &shift);
+        auto check = [&](uint32_t n) { bad += (uint32_t)divu_by_magic<int>((int)n, magic, shift) != n / (uint32_t)d; };
+        for (uint32_t k = 0; k < 64; ++k)
+            for (int e = -2; e <= 2; ++e) {
+                const int64_t n = (int64_t)k * d * 33554432 / 64 * 64 + e;            // around multiples of d across the range
+                if (n >= 0 && n <= 2147483648ll) check((uint32_t)n);
+            }
+        for (uint32_t n : {0u, 1u, 2147483646u, 2147483647u, 2147483648u}) check(n);
+        for (int i = 0; i < 200000; ++i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            check((uint32_t)(x % 2147483649ull));
+        }
+    }
     return bad;
 }
 

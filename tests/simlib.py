@@ -58,6 +58,7 @@ def lib():
         l.sim_flow_fuzz.restype = C.c_int64
         l.sim_flow_fuzz.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_int64)]
         l.sim_flow_tolerance_check.restype = C.c_int
+        l.sim_div_magic_check.restype = C.c_int
         _lib = l
     return _lib
 

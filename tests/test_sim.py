@@ -279,3 +279,8 @@ def test_device_session_machinery_equals_the_generic_wrapper_on_sample_tags(fs):
     # buffer and replay frames that had to move to their rows were all exercised
     assert saw_blocks > 100000 and saw_direct > 50000 and saw_framed > 50000 and saw_spills > 50
     assert fs == 8000 or saw_drops > 1000
+
+
+def test_reciprocal_division_of_the_nlms_step_is_exact():
+    """divu_by_magic with div_magic's 33-bit reciprocals == n / d for d = 1..65 (bin + 1) over [0, 2^31]."""
+    assert simlib.lib().sim_div_magic_check() == 0

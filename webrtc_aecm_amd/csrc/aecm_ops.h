@@ -237,26 +237,19 @@ AECM_HD int mulhi_i32(int a, int b) { return (int)(((int64_t)a * (int64_t)b) >> 
 // High 32 bits of the unsigned 64-bit product                                -> v_mul_hi_u32
 AECM_HD int mulhi_u32(int a, int b) { return (int)(((uint64_t)(uint32_t)a * (uint64_t)(uint32_t)b) >> 32); }
 
-// Truncating signed division by a small positive constant divisor d (2 <= d <= 2^16) through a
-// precomputed reciprocal: with L = ceil(log2 d) and M = ceil(2^(31+L) / d) < 2^32,
-//   floor(n / d) == mulhi_u32(n, M) >> (L - 1)      for every 0 <= n <= 2^31
-// (Granlund-Montgomery: the error e = M*d - 2^(31+L) < 2^L, so n*e < 2^(31+L)).  d == 1 passes
-// magic == 0 and is returned unchanged.
+// floor(n / d) for 0 <= n <= 2^31 and a small divisor 1 <= d <= 2^16 through a precomputed reciprocal: with
+// L = ceil(log2 d) and the 33-bit M = ceil(2^(32+L) / d) in [2^32, 2^33),
+//   floor(n / d) == floor(n * M / 2^(32+L)) == (n + mulhi_u32(n, M - 2^32)) >> L
+// (Granlund-Montgomery with one more bit of reciprocal than the dividend has, exact for every 32-bit n; the sum cannot
+// overflow: mulhi_u32(n, .) < n <= 2^31).  d == 1 is no special case: M - 2^32 == 0, L == 0.
 AECM_HD void div_magic(int d, int *magic, int *shift) {
-    if (d <= 1) { *magic = 0; *shift = 0; return; }
-    int L = 32 - clz32(d - 1);                                   // ceil(log2 d)
-    const uint64_t num = (uint64_t)1 << (31 + L);
-    *magic = (int)(uint32_t)((num + (uint64_t)d - 1) / (uint64_t)d);
-    *shift = L - 1;
+    const int L = d <= 1 ? 0 : 32 - clz32(d - 1);                // ceil(log2 d)
+    const uint64_t num = (uint64_t)1 << (32 + L);
+    const uint64_t m33 = (num + (uint64_t)d - 1) / (uint64_t)d;
+    *magic = (int)(uint32_t)(m33 - ((uint64_t)1 << 32));
+    *shift = L;
 }
-// The same for a dividend known to be non-negative: no sign handling.
-template <class I> AECM_HD I divu_by_magic(I n, I magic, I shift) { return sel(magic == 0, n, lsr(mulhi_u32(n, magic), shift)); }
-template <class I> AECM_HD I div_by_magic(I x, I magic, I shift) {
-    I sign = sar(x, 31);
-    I n = sub(x ^ sign, sign);                                   // |x| (2^31 for INT_MIN, still in range)
-    I q = sel(magic == 0, n, lsr(mulhi_u32(n, magic), shift));
-    return sub(q ^ sign, sign);
-}
+template <class I> AECM_HD I divu_by_magic(I n, I magic, I shift) { return lsr(add(n, mulhi_u32(n, magic)), shift); }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 AECM_HD int add_sat32(int a, int b) { return __builtin_elementwise_add_sat(a, b); }   // v_add_i32 clamp

@@ -136,8 +136,8 @@ struct BlockEngine {
         r.k_p = W::opaque_const(32770);
         r.lcg_mul64 = (int)lcg_pow(64);
         r.lcg_add64 = (int)lcg_inc(64);
-        r.bin64_div_magic = (int)4228890877u;            // ceil(2^38 / 65), see div_magic()
-        r.bin64_div_shift = 6;
+        r.bin64_div_magic = (int)4162814457u;            // ceil(2^39 / 65) - 2^32, see div_magic()
+        r.bin64_div_shift = 7;
         if (W::kLaneConstsInTable) return;               // device: read from the LDS copy of the blob at each use
         if (W::kPrecomputedConstants) {                  // device: one coalesced load per row
             for (int k = 0; k < kLaneConstRows; ++k) r.lc[k] = W::load_u32(consts + k * kLanes, r.lane);
