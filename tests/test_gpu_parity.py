@@ -828,6 +828,42 @@ def test_replay_frame_outlives_its_place_in_the_far_ring(fs):
 
 
 @_needs_ref
+def test_65536_live_sessions_property():
+    """The serving claim at its full size, through a size-independent property: 65 536 sessions replicate 32 distinct
+    (audio, msInSndCardBuf) pairs, so every session must equal -- tick by tick, over start-up, delay compensation and
+    steady state -- the reference session of the pair it replicates (device-resident audio, per-session delays)."""
+    import torch
+    S, U, fs, frame, n_ticks = 65536, 32, 16000, 160, 48
+    pairs = [synth_pair(7000 + k, n_ticks * frame // 64 + 1, fs, "mixed") for k in range(U)]
+    far_u = np.stack([p[0][:n_ticks * frame] for p in pairs])
+    near_u = np.stack([p[1][:n_ticks * frame] for p in pairs])
+    ms_u = (25 + 4 * np.arange(U)).astype(np.int16)                       # 25 .. 149 ms: different start-up lengths and stuffing
+    refs = [pyoracle.RefSession(fs, 1, 3) for _ in range(U)]
+    exp = np.empty((U, n_ticks * frame), dtype=np.int16)
+    for i in range(n_ticks):
+        sl = slice(i * frame, (i + 1) * frame)
+        for k in range(U):
+            assert refs[k].buffer_farend(far_u[k, sl]) == 0
+            rc, exp[k, sl] = refs[k].process(near_u[k, sl], None, int(ms_u[k]))
+            assert rc == 0
+    idx = torch.arange(S) % U
+    dfar = torch.from_numpy(far_u)[idx].contiguous().cuda()
+    dnear = torch.from_numpy(near_u)[idx].contiguous().cuda()
+    dexp = torch.from_numpy(exp).cuda()
+    ms = ms_u[idx.numpy()]
+    # Tick() uses ONE row stride for far, near and out: give the output the recordings' stride too
+    dout = torch.empty_like(dnear)
+    torch.cuda.synchronize()
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    for i in range(n_ticks):
+        off = i * frame * 2                                                # bytes into every row
+        assert sb.tick_device_per_session(dfar.data_ptr() + off, dnear.data_ptr() + off, dout.data_ptr() + off, dfar.shape[1], frame, ms) == 0
+    torch.cuda.synchronize()
+    sb.close()
+    assert torch.equal(dout.view(S // U, U, -1), dexp.unsqueeze(0).expand(S // U, U, -1))
+
+
+@_needs_ref
 def test_sixteen_thousand_sessions_each_with_its_own_history():
     """The serving shape at scale: 16 384 live sessions, EVERY one with its own msInSndCardBuf walk, its own far-end
     underruns, its own call shape (one 160-sample call or two of 80) and its own age (slots re-initialised at random
