@@ -828,12 +828,13 @@ def test_replay_frame_outlives_its_place_in_the_far_ring(fs):
 
 
 @_needs_ref
-def test_65536_live_sessions_property():
+@pytest.mark.parametrize("fs,frame", [(16000, 160), (8000, 80), (8000, 160)])
+def test_65536_live_sessions_property(fs, frame):
     """The serving claim at its full size, through a size-independent property: 65 536 sessions replicate 32 distinct
     (audio, msInSndCardBuf) pairs, so every session must equal -- tick by tick, over start-up, delay compensation and
     steady state -- the reference session of the pair it replicates (device-resident audio, per-session delays)."""
     import torch
-    S, U, fs, frame, n_ticks = 65536, 32, 16000, 160, 48
+    S, U, n_ticks = 65536, 32, 48
     pairs = [synth_pair(7000 + k, n_ticks * frame // 64 + 1, fs, "mixed") for k in range(U)]
     far_u = np.stack([p[0][:n_ticks * frame] for p in pairs])
     near_u = np.stack([p[1][:n_ticks * frame] for p in pairs])
