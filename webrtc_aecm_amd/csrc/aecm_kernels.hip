@@ -198,7 +198,7 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
 }
 
 // ---- device-resident session machinery (aecm_flow_plan.h) ---------------------------------------------
-template <bool kHasClean>
+template <bool kHasClean, class Append>
 struct TickFlowBlockIo {
     using E = BlockEngine<Gfx950Wave<true>, kHasClean>;
     using Regs = typename E::Regs;
@@ -207,13 +207,18 @@ struct TickFlowBlockIo {
     int16_t *out_row;                // output stream ring
     int far_mask, mask;
     unsigned far_pos, near_pos, out_pos;      // positions of the tick's first block in far_src / the near rings / the output ring
+    const Append &append;            // the tick's samples -> rings
     __device__ __forceinline__ int far(const Regs &r, int b) const { return far_src[(far_pos + b * kBlock + r.lane) & far_mask]; }
     __device__ __forceinline__ int near(const Regs &r, int b) const { return nr[(near_pos + b * kBlock + r.lane) & mask]; }
     __device__ __forceinline__ int clean(const Regs &r, int b) const { return cr[(near_pos + b * kBlock + r.lane) & mask]; }
     __device__ __forceinline__ void out(const Regs &r, int b, int v) const { out_row[(out_pos + b * kBlock + r.brev) & mask] = (int16_t)v; }
-    // this wave's fetches below must see this wave's stores (the tick's samples, the framed far end); the engine's state
-    // loads are already in flight
-    __device__ __forceinline__ void ready() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+    // Called by the engine after it has issued its state loads: the tick's samples go into the rings HERE (8-byte stores
+    // that, placed ahead of those loads, would make the compiler fetch the scalar half of the state with vector loads: for
+    // all it knows they could alias it), then this wave's fetches below must see this wave's stores.
+    __device__ __forceinline__ void ready() const {
+        append();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
 };
 
 // One lane per session: the tick's session machinery for 64 sessions per wavefront.
@@ -275,13 +280,35 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
     int16_t *orow = io.out_ring + s * io.ring_len;
     int16_t *ff = fio.far_frames + s * kFlowFarFrameRing, *old = fio.far_old + s * (2 * kFlowFrame);
     int16_t *out = io.out + s * io.io_stride;
-    // 2. the tick's samples into the rings: what the jitter buffer accepted of the far end, all of the near end
-    for (int j = lane; j < n; j += 64) {
-        for (int c = 0; c < 2; ++c)
-            if (j >= p.far[c].src && j < p.far[c].src + p.far[c].count) fr[(p.far[c].pos + (unsigned)(j - p.far[c].src)) & mask] = fin[j];
-        nr[((unsigned)io.near_pos + j) & mask] = nin[j];
-        if (kHasClean) cr[((unsigned)io.near_pos + j) & mask] = cin[j];
-    }
+    // 2. the tick's samples into the rings: what the jitter buffer accepted of the far end, all of the near end.  Four
+    //    samples (8 bytes) per lane where everything is 8-byte aligned -- the caller's rows, and ring positions that are
+    //    multiples of 4 (near positions always are: ticks are 80 or 160 samples; far positions unless a saturated jitter
+    //    buffer accepted an odd count; rings are a multiple of 4 long, so a group never straddles the wrap) -- else one
+    //    sample per lane.
+    typedef short Quad __attribute__((ext_vector_type(4)));
+    const bool rows_aligned = ((reinterpret_cast<uintptr_t>(io.far_in) | reinterpret_cast<uintptr_t>(io.near_in) |
+                                reinterpret_cast<uintptr_t>(io.out) | (kHasClean ? reinterpret_cast<uintptr_t>(io.clean_in) : 0) |
+                                (uintptr_t)(io.io_stride * 2)) & 7) == 0;
+    const bool far_aligned = ((p.far[0].pos | p.far[0].count | p.far[1].pos | p.far[1].count) & 3) == 0;
+    const auto append = [&]() {
+        if (rows_aligned && far_aligned) {
+            if (lane < n / 4) {
+                const int j = 4 * lane;
+                for (int c = 0; c < 2; ++c)
+                    if (j >= p.far[c].src && j < p.far[c].src + p.far[c].count)
+                        *reinterpret_cast<Quad *>(fr + ((p.far[c].pos + (unsigned)(j - p.far[c].src)) & mask)) = *reinterpret_cast<const Quad *>(fin + j);
+                *reinterpret_cast<Quad *>(nr + (((unsigned)io.near_pos + j) & mask)) = *reinterpret_cast<const Quad *>(nin + j);
+                if (kHasClean) *reinterpret_cast<Quad *>(cr + (((unsigned)io.near_pos + j) & mask)) = *reinterpret_cast<const Quad *>(cin + j);
+            }
+        } else {
+            for (int j = lane; j < n; j += 64) {
+                for (int c = 0; c < 2; ++c)
+                    if (j >= p.far[c].src && j < p.far[c].src + p.far[c].count) fr[(p.far[c].pos + (unsigned)(j - p.far[c].src)) & mask] = fin[j];
+                nr[((unsigned)io.near_pos + j) & mask] = nin[j];
+                if (kHasClean) cr[((unsigned)io.near_pos + j) & mask] = cin[j];
+            }
+        }
+    };
     // 3. the far end of the tick's blocks.  Usually (p.direct) it is one run of the far stream and the blocks fetch it from
     //    the far ring itself.  Otherwise (an underrun replay, a jump of the jitter buffer's read pointer, the first tick
     //    after start-up) the frames are laid out in the framed-far ring first.
@@ -327,18 +354,32 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
     // 4. the blocks (the fence between the stores above and the blocks' fetches is TickFlowBlockIo::ready)
     const int nb = p.n_blocks;
     if (nb > 0) {
-        TickFlowBlockIo<kHasClean> bio{p.direct ? fr : ff, nr, cr, orow, p.direct ? mask : kFlowFarFrameRing - 1, mask,
-                                       p.direct ? p.blk_pos0 + p.far_delta : p.blk_pos0, p.near_base + p.blk_pos0, p.blk_pos0};
-        TickFlowBlockIo<kHasClean>::E::run_stream_io(st, bio, s, nb);
+        using Io = TickFlowBlockIo<kHasClean, decltype(append)>;
+        Io bio{p.direct ? fr : ff, nr, cr, orow, p.direct ? mask : kFlowFarFrameRing - 1, mask,
+               p.direct ? p.blk_pos0 + p.far_delta : p.blk_pos0, p.near_base + p.blk_pos0, p.blk_pos0, append};
+        Io::E::run_stream_io(st, bio, s, nb);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    } else {
+        append();                    // a session still in its start-up phase: no blocks, but its rings take the samples
     }
     // 5. the output frames: block outputs (this tick's or, when stuffing, older ones) or the start-up copy of the
     //    (clean) near end (echo_control_mobile.cc:285-291)
+    //    Output positions are multiples of 16 (blocks of 64, frames of 80, stuffing by 16): both frames as groups of four
+    //    samples, 20 lanes each, when the caller's rows are aligned.
     const int16_t *pass = kHasClean ? cin : nin;
-    for (int f = 0; f < 2; ++f) {
-        if (f >= p.n_frames) continue;
-        for (int j = lane; j < kFlowFrame; j += 64)
-            out[f * kFlowFrame + j] = p.frame[f].active ? orow[(p.frame[f].out_pos + j) & mask] : pass[f * kFlowFrame + j];
+    if (rows_aligned && ((p.frame[0].out_pos | p.frame[1].out_pos) & 3) == 0) {
+        const int f = lane >= kFlowFrame / 4 ? 1 : 0, j = 4 * (lane - f * (kFlowFrame / 4));
+        if (lane < p.n_frames * (kFlowFrame / 4)) {
+            const Quad from_ring = *reinterpret_cast<const Quad *>(orow + ((p.frame[f].out_pos + j) & mask));
+            const Quad from_input = *reinterpret_cast<const Quad *>(pass + f * kFlowFrame + j);
+            *reinterpret_cast<Quad *>(out + f * kFlowFrame + j) = p.frame[f].active ? from_ring : from_input;
+        }
+    } else {
+        for (int f = 0; f < 2; ++f) {
+            if (f >= p.n_frames) continue;
+            for (int j = lane; j < kFlowFrame; j += 64)
+                out[f * kFlowFrame + j] = p.frame[f].active ? orow[(p.frame[f].out_pos + j) & mask] : pass[f * kFlowFrame + j];
+        }
     }
 }
 
