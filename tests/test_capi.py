@@ -81,6 +81,18 @@ def test_block_kernel_register_budget(tmp_path):
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = len(re.findall(r"^\s*scratch_(load|store)", body, re.M))
         assert vgprs <= 72 and scratch == 0, (has_clean, vgprs, scratch)
+    # The tick kernel: the engine's 64 scalar state words must arrive through scalar loads.  A conditional fence, or a
+    # store wider than the rings' int16 (vector types alias everything), ahead of load_state silently turns them into
+    # vector loads + v_readfirstlane (profiles/r02_experiments.md).  The only 16-byte vector loads it may contain are the
+    # three of the LDS table fill.
+    for has_clean in ("0", "1"):
+        m = re.search(r"^_ZN4aecm21aecm_tick_flow_kernelILb%sEEE\w*:.*\n" % has_clean, text, re.M)
+        assert m, "tick kernel not found in the device assembly"
+        body = text[m.end():]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        wide_loads = len(re.findall(r"^\s*global_load_dwordx4", body, re.M))
+        scalar_x16 = len(re.findall(r"^\s*s_load_dwordx16", body, re.M))
+        assert wide_loads <= 3 and scalar_x16 >= 4, (has_clean, wide_loads, scalar_x16)
 
 
 def test_forwarder_header_and_unmodified_reference_caller_links():
