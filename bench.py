@@ -127,6 +127,45 @@ def cpu_baseline(fs, pairs, budget_s=12.0):
     }
 
 
+def verify_timed_workload(batch, far, near, clean, out, S, T, passes, fs, fixed_delay):
+    """Parity of the timed workload itself (outside the timed region): streams 0..15, S/2 and S-1 of this rank's own
+    batch are pushed through the CPU checker -- the unmodified reference (oracle/_ref, WebRtcAecm_ProcessBlock,
+    aecm_core_c.cc:368-711) when its prebuilt library travelled with the tree, our restatement otherwise -- for every
+    block the GPU processed (warm-up + timed passes over the T-block input), and the checker's output of the LAST pass
+    and its 24-word state digest must equal the GPU's `out` rows and WebRtcAecmBatch_GetDigest bit for bit."""
+    from oracle import pyoracle
+    use_ref = pyoracle.have_reference()
+    picks = sorted(set(list(range(min(16, S))) + [S // 2, S - 1]))
+    host = [(far[i].cpu().numpy(), near[i].cpu().numpy(), None if clean is None else clean[i].cpu().numpy(),
+             out[i].cpu().numpy()) for i in picks]
+    gpu_digest = [batch.digest(i) for i in picks]
+
+    def one(k):
+        f, d, c, got = host[k]
+        chk = pyoracle.RefCoreStream(fs, 1, 1) if use_ref else pyoracle.OracleStream(fs, 1, 1)
+        if fixed_delay >= 0:
+            chk.control(fixed_delay, 1)
+        exp = None
+        for _ in range(passes):
+            if c is None:
+                exp = chk.process(f, d)
+            else:
+                exp = np.concatenate([chk.process_block_clean(f[b * 64:(b + 1) * 64], d[b * 64:(b + 1) * 64], c[b * 64:(b + 1) * 64])
+                                      for b in range(T)])
+        bad_out = int(np.count_nonzero(exp != got))
+        dig_ok = bool(np.array_equal(chk.digest(), gpu_digest[k]))
+        return bad_out, dig_ok
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, min(len(picks), usable_cores()))) as ex:
+        res = list(ex.map(one, range(len(picks))))
+    bad = [picks[k] for k, (b, dg) in enumerate(res) if b or not dg]
+    return {"streams": picks, "blocks": passes * T, "blocks_compared_sample_by_sample": T,
+            "checker": "reference" if use_ref else "port", "ok": not bad, "mismatching_streams": bad,
+            "state_digest_compared": True, "seconds": time.perf_counter() - t0,
+            "what": f"{len(picks)} streams of the timed batch x all {passes} passes ({passes * T} blocks each) re-run on the CPU "
+                    f"checker; last pass's output rows and the final state digest compared bit for bit"}
+
+
 def workload_name(S, T, fs, world, clean):
     """Which BASELINE.json configuration this run is (by streams per GPU, rate and GPU count)."""
     if clean:
@@ -195,6 +234,7 @@ def main():
     ap.add_argument("--fs", type=int, default=16000)
     ap.add_argument("--variant", choices=["fast", "safe"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the CPU re-run of the timed workload (A/B timing loops only)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the counter gather (nccl = RCCL)")
     ap.add_argument("--share-devices", action="store_true",
                     help="map rank r to HIP device r %% device_count (exercises the N-rank path on a box with fewer GPUs; "
@@ -206,6 +246,11 @@ def main():
 
     from webrtc_aecm_amd import dist as adist
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus and not args.share_devices:      # one clear line, before any rendezvous
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} HIP device(s) visible on this node "
+                             f"(--share-devices maps ranks onto the devices present)")
         adist.self_launch(str(Path(__file__).resolve()), sys.argv[1:], args.gpus)      # does not return
 
     import torch
@@ -214,18 +259,21 @@ def main():
 
     if args.share_devices:
         args.dist_backend = "gloo"
-    rank, local_rank, world = adist.init(args.dist_backend)
+    # everything that can be wrong with the launch is checked BEFORE the rendezvous, so a bad launch dies in seconds with
+    # one line per rank instead of hanging in the process-group set-up
+    rank, local_rank, world = adist.env_rank_world()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the AECM hot path has no CPU implementation in the product")
     n_dev = torch.cuda.device_count()
     if args.share_devices:
         local_rank %= n_dev
     elif local_rank >= n_dev:
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} HIP device(s) visible "
+        raise SystemExit(f"bench.py: rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} HIP device(s) visible "
                          f"(--share-devices maps ranks onto the devices present)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)       # before init_process_group: RCCL binds the communicator to the current device
+    adist.init(args.dist_backend, local_rank)
     device = torch.device("cuda", local_rank)
 
     S, T, K, W = args.streams, args.blocks, args.steps, args.warmup
@@ -263,7 +311,13 @@ def main():
     kernel_ms_total, launches = batch.timers()      # HIP events recorded by the library around every launch, on its stream
     assert launches == K, (launches, K)
 
-    c = adist.gather_counters(S * T * K, wall, kernel_ms_total, device if args.dist_backend == "nccl" else torch.device("cpu"))
+    cdev = device if args.dist_backend == "nccl" else torch.device("cpu")
+    dev_name = "%s (%d CUs, hip device %d)" % (aecm.device_info(local_rank)[0], aecm.device_info(local_rank)[1], local_rank)
+    c = adist.gather_counters(S * T * K, wall, kernel_ms_total, cdev, dev_name)
+    parity = None
+    if not args.no_parity:                  # every rank checks streams of its own shard; rank 0 reports, all must agree
+        parity = verify_timed_workload(batch, far, near, clean, out, S, T, W + K, args.fs, args.fixed_delay)
+        parity["ranks_ok"] = adist.all_ok(parity["ok"], cdev)
     if rank == 0:
         value = c["frames"] / c["seconds"]
         kern_avg_s = kernel_ms_total / launches / 1e3
@@ -288,6 +342,7 @@ def main():
             "device": dict(zip(("name", "compute_units", "clock_khz"), aecm.device_info(local_rank))),
             "ranks": {"world_size": world, "ranks_seen": c["ranks_seen"], "collective_backend": c["backend"],
                       "devices_visible_to_rank0": n_dev, "share_devices": bool(args.share_devices),
+                      "per_rank_streams": [p[0] // (T * K) for p in c["per_rank"]], "per_rank_device": c["names"],
                       "per_rank_frames_per_s": [p[0] / p[1] for p in c["per_rank"]],
                       "per_rank_kernel_ms_per_step": [p[2] / K for p in c["per_rank"]]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -299,6 +354,8 @@ def main():
                                  "see issue_bound for the binding resource",
                          "issue_bound": issue},
         }
+        if parity is not None:
+            res["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             n_pairs = min(usable_cores(), S, 32)
             pairs = [(far[i].cpu().numpy(), near[i].cpu().numpy()) for i in range(n_pairs)]
@@ -313,6 +370,9 @@ def main():
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
+    if parity is not None and not (parity["ok"] and parity["ranks_ok"] == world):
+        raise SystemExit(f"rank {rank}: the timed workload is NOT bit-exact vs the {parity['checker']} "
+                         f"(streams {parity['mismatching_streams']}; ranks ok {parity['ranks_ok']}/{world})")
 
 
 if __name__ == "__main__":

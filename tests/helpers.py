@@ -25,10 +25,14 @@ def oracle_run(seed, n_blocks, fs, cng, echo_mode, profile=None, chunks=None):
     return out, o.digest()
 
 
-def oracle_batch(seeds, n_blocks, fs, configs, workers=None):
-    """Oracle over many streams in parallel threads (ctypes releases the GIL)."""
+def oracle_batch(seeds, n_blocks, fs, configs, workers=None, pairs=None):
+    """Oracle over many streams in parallel threads (ctypes releases the GIL).  pairs = (far, near) [len(seeds), L]
+    arrays already synthesised from these seeds (saves synthesising them a second time)."""
     def one(i):
         cng, em = configs[i]
+        if pairs is not None:
+            o = pyoracle.OracleStream(fs, cng, em)
+            return o.process(pairs[0][i], pairs[1][i]), o.digest()
         return oracle_run(seeds[i], n_blocks, fs, cng, em)
     with ThreadPoolExecutor(max_workers=workers) as ex:
         res = list(ex.map(one, range(len(seeds))))

@@ -65,7 +65,7 @@ def test_two_rank_gloo_sharded_run_matches_single_process(tmp_path):
 def test_bench_self_launches_its_ranks(tmp_path):
     """`python bench.py --gpus 2` without WORLD_SIZE re-executes itself under torch.distributed.run with two ranks
     (the driver's command shape for N = 1 must also work for N > 1).  Without a GPU both ranks get as far as the
-    device check -- after the process group of 2 has formed -- and say so."""
+    device check (made before the rendezvous, so a bad launch dies in seconds) and say so."""
     import torch
     if torch.cuda.is_available():
         import pytest
@@ -77,3 +77,18 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert r.returncode != 0
     assert out.count("bench.py needs a GPU") >= 2, out[-3000:]          # both ranks ran main() under WORLD_SIZE=2
     assert "WORLD_SIZE=1" not in out
+
+
+def test_bench_refuses_more_ranks_than_devices_with_one_line():
+    """`python bench.py --gpus 2` on a node with fewer HIP devices: one clear line, no rendezvous, no ranks started."""
+    import time
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two devices present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and out.count("HIP device(s) visible on this node") == 1, out[-2000:]
+    assert "torch.distributed" not in out and time.perf_counter() - t0 < 30

@@ -85,6 +85,56 @@ def test_bench_self_launch_two_ranks_share_one_gpu():
     assert len(d["ranks"]["per_rank_frames_per_s"]) == 2 and all(v > 1e6 for v in d["ranks"]["per_rank_frames_per_s"])
     assert d["config"]["streams_per_gpu"] == 4096 and "configs[1]" in d["config"]["workload"]
     assert d["value"] > 0 and d["roofline"]["kernel_avg_ms"] > 0
+    assert d["ranks"]["per_rank_streams"] == [4096, 4096] and len(d["ranks"]["per_rank_device"]) == 2
+    assert d["parity"]["ok"] is True and d["parity"]["ranks_ok"] == 2 and d["parity"]["streams"][-1] == 4095
+
+
+def _bench_json(argv, env=None, timeout=900):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], env=env or _clean_env(), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_counter_collectives_over_rccl():
+    """The RCCL code path of `bench.py --gpus N` on the one GPU present: AECM_FORCE_DIST=1 forms a one-rank process group
+    with backend nccl (= RCCL) bound to the device, the barrier runs on the device, the counters, the device names and
+    the parity flag travel as device tensors through all-reduce / all-gather -- exactly the calls the 8-GPU run makes."""
+    env = dict(_clean_env(), AECM_FORCE_DIST="1", MASTER_PORT="29641")
+    d = _bench_json(["--gpus", "1", "--dist-backend", "nccl", "--streams", "4096", "--blocks", "64", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline"], env=env)
+    assert d["ranks"]["collective_backend"] == "nccl" and d["ranks"]["ranks_seen"] == 1 and d["n_gpus"] == 1
+    assert len(d["ranks"]["per_rank_device"]) == 1 and "gfx950" in d["ranks"]["per_rank_device"][0]
+    assert d["parity"]["ok"] is True and d["parity"]["ranks_ok"] == 1 and d["parity"]["blocks"] == 4 * 64
+    assert d["value"] > 1e6
+
+
+def test_bench_strong_scaling_shards_sum_to_the_total():
+    """--total-streams splits a fixed total over the ranks (strong scaling): two ranks sharing the GPU own 4096 + 4095 of
+    8191 streams, the frames counted are total x blocks x steps, and every rank's timed workload passes its own parity check."""
+    d = _bench_json(["--gpus", "2", "--share-devices", "--total-streams", "8191", "--blocks", "64", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline"])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["ranks"]["ranks_seen"] == 2
+    assert d["ranks"]["per_rank_streams"] == [4096, 4095] and sum(d["ranks"]["per_rank_streams"]) == 8191
+    assert abs(d["value"] * d["config"]["timed_region_s"] - 8191 * 64 * 3) < 1.0
+    assert d["parity"]["ok"] is True and d["parity"]["ranks_ok"] == 2
+
+
+def test_bench_refuses_more_ranks_than_devices_quickly():
+    """`bench.py --gpus 4` on a box with fewer devices must die with ONE clear line before any rendezvous."""
+    import time
+    import torch
+    n = torch.cuda.device_count()
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n + 3)], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    dt = time.perf_counter() - t0
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and out.count(f"only {n} HIP device(s) visible") == 1, out[-2000:]
+    assert dt < 60, dt                       # interpreter + `import torch` only (the 5 s goal is the check itself, not the import)
+    # the same launch shape as the driver's (ranks started by torch.distributed.run): every rank refuses before init_process_group
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n + 1), "--master-addr", "127.0.0.1",
+                        "--master-port", "29643", str(ROOT / "bench.py"), "--gpus", str(n + 1)], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and f"LOCAL_RANK {n} but only {n} HIP device(s) visible" in out, out[-2000:]
 
 
 def test_reference_main_cc_unmodified_on_the_gpu(tmp_path):
