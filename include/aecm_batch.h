@@ -76,10 +76,15 @@ int32_t WebRtcAecmBatch_ProcessRecordingsHost(AecmBatch *b, const int16_t *far_h
                                               int32_t samples_per_call, int32_t num_calls, int16_t msInSndCardBuf);
 int32_t WebRtcAecmBatch_Synchronize(AecmBatch *b);
 
-/* Duration of the most recent ProcessBlocks kernel, from HIP events recorded around the launch on
- * the engine's own stream (waits for it to finish). */
+/* Duration of the most recent timed ProcessBlocks kernel, from HIP events recorded around the launch on
+ * the engine's own stream (waits for it to finish).
+ * Timed: every launch made by WebRtcAecmBatch_ProcessBlocks and by the staged form of ProcessBlocksHost /
+ * ProcessRecordings*.  NOT timed (latency paths that would pay for the event pair): host calls of at most 64 KiB of
+ * audio, which run the kernel directly on a pinned mapped buffer (the whole single-session WebRtcAecm_* ABI; switch
+ * off with AECM_HOST_MAPPED=0), and the session ticks (WebRtcAecmSessions_Tick*).  For those, GetTimers / GetLastLaunchMs
+ * keep reporting the last timed launch. */
 int32_t WebRtcAecmBatch_GetLastLaunchMs(AecmBatch *b, float *ms);
-/* Sum of the kernel durations since the last call to WebRtcAecmBatch_ResetTimers and their count. */
+/* Sum of the timed kernel durations (see above) since the last call to WebRtcAecmBatch_ResetTimers and their count. */
 int32_t WebRtcAecmBatch_GetTimers(AecmBatch *b, double *total_ms, int64_t *launches);
 int32_t WebRtcAecmBatch_ResetTimers(AecmBatch *b);
 

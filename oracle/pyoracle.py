@@ -45,7 +45,14 @@ def build(force: bool = False) -> None:
     product = HERE.parent / "webrtc_aecm_amd" / "_lib" / "libaecm_mi355x.so"
     if Path("/root/reference/main.cc").is_file() and product.exists() and (
             force or not REFMAIN.exists() or REFMAIN.stat().st_mtime < product.stat().st_mtime):
-        subprocess.check_call(["make", "-C", str(HERE), "refmain"], stdout=subprocess.DEVNULL)
+        # best effort: only the one test that runs the reference's main.cc needs it (it skips without the binary); a
+        # link problem here must not fail the pure-oracle tests
+        r = subprocess.run(["make", "-C", str(HERE), "refmain"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            import sys
+            print(f"pyoracle: building oracle/_ref/aecm_run_refmain failed (test infrastructure only):\n{r.stderr[-800:]}", file=sys.stderr)
+            if REFMAIN.exists() and REFMAIN.stat().st_mtime < product.stat().st_mtime:
+                REFMAIN.unlink()                  # never leave a binary linked against an older library interface
 
 
 def have_reference() -> bool:

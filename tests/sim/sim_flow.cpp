@@ -133,6 +133,10 @@ int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t
                 if (ph >= 138 && ph < 160) flags |= kFlowNoFarend;
                 break;
             }
+            case 11:                                                            // 16 kHz in 80-sample calls for more than 32 767 calls: the
+                n = tick < 33100 ? 80 : 160;                                    // wrapper's short counters wrap while nBlocks10ms == 0, then
+                ms = 40 + (int)(tick % 3);                                      // 160-sample calls compare them as size_t (:320,:330)
+                break;
             default: n = rng.chance(20) ? 80 : 160; ms = rng.range(0, 200); flags = rng.range(0, 3); break;
         }
         if (n != 160) flags &= ~kFlowSplitCalls;

@@ -127,6 +127,11 @@ inline VecI shl_add(const VecI &a, int n, const VecI &c) {
         return r;                                                             \
     }                                                                         \
     inline VecI NAME(const VecI &a, const VecI &k, int c) { return NAME(a, k, VecI(c)); }
+inline VecI dot2_i16_uc(const VecI &a, const VecI &b, int c) {
+    VecI r;
+    for (int i = 0; i < 64; ++i) r.v[i] = dot2_i16_uc(a.v[i], b.v[i], c);
+    return r;
+}
 SIM_MAD16(mad16_lo)
 SIM_MAD16(mad16_hi)
 SIM_MAD16(mad16_lo_uc)
@@ -159,9 +164,11 @@ struct SimWave {
     using vb = VecB;
     static constexpr bool kPrecomputedConstants = false;   // the simulator evaluates the definitions
     static constexpr bool kLaneConstsInTable = false;
+    static constexpr bool kTight = false;
     template <int ROW> static vi table_lane_const(const vi &) { return vi(0); }   // never used (kLaneConstsInTable == false)
     static vi table_index_for_this_block() { return vi(0); }
     static void begin_block(int, int) {}
+    template <int PHASE> static void phase_priority() {}
     static int pin_uniform(int x) { return x; }                            // device: a uniform value pinned to a scalar register
     static int per_block(int x) { return x; }                              // device: keeps launch-invariant conditions in the loop                                   // device: issue-priority rotation
 
@@ -242,6 +249,9 @@ struct SimWave {
         a = na;
         b = nb;
     }
+    template <int Q, int N>
+    static void exchange_all(vi (&aa)[N], vi (&bb)[N]) { for (int n = 0; n < N; ++n) exchange<Q>(aa[n], bb[n]); }
+    static vi divu_u32_u16(const vi &n, const vi &d) { return divu(n, d); }    // device: two float steps (wave_gfx950.h)
     static int reduce_max(const vi &v) { int m = v.v[0]; for (int i = 1; i < 64; ++i) m = v.v[i] > m ? v.v[i] : m; return m; }
     static int reduce_min(const vi &v) { int m = v.v[0]; for (int i = 1; i < 64; ++i) m = v.v[i] < m ? v.v[i] : m; return m; }
     static int reduce_add(const vi &v) { int s = 0; for (int i = 0; i < 64; ++i) s = add(s, v.v[i]); return s; }

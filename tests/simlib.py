@@ -3,6 +3,7 @@ DSP (webrtc_aecm_amd/csrc/aecm_wave.h) instantiated on a 64-lane CPU simulator (
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -10,7 +11,11 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "webrtc_aecm_amd" / "csrc"
-SIM_SO = ROOT / "tests" / "_build" / "libaecm_sim.so"
+# AECM_SIM_SANITIZE=1: the same sources built with AddressSanitizer + UndefinedBehaviorSanitizer into their own library
+# (tests/test_sanitizers.py runs part of the CPU suite on it in a child process with the sanitizer runtimes preloaded)
+SANITIZE = os.environ.get("AECM_SIM_SANITIZE") == "1"
+SIM_SO = ROOT / "tests" / "_build" / ("libaecm_sim_san.so" if SANITIZE else "libaecm_sim.so")
+SAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
 _SOURCES = [ROOT / "tests" / "sim" / "sim_lib.cpp", ROOT / "tests" / "sim" / "sim_engine.cpp", ROOT / "tests" / "sim" / "sim_flow.cpp",
             CSRC / "aecm_host_state.cpp", CSRC / "aecm_session.cpp", CSRC / "aecm_schedule.cpp"]
 _DEPS = _SOURCES + [ROOT / "tests" / "sim" / "wave_sim.h", CSRC / "aecm_wave.h", CSRC / "aecm_ops.h",
@@ -25,7 +30,7 @@ def build():
     if SIM_SO.exists() and all(SIM_SO.stat().st_mtime >= d.stat().st_mtime for d in _DEPS):
         return
     SIM_SO.parent.mkdir(parents=True, exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fwrapv", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+    subprocess.check_call(["g++", *(SAN_FLAGS if SANITIZE else ["-O2"]), "-std=c++17", "-fwrapv", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
                            "-I/opt/rocm/include", f"-I{CSRC}",
                            f"-I{ROOT / 'tests' / 'sim'}", *map(str, _SOURCES), "-o", str(SIM_SO)])
 

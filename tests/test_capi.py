@@ -73,14 +73,14 @@ def test_block_kernel_register_budget(tmp_path):
     subprocess.check_call([build._hipcc(), *flags, "-S", "--cuda-device-only", f"-I{build.CSRC}", str(build.CSRC / "aecm_kernels.hip"),
                            "-o", str(out)], stderr=subprocess.DEVNULL)
     text = out.read_text()
-    for has_clean in ("0", "1"):
-        m = re.search(r"^_ZN4aecm19aecm_process_kernelILb1ELb%sEEE\w*:.*\n" % has_clean, text, re.M)
+    for has_clean, phase_prio in (("0", "1"), ("1", "1"), ("0", "0"), ("1", "0")):     # <fast, clean, issue priority by phase>
+        m = re.search(r"^_ZN4aecm19aecm_process_kernelILb1ELb%sELb%sEEE\w*:.*\n" % (has_clean, phase_prio), text, re.M)
         assert m, "fast block kernel not found in the device assembly"
         body = text[m.end():]
         body = body[:body.index(".end_amdhsa_kernel")]
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = len(re.findall(r"^\s*scratch_(load|store)", body, re.M))
-        assert vgprs <= 72 and scratch == 0, (has_clean, vgprs, scratch)
+        assert vgprs <= 72 and scratch == 0, (has_clean, phase_prio, vgprs, scratch)
     # The tick kernel: the engine's 64 scalar state words must arrive through scalar loads.  A conditional fence, or a
     # store wider than the rings' int16 (vector types alias everything), ahead of load_state silently turns them into
     # vector loads + v_readfirstlane (profiles/r02_experiments.md).  The only 16-byte vector loads it may contain are the
@@ -119,7 +119,7 @@ def test_isa_census_of_the_built_library():
     MFMA and no scratch, and its static mix is the integer VALU + scalar mix DESIGN.md describes."""
     from webrtc_aecm_amd import build, isa_census
     c = isa_census.census(build.build())
-    assert "aecm_process_kernelILb1ELb0" in c["kernel"] and len(c["fingerprint"]) == 16
+    assert "aecm_process_kernelILb1ELb0ELb1" in c["kernel"] and len(c["fingerprint"]) == 16
     assert c["counts"]["VALU"] > 800 and c["counts"]["SALU"] > 300
     assert not any(op.startswith(("v_mfma", "scratch_")) for op in c["opcodes"])
     assert c["opcodes"].get("v_dot2c_i32_i16_e32", 0) + c["opcodes"].get("v_dot2_i32_i16", 0) >= 60

@@ -1089,3 +1089,155 @@ def test_mixed_call_cadence_in_one_session_batch():
     rc, _, _ = sb.tick_host_per_session(z, z, np.array([40, 40], np.int16), flags=np.array([aecm.ffi.SESSION_SPLIT_CALLS, 0], np.uint8))
     assert rc == aecm.ffi.AECM_BAD_PARAMETER_ERROR                  # two 80-sample calls need a 160-sample tick
     sb.close()
+
+
+def test_state_snapshot_value_ranges_are_validated():
+    """ImportState also refuses values outside the ranges the kernel's arithmetic shortcuts rely on (as_nonneg(supGain),
+    int16 members whose narrowing casts are dropped as the identity, Q domains used as shift counts, counters): a blob
+    no run of the algorithm can produce must not be run on (aecm_host_state.cpp: ValidateStateImage)."""
+    import struct
+    fs = 16000
+    far, near = synth_streams([9], 300, fs)
+    b = aecm.AecmBatch(1, fs)
+    b.process_host(far, near)
+    blob = b.export_state(0)
+    lib = aecm.load()
+    dig = b.digest(0)
+    scal0 = 32 + 12 * 64 * 4
+    S = {"SUPGAIN": 21, "SUPGAIN_OLD": 22, "FARLOG": 8, "FE_MIN": 9, "CURVAD": 14, "SEED": 1, "NLP": 31, "SG_A": 33,
+         "B64_NEARFILT": 41, "B64_NOISE": 42, "B64_LOWCTR": 43, "MIN_PROB": 26, "FIXED_DELAY": 32}
+
+    def imp(x):
+        return lib.WebRtcAecmBatch_ImportState(b.h, 0, bytes(x), len(x))
+    assert imp(blob) == 0
+    for name, value in (("SUPGAIN", -1), ("SUPGAIN", 40000), ("SUPGAIN_OLD", 70000), ("FARLOG", 32768), ("FE_MIN", -32769),
+                        ("CURVAD", 2), ("SEED", -5), ("NLP", 1 << 20), ("SG_A", -40000), ("B64_NEARFILT", 65536),
+                        ("B64_NOISE", -1), ("B64_LOWCTR", 9), ("MIN_PROB", -1), ("FIXED_DELAY", -40000)):
+        bad = bytearray(blob)
+        struct.pack_into("<i", bad, scal0 + 4 * S[name], value)
+        assert imp(bad) == aecm.ffi.AECM_BAD_PARAMETER_ERROR, (name, value)
+    # lane-vector words: a far-spectrum Q domain of 20 (5-bit field of the nearFilt word), a negative noise estimate
+    v_nearfilt, v_noise = 32 + 5 * 64 * 4, 32 + 6 * 64 * 4
+    bad = bytearray(blob)
+    w, = struct.unpack_from("<I", bad, v_nearfilt + 4 * 7)
+    struct.pack_into("<I", bad, v_nearfilt + 4 * 7, (w & ~(31 << 22)) | (20 << 22))
+    assert imp(bad) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    bad = bytearray(blob)
+    struct.pack_into("<i", bad, v_noise + 4 * 63, -7)
+    assert imp(bad) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert np.array_equal(b.digest(0), dig)
+    # Control narrows its arguments to int16 like the reference: anything outside [-32768, 100) is refused, not wrapped
+    assert lib.WebRtcAecmBatch_Control(b.h, -65436, 1, 0, -1) == aecm.ffi.AECM_BAD_PARAMETER_ERROR     # would wrap to +100
+    assert lib.WebRtcAecmBatch_Control(b.h, 99, 1 << 17, 0, -1) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert lib.WebRtcAecmBatch_Control(b.h, -1, 1, 0, -1) == 0
+
+
+@_needs_ref
+def test_process_in_place_out_aliases_the_near_end():
+    """The reference lets `out` alias nearendNoisy or nearendClean (echo_control_mobile.cc:285-291 copies only when they
+    differ; its own main.cc processes in place through a copy).  WebRtcAecm_Process with out == nearendNoisy and with
+    out == nearendClean, during start-up and in the steady state, 80- and 160-sample calls, both rates, against the
+    reference driven in exactly the same aliased way."""
+    lib, ref = aecm.load(), pyoracle.ref_lib()
+    for k, (fs, frame, alias) in enumerate(((16000, 160, "noisy"), (16000, 80, "noisy"), (8000, 80, "clean"), (16000, 160, "clean"),
+                                            (8000, 160, "noisy"))):
+        far, near = synth_pair(2300 + k, 3 * fs // 64, fs, "mixed")
+        clean = synth_clean(near)
+        n_calls = far.size // frame
+        ms_seq, far_present = call_pattern(70 + k, n_calls)
+        r = pyoracle.RefSession(fs, 1, 3)
+        s = aecm.Aecm()
+        assert s.init(fs) == 0 and s.set_config(1, 3) == 0
+        for i in range(n_calls):
+            sl = slice(i * frame, (i + 1) * frame)
+            if far_present[i]:
+                f = np.ascontiguousarray(far[sl])
+                assert lib.WebRtcAecm_BufferFarend(s.h, f.ctypes.data, frame) == ref.WebRtcAecm_BufferFarend(r.h, f.ctypes.data, frame) == 0
+            bufs = []
+            for handle, l in ((s.h, lib), (r.h, ref)):
+                noisy, cl = near[sl].copy(), clean[sl].copy()
+                if alias == "noisy":          # out == nearendNoisy, no clean input
+                    rc = l.WebRtcAecm_Process(handle, noisy.ctypes.data, None, noisy.ctypes.data, frame, int(ms_seq[i]))
+                    bufs.append((rc, noisy, cl))
+                else:                         # out == nearendClean
+                    rc = l.WebRtcAecm_Process(handle, noisy.ctypes.data, cl.ctypes.data, cl.ctypes.data, frame, int(ms_seq[i]))
+                    bufs.append((rc, cl, noisy))
+            (rc_g, out_g, other_g), (rc_r, out_r, other_r) = bufs
+            assert rc_g == rc_r, (fs, frame, alias, i)
+            assert np.array_equal(out_g, out_r), (fs, frame, alias, i)
+            assert np.array_equal(other_g, other_r), "the non-aliased input must be left alone"
+        s.close()
+
+
+@_needs_ref
+def test_independent_instances_driven_from_their_own_threads():
+    """The reference's threading contract: distinct instances share nothing and may be driven from different
+    threads.  Eight host threads each own one WebRtcAecm_* session, two more each own one AecmBatch (4 streams) on the
+    same device; every thread's results must equal the reference's for its own inputs."""
+    import threading
+    fs, frame = 16000, 160
+    n_sess, n_calls = 8, 150
+    results, errors = {}, []
+
+    def session_worker(t):
+        try:
+            far, near = synth_pair(3100 + t, n_calls * frame // 64 + 1, fs, "mixed")
+            ms_seq, far_present = call_pattern(300 + t, n_calls)
+            s = aecm.Aecm()
+            assert s.init(fs) == 0 and s.set_config(1, t % 5) == 0
+            results[("s", t)] = drive_session(s, far, near, frame, ms_seq, far_present)
+            s.close()
+        except Exception as e:                       # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    def batch_worker(t):
+        try:
+            seeds = [3200 + 10 * t + k for k in range(4)]
+            far, near = synth_streams(seeds, 400, fs)
+            b = aecm.AecmBatch(4, fs, 1, 2)
+            outs = [b.process_host(far[:, c * 6400:(c + 1) * 6400], near[:, c * 6400:(c + 1) * 6400]) for c in range(4)]
+            results[("b", t)] = (np.concatenate(outs, axis=1), [b.digest(k) for k in range(4)])
+            b.close()
+        except Exception as e:                       # noqa: BLE001
+            errors.append((t, repr(e)))
+    threads = [threading.Thread(target=session_worker, args=(t,)) for t in range(n_sess)] + \
+              [threading.Thread(target=batch_worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(600)
+    assert not errors, errors
+    for t in range(n_sess):
+        far, near = synth_pair(3100 + t, n_calls * frame // 64 + 1, fs, "mixed")
+        ms_seq, far_present = call_pattern(300 + t, n_calls)
+        exp, exp_codes = drive_session(pyoracle.RefSession(fs, 1, t % 5), far, near, frame, ms_seq, far_present)
+        got, codes = results[("s", t)]
+        assert np.array_equal(codes, exp_codes) and np.array_equal(got, exp), t
+    for t in range(2):
+        seeds = [3200 + 10 * t + k for k in range(4)]
+        far, near = synth_streams(seeds, 400, fs)
+        out, digs = results[("b", t)]
+        for k in range(4):
+            r = pyoracle.RefCoreStream(fs, 1, 2)
+            assert np.array_equal(out[k], r.process(far[k], near[k])) and np.array_equal(digs[k], r.digest()), (t, k)
+
+
+def test_c_abi_under_ubsan():
+    """The C-ABI tests once more on libaecm_mi355x_ubsan.so: the same gfx950 kernels under host objects (engine, sessions,
+    C API, session flow, schedule, host state) compiled with -fsanitize=undefined -fno-sanitize-recover.  Any
+    report aborts the child process."""
+    import os
+    import subprocess
+    import sys
+    from webrtc_aecm_amd import build
+    assert build.LIB_UBSAN.exists(), "webrtc_aecm_amd/build.py builds it next to the shipped library"
+    env = dict(os.environ, AECM_LIB_PATH=str(build.LIB_UBSAN), UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    sel = ("session_abi or snapshot or echo_path or control or tick_major or ragged or chunked or clean_input or recordings_equal or "
+           "streaming_session_batch or unaligned or per_session_sound or churn or mixed_call or tick_argument or in_place or cli_single")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-p", "no:cacheprovider", "-k", sel],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    log = r.stdout + r.stderr
+    if os.environ.get("AECM_SANITIZER_LOG"):
+        open(os.environ["AECM_SANITIZER_LOG"], "w").write(log)
+    assert r.returncode == 0 and "runtime error" not in log, log[-4000:]
+    assert " passed" in log

@@ -279,6 +279,39 @@ def test_device_session_machinery_equals_the_generic_wrapper_on_sample_tags(fs):
     # buffer and replay frames that had to move to their rows were all exercised
     assert saw_blocks > 100000 and saw_direct > 50000 and saw_framed > 50000 and saw_spills > 50
     assert fs == 8000 or saw_drops > 1000
+    if fs == 16000:     # counters wrapped negative during an endless 80-sample start-up, then compared as size_t (scenario 11)
+        tick, detail = simlib.flow_fuzz(77, fs, 33600, 11, 12345)
+        assert tick == -1 and detail[2] > 300, (tick, detail)
+
+
+def test_wrapped_startup_counters_follow_the_reference():
+    """The reference compares its short start-up counters with a size_t product (echo_control_mobile.cc:320,330).  At 16 kHz
+    with 80-sample calls nBlocks10ms is 0, neither limit can fire, and after 32 768 calls the counters are negative: the
+    first 160-sample call then sees a huge unsigned product and leaves the buffer-size check.  The host session logic
+    (SessionFlow, which the device plan is fuzzed against) must follow the real reference through exactly that."""
+    if not pyoracle.have_reference():
+        pytest.skip("needs oracle/_ref")
+    fs, n80, n160 = 16000, 33000, 60
+    far, near = synth_pair(4242, (n160 * 160) // 64 + 2, fs, "steady")
+    z = np.zeros(80, np.int16)
+    r = pyoracle.RefSession(fs, 1, 3)
+    s = simlib.SimSession()
+    assert s.init(fs) == 0 and s.set_config(1, 3) == 0
+    ob = np.empty(80, dtype=np.int16)
+    for i in range(n80):
+        ms = 40 + i % 3
+        if i % 400 == 0:      # the far end is offered now and then (the jitter buffer saturates either way)
+            assert r.lib.WebRtcAecm_BufferFarend(r.h, z.ctypes.data, 80) == s.buffer_farend(z)
+        rc = r.lib.WebRtcAecm_Process(r.h, z.ctypes.data, None, ob.ctypes.data, 80, ms)
+        rc2, o2 = s.process(z, None, ms)
+        assert rc == rc2 and np.array_equal(ob, o2), i
+    ob = np.empty(160, dtype=np.int16)
+    for i in range(n160):
+        sl = slice(i * 160, (i + 1) * 160)
+        assert r.lib.WebRtcAecm_BufferFarend(r.h, far[sl].ctypes.data, 160) == s.buffer_farend(far[sl])
+        rc = r.lib.WebRtcAecm_Process(r.h, near[sl].ctypes.data, None, ob.ctypes.data, 160, 40)
+        rc2, o2 = s.process(near[sl], None, 40)
+        assert rc == rc2 and np.array_equal(ob, o2), i
 
 
 def test_reciprocal_division_of_the_nlms_step_is_exact():

@@ -40,7 +40,7 @@ def classify(op):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="aecm_process_kernelILb1ELb0EE")
+    ap.add_argument("--kernel", default="aecm_process_kernelILb1ELb0ELb1EE")
     ap.add_argument("--dump")
     ap.add_argument("--extra", default="", help="extra hipcc flags")
     ap.add_argument("--hot", action="store_true",

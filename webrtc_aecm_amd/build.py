@@ -13,6 +13,10 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "_lib"
 LIB = LIB_DIR / "libaecm_mi355x.so"
 LIB_CHECKED = LIB_DIR / "libaecm_mi355x_checked.so"
+# the same kernels under host objects built with UndefinedBehaviorSanitizer (test infrastructure: tests/test_gpu_parity.py
+# runs the C-ABI tests on it; never the default)
+LIB_UBSAN = LIB_DIR / "libaecm_mi355x_ubsan.so"
+UBSAN_FLAGS = ["-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-shared-libsan", "-Wno-option-ignored"]
 CLI = LIB_DIR / "aecm_run"
 SOURCES = ["aecm_kernels.hip", "aecm_engine.cpp", "aecm_session.cpp", "aecm_schedule.cpp", "aecm_sessions.cpp", "aecm_capi.cpp",
            "aecm_host_state.cpp"]
@@ -29,9 +33,9 @@ def _hipcc() -> str:
 
 
 def is_stale() -> bool:
-    if not LIB.exists() or not LIB_CHECKED.exists() or not CLI.exists():
+    if not LIB.exists() or not LIB_CHECKED.exists() or not LIB_UBSAN.exists() or not CLI.exists():
         return True
-    t = min(LIB.stat().st_mtime, LIB_CHECKED.stat().st_mtime)
+    t = min(LIB.stat().st_mtime, LIB_CHECKED.stat().st_mtime, LIB_UBSAN.stat().st_mtime)
     deps = list(CSRC.glob("*")) + list((PKG.parent / "include").rglob("*.h"))
     return any(d.stat().st_mtime > t for d in deps)
 
@@ -97,29 +101,45 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         try:
             if not force and not is_stale():          # another process built it while we waited
                 return LIB
+            for stale in LIB_DIR.glob(".obj.*"):           # left behind by a build that was killed
+                shutil.rmtree(stale, ignore_errors=True)
             obj_dir = LIB_DIR / f".obj.{os.getpid()}"
             obj_dir.mkdir(exist_ok=True)
             hipcc = _hipcc()
             jobs = [(s, obj_dir / (s + ".o"), []) for s in SOURCES]
             jobs.append(("aecm_kernels.hip", obj_dir / "aecm_kernels.checked.o", ["-DAECM_CHECKED"]))
+            jobs += [(s, obj_dir / (s + ".ubsan.o"), UBSAN_FLAGS) for s in SOURCES if s != "aecm_kernels.hip"]
 
             def compile_one(job):
                 src, obj, extra = job
-                cmd = [hipcc, *_compile_flags(), *extra, "-c", str(CSRC / src), "-o", str(obj)]
+                flags = [f for f in _compile_flags() if not (f == "-O3" and "-O1" in extra)]
+                cmd = [hipcc, *flags, *extra, "-c", str(CSRC / src), "-o", str(obj)]
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 subprocess.check_call(cmd, cwd=str(CSRC))
-            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
-                list(ex.map(compile_one, jobs))
-            common = [str(obj_dir / (s + ".o")) for s in SOURCES if s != "aecm_kernels.hip"]
-            for out, kern in ((LIB, obj_dir / "aecm_kernels.hip.o"), (LIB_CHECKED, obj_dir / "aecm_kernels.checked.o")):
-                tmp = LIB_DIR / f".{out.name}.{os.getpid()}.tmp"
-                cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", str(kern), *common, "-o", str(tmp)]
-                if verbose:
-                    print(" ".join(cmd), flush=True)
-                subprocess.check_call(cmd, cwd=str(CSRC))
-                os.replace(tmp, out)
-            shutil.rmtree(obj_dir, ignore_errors=True)
+            try:                                        # the object directory goes away whether or not the build succeeds
+                with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+                    list(ex.map(compile_one, jobs))
+                common = [str(obj_dir / (s + ".o")) for s in SOURCES if s != "aecm_kernels.hip"]
+                common_ubsan = [str(obj_dir / (s + ".ubsan.o")) for s in SOURCES if s != "aecm_kernels.hip"]
+                rt = subprocess.run([str(Path(hipcc).resolve().parent.parent / "lib" / "llvm" / "bin" / "clang"),
+                                     "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], capture_output=True, text=True).stdout.strip()
+                rt_dir = str(Path(rt).parent) if rt and Path(rt).is_absolute() else "/opt/rocm/lib/llvm/lib/clang/22/lib/linux"
+                for out, kern, host, link in ((LIB, obj_dir / "aecm_kernels.hip.o", common, []),
+                                              (LIB_CHECKED, obj_dir / "aecm_kernels.checked.o", common, []),
+                                              (LIB_UBSAN, obj_dir / "aecm_kernels.hip.o", common_ubsan, ["-fsanitize=undefined", "-shared-libsan", f"-Wl,-rpath,{rt_dir}"])):
+                    tmp = LIB_DIR / f".{out.name}.{os.getpid()}.tmp"
+                    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *link, str(kern), *host, "-o", str(tmp)]
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    try:
+                        subprocess.check_call(cmd, cwd=str(CSRC))
+                        os.replace(tmp, out)
+                    finally:
+                        if tmp.exists():
+                            tmp.unlink()
+            finally:
+                shutil.rmtree(obj_dir, ignore_errors=True)
             # the command-line front end (reference main.cc equivalent + multi-file batch mode)
             tmp_cli = LIB_DIR / f".{CLI.name}.{os.getpid()}.tmp"
             cli = ["g++", "-O2", "-std=c++17", str(CSRC / "aecm_cli.cpp"), "-o", str(tmp_cli), f"-L{LIB_DIR}", "-laecm_mi355x",

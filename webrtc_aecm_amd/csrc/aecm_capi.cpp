@@ -111,7 +111,10 @@ int32_t WebRtcAecmBatch_set_config(AecmBatch *b, AecmConfig config, int32_t firs
 int32_t WebRtcAecmBatch_Control(AecmBatch *b, int32_t fixed_delay, int32_t nlp_flag, int32_t first, int32_t count) {
     if (int32_t rc = CheckRange(b, first, &count)) return rc;
     // the reference uses fixedDelay unchecked as a far-history offset (aecm_core.cc:157-172, MAX_DELAY = 100 slots)
-    if (fixed_delay >= aecm::kHistory) return AECM_BAD_PARAMETER_ERROR;
+    // and narrows both arguments to int16_t: validated as the values the core will hold -- anything outside
+    // [-32768, kHistory) is refused (a large negative int32 would otherwise wrap into range or beyond it)
+    if (fixed_delay < -32768 || fixed_delay >= aecm::kHistory) return AECM_BAD_PARAMETER_ERROR;
+    if (nlp_flag < -32768 || nlp_flag > 32767) return AECM_BAD_PARAMETER_ERROR;
     return b->engine->Control(fixed_delay, nlp_flag, first, count) ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 

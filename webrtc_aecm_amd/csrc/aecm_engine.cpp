@@ -228,10 +228,15 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
 }
 
 bool BatchEngine::ProcessBlocksHostMapped(const IoView &io, int num_blocks) {
-    if (!mapped_host_) {
+    if (!mapped_host_) {                          // both pointers are published together, only when both calls succeeded
         void *dev = nullptr;
-        if (!AECM_HIP_OK(hipHostMalloc((void **)&mapped_host_, kMappedBytes, hipHostMallocMapped))) return false;
-        if (!AECM_HIP_OK(hipHostGetDevicePointer(&dev, mapped_host_, 0))) return false;
+        int16_t *host = nullptr;
+        if (!AECM_HIP_OK(hipHostMalloc((void **)&host, kMappedBytes, hipHostMallocMapped))) return false;
+        if (!AECM_HIP_OK(hipHostGetDevicePointer(&dev, host, 0)) || !dev) {
+            (void)hipHostFree(host);
+            return false;
+        }
+        mapped_host_ = host;
         mapped_dev_ = static_cast<int16_t *>(dev);
     }
     const size_t row = (size_t)num_blocks * kBlock, per = (size_t)num_streams_ * row;
@@ -435,13 +440,17 @@ bool BatchEngine::SetEchoPath(int stream, const int16_t path[kBins]) {
     int32_t scal[kNumScal] = {0};
     aecm::SetEchoPath(vec.data(), scal, path);
     uint32_t *dvec = st_.vec + (size_t)stream * kVecWordsPerStream;
-    if (!AECM_HIP_OK(hipMemcpyAsync(dvec + V_CH16 * kLanes, vec.data() + V_CH16 * kLanes, kLanes * sizeof(uint32_t), hipMemcpyHostToDevice, stream_)) ||
-        !AECM_HIP_OK(hipMemcpyAsync(dvec + V_CH32 * kLanes, vec.data() + V_CH32 * kLanes, kLanes * sizeof(uint32_t), hipMemcpyHostToDevice, stream_)))
-        return false;
-    const int32_t fields[7] = {S_B64_CHSTORED, S_B64_CHADAPT16, S_B64_CHADAPT32, S_MSE_ADAPT_OLD, S_MSE_STORED_OLD, S_MSE_THRESH, S_MSECNT};
-    int32_t values[7];
-    for (int i = 0; i < 7; ++i) values[i] = scal[fields[i]];
-    return PatchScalars(fields, values, 7, stream, 1) && AECM_HIP_OK(hipStreamSynchronize(stream_));   // vec goes out of scope
+    // `vec` is a local: whatever happens below, no copy from it may still be in flight when this function returns
+    bool ok = AECM_HIP_OK(hipMemcpyAsync(dvec + V_CH16 * kLanes, vec.data() + V_CH16 * kLanes, kLanes * sizeof(uint32_t), hipMemcpyHostToDevice, stream_)) &&
+              AECM_HIP_OK(hipMemcpyAsync(dvec + V_CH32 * kLanes, vec.data() + V_CH32 * kLanes, kLanes * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    if (ok) {
+        const int32_t fields[7] = {S_B64_CHSTORED, S_B64_CHADAPT16, S_B64_CHADAPT32, S_MSE_ADAPT_OLD, S_MSE_STORED_OLD, S_MSE_THRESH, S_MSECNT};
+        int32_t values[7];
+        for (int i = 0; i < 7; ++i) values[i] = scal[fields[i]];
+        ok = PatchScalars(fields, values, 7, stream, 1);
+    }
+    const bool drained = AECM_HIP_OK(hipStreamSynchronize(stream_));
+    return ok && drained;
 }
 
 bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
@@ -502,12 +511,10 @@ int32_t BatchEngine::ImportState(int stream, const void *buf) {
     const uint8_t *body = p + kStateHeaderBytes;
     int32_t scal[kNumScal];
     memcpy(scal, body + kVecWordsPerStream * 4, sizeof scal);
-    // everything the kernel uses as an index or a shift count (aecm_wave.h: hist rows, readlane / writelane lanes)
-    const bool sane = scal[S_MULT] * 8000 == (int32_t)h.fs && scal[S_HISTPOS] >= 0 && scal[S_HISTPOS] <= kHistory &&
-                      scal[S_LAST_DELAY] >= -2 && scal[S_LAST_DELAY] < kHistory && scal[S_FIXED_DELAY] < kHistory &&
-                      scal[S_STARTUP] >= 0 && scal[S_STARTUP] <= 2 && (scal[S_CNG] == 0 || scal[S_CNG] == 1) &&
-                      scal[S_DFANOISYQ] >= 0 && scal[S_DFANOISYQ] <= 15 && scal[S_DFACLEANQ] >= 0 && scal[S_DFACLEANQ] <= 15 &&
-                      scal[S_DFANOISYQ_OLD] >= 0 && scal[S_DFANOISYQ_OLD] <= 15 && scal[S_DFACLEANQ_OLD] >= 0 && scal[S_DFACLEANQ_OLD] <= 15;
+    // everything the kernel uses as an index or a shift count, and the value ranges its arithmetic shortcuts rely on
+    std::vector<uint32_t> vec(kVecWordsPerStream);
+    memcpy(vec.data(), body, kVecWordsPerStream * 4);
+    const bool sane = ValidateStateImage(vec.data(), scal, (int)h.fs) == nullptr;
     if (!sane) return kErrBadParameter;
     if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return kErrUnspecified;
     if (!(AECM_HIP_OK(hipMemcpy(st_.vec + (size_t)stream * kVecWordsPerStream, body, kVecWordsPerStream * 4, hipMemcpyHostToDevice)) &&

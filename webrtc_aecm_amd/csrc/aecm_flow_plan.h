@@ -182,11 +182,14 @@ AECM_FLOW_HD void FlowStartup(FlowRegs &s, int mult, int n_frames) {
         } else {
             s.v[F_COUNTER] = 0;
         }
-        if (s.v[F_COUNTER] * n_blocks_10ms >= 6) {
+        // Both comparisons are made in size_t in the reference (short counter * size_t nBlocks10ms, :320,:330): a counter
+        // that has wrapped negative -- more than 32 767 start-up calls of 80 samples at 16 kHz, where nBlocks10ms is 0 and
+        // neither limit can fire -- is a huge unsigned product there.
+        if ((uint64_t)(int64_t)s.v[F_COUNTER] * (uint64_t)n_blocks_10ms >= 6u) {
             s.v[F_BUF_SIZE_START] = FlowAsShort(FlowMin((3 * s.v[F_SUM] * mult) / (s.v[F_COUNTER] * 40), 50));
             s.v[F_CHECK_BUFF_SIZE] = 0;
         }
-        if (s.v[F_CHECK_BUF_SIZE_CTR] * n_blocks_10ms > 50) {
+        if ((uint64_t)(int64_t)s.v[F_CHECK_BUF_SIZE_CTR] * (uint64_t)n_blocks_10ms > 50u) {
             s.v[F_BUF_SIZE_START] = FlowAsShort(FlowMin((3 * ms * mult) / 40, 50));
             s.v[F_CHECK_BUFF_SIZE] = 0;
         }

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <initializer_list>
 
 #include "aecm_ops.h"
 #include "aecm_tables.h"
@@ -64,6 +65,38 @@ bool ApplyConfig(int32_t *scal, int cng_mode, int echo_mode) {
 void ApplyControl(int32_t *scal, int fixed_delay, int nlp_flag) {
     scal[S_NLP] = (int16_t)nlp_flag;
     scal[S_FIXED_DELAY] = (int16_t)fixed_delay;
+}
+
+const char *ValidateStateImage(const uint32_t *vec, const int32_t *scal, int fs) {
+    auto in = [&](int f, int lo, int hi) { return scal[f] >= lo && scal[f] <= hi; };
+    auto i16 = [&](int f) { return in(f, -32768, 32767); };
+    // indices, lanes, shift counts
+    if (scal[S_MULT] * 8000 != fs || (fs != 8000 && fs != 16000)) return "mult";
+    if (!in(S_HISTPOS, 0, kHistory)) return "far_history_pos";
+    if (!in(S_LAST_DELAY, -2, kHistory - 1)) return "last_delay";
+    if (!in(S_FIXED_DELAY, -32768, kHistory - 1)) return "fixedDelay";
+    if (!in(S_STARTUP, 0, 2)) return "startupState";
+    if (!in(S_DFANOISYQ, 0, 15) || !in(S_DFANOISYQ_OLD, 0, 15) || !in(S_DFACLEANQ, 0, 15) || !in(S_DFACLEANQ_OLD, 0, 15)) return "dfaQDomain";
+    // flags and small counters
+    if (!in(S_CNG, 0, 1)) return "cngMode";
+    if (!in(S_CURVAD, 0, 1) || !in(S_FIRSTVAD, 0, 1) || !in(S_FAR_INIT, 0, 1) || !in(S_NEAR_INIT, 0, 1)) return "flag";
+    if (!in(S_B64_LOWCTR, 0, 7) || !in(S_B64_HIGHCTR, 0, 7)) return "noiseEstCtr[64]";
+    // the reference's int16 members (the kernel treats their narrowing casts as the identity)
+    for (int f : {S_FARLOG, S_FE_MIN, S_FE_MAX, S_FE_MAXMIN, S_FE_VAD, S_FE_MSE, S_VADCNT, S_MSECNT, S_SUPGAIN_OLD, S_NOISECTR, S_NLP,
+                  S_SG_A, S_SG_D, S_SG_DAB, S_SG_DBD, S_B64_CHSTORED, S_B64_CHADAPT16, S_B64_NEARFILT})
+        if (!i16(f)) return "int16 member";
+    if (!in(S_SUPGAIN, 0, 32767)) return "supGain";                   // a smoothed maximum of non-negative targets (aecm_core.cc:1000-1052)
+    if (scal[S_SEED] < 0) return "seed";                               // the LCG state is 31 bits (spl.cc:129-147)
+    if (scal[S_MIN_PROB] < 0 || scal[S_LAST_PROB] < 0) return "delay probability";
+    if (scal[S_B64_NOISE] < 0) return "noiseEst[64]";
+    for (int t = 0; t < kLanes; ++t) {
+        const uint32_t w = vec[V_NEARFILT * kLanes + t];
+        if (((w >> 22) & 31u) > 14u || (t < kSecondPass && (w >> 27) > 14u)) return "far_q_domains";
+        if ((int32_t)vec[V_NOISE * kLanes + t] < 0) return "noiseEst";
+        const uint32_t m = vec[V_M01 * kLanes + t];
+        if ((m & 0xffffu) > (32u << 9) || (t < kSecondPass && (m >> 16) > (32u << 9))) return "mean_bit_counts";
+    }
+    return nullptr;
 }
 
 void SetEchoPath(uint32_t *vec, int32_t *scal, const int16_t path[kBins]) {

@@ -36,6 +36,13 @@ void ApplyControl(int32_t *scal, int fixed_delay, int nlp_flag);
 void SetEchoPath(uint32_t *vec, int32_t *scal, const int16_t path[kBins]);
 void GetEchoPath(const uint32_t *vec, const int32_t *scal, int16_t path[kBins]);
 
+// Is this (vec, scal) image one the kernels may run on?  Everything the block kernel uses as an index, a lane number or
+// a shift count, and every value range its cheaper-instruction shortcuts rely on (aecm_ops.h: as_i16 / as_nonneg /
+// mul24 / checked_shift31 claims that hold for every state the algorithm itself can reach): int16 fields inside int16,
+// supGain >= 0, Q domains <= 14, counters and flags in their ranges.  fs: the rate the image claims (mult * 8000).
+// Used by WebRtcAecmBatch_ImportState; returns the name of the first offending field, or nullptr when the image is sane.
+const char *ValidateStateImage(const uint32_t *vec, const int32_t *scal, int fs);
+
 // The read-only constants blob of the kernels (layout: aecm_state.h, kConstBlobWords words).
 void BuildKernelConstants(std::vector<uint32_t> *blob);
 

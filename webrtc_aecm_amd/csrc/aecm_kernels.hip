@@ -82,7 +82,7 @@ __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
 #ifndef AECM_MAX_WAVES_PER_EU
 #define AECM_MAX_WAVES_PER_EU 8
 #endif
-template <bool kFast, bool kHasClean>
+template <bool kFast, bool kHasClean, bool kPhasePrio = true>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, const int32_t *blocks_per_stream) {
     FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
@@ -93,7 +93,7 @@ void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, c
         n_blocks = __builtin_amdgcn_readfirstlane(blocks_per_stream[stream]);
         if (n_blocks <= 0) return;
     }
-    BlockEngine<Gfx950Wave<kFast>, kHasClean>::run_stream(st, io, stream, n_blocks);
+    BlockEngine<Gfx950Wave<kFast, kPhasePrio>, kHasClean>::run_stream(st, io, stream, n_blocks);
 }
 
 hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
@@ -103,13 +103,27 @@ hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_stre
     const dim3 block(64 * kWavesPerWorkgroup);
     const size_t lds = sizeof(LdsTables);
     const bool clean = io.near_clean != nullptr;
-    if (variant == kVariantFast) {
-        if (clean) hipLaunchKernelGGL((aecm_process_kernel<true, true>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
-        else hipLaunchKernelGGL((aecm_process_kernel<true, false>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
-    } else {
-        if (clean) hipLaunchKernelGGL((aecm_process_kernel<false, true>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
-        else hipLaunchKernelGGL((aecm_process_kernel<false, false>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream);
+    // Issue priority by phase of the block when the launch is more waves than the chip holds at once (they then run in
+    // rounds and spread over the phases by themselves), the per-block rotation when every wave of the launch is resident
+    // from the start and they would otherwise march in lock step (wave_gfx950.h: kPhasePrio).
+    static int resident_waves[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (resident_waves[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        resident_waves[dev] = cus * 4 * AECM_WAVES_PER_EU;
     }
+    const bool phase = n_streams > resident_waves[dev];
+#define AECM_LAUNCH(F, C, P) hipLaunchKernelGGL((aecm_process_kernel<F, C, P>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream)
+    if (variant == kVariantFast) {
+        if (clean) { if (phase) AECM_LAUNCH(true, true, true); else AECM_LAUNCH(true, true, false); }
+        else { if (phase) AECM_LAUNCH(true, false, true); else AECM_LAUNCH(true, false, false); }
+    } else {
+        if (clean) AECM_LAUNCH(false, true, false);
+        else AECM_LAUNCH(false, false, false);
+    }
+#undef AECM_LAUNCH
     return hipGetLastError();
 }
 
@@ -200,7 +214,7 @@ hipError_t LaunchAssembleOutput(const int16_t *blocks, int64_t blocks_stride, co
 // ---- device-resident session machinery (aecm_flow_plan.h) ---------------------------------------------
 template <bool kHasClean, class Append>
 struct TickFlowBlockIo {
-    using E = BlockEngine<Gfx950Wave<true>, kHasClean>;
+    using E = BlockEngine<Gfx950Wave<true, true, true>, kHasClean>;
     using Regs = typename E::Regs;
     const int16_t *far_src;          // the far ring itself (direct ticks) or the framed far stream
     const int16_t *nr, *cr;          // near / clean rings of this session
@@ -433,6 +447,23 @@ __device__ __forceinline__ void TestExchange(int va, int vb, uint64_t *fails) {
     if (a1 != ea || b1 != eb) atomicAdd((unsigned long long *)&fails[1], 1ull);
 }
 
+// exchange_all (the N-transform form, DPP-select assembly for the quad stages) against N applications of the definition
+template <int Q, int N>
+__device__ __forceinline__ void TestExchangeAll(int va, int vb, uint64_t *fails) {
+    const int lane = threadIdx.x & 63;
+    int aa[N], bb[N], ea[N], eb[N];
+    for (int n = 0; n < N; ++n) {
+        aa[n] = (int)Mix((unsigned)va + 0x9e37u * n);
+        bb[n] = (int)Mix((unsigned)vb ^ (0x85ebu * (n + 1)));
+        const int pa = __shfl(aa[n], lane ^ (1 << Q)), pb = __shfl(bb[n], lane ^ (1 << Q));
+        ea[n] = ((lane >> Q) & 1) ? pb : aa[n];
+        eb[n] = ((lane >> Q) & 1) ? bb[n] : pa;
+    }
+    Gfx950Wave<true>::exchange_all<Q, N>(aa, bb);
+    for (int n = 0; n < N; ++n)
+        if (aa[n] != ea[n] || bb[n] != eb[n]) atomicAdd((unsigned long long *)&fails[1], 1ull);
+}
+
 __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int exhaustive, const uint32_t *consts) {
     FillLdsTables<256>(consts);
     using S = Gfx950Wave<false>;
@@ -455,6 +486,9 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
             // 1: FFT operand exchange on every lane bit
             TestExchange<0>(v, w, fails); TestExchange<1>(v, w, fails); TestExchange<2>(v, w, fails);
             TestExchange<3>(v, w, fails); TestExchange<4>(v, w, fails); TestExchange<5>(v, w, fails);
+            TestExchangeAll<0, 1>(v, w, fails); TestExchangeAll<0, 2>(v, w, fails); TestExchangeAll<0, 3>(v, w, fails);
+            TestExchangeAll<1, 1>(v, w, fails); TestExchangeAll<1, 2>(v, w, fails); TestExchangeAll<1, 3>(v, w, fails);
+            TestExchangeAll<2, 2>(v, w, fails); TestExchangeAll<5, 3>(v, w, fails);
             // 2: reductions against a serial readlane loop
             int mx = (int)0x80000000, mn = 0x7fffffff, sm = 0;
             for (int i = 0; i < 64; ++i) {
@@ -551,6 +585,27 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
         const unsigned x = exhaustive ? (unsigned)i : (Mix((unsigned)i) & 0x7fffffffu);
         const uint64_t r = (unsigned)F::isqrt31((int)x);
         if (r * r > x || (r + 1) * (r + 1) <= x) bump(6);
+    }
+    // 6 (cont.): floor(n / d) of the Wiener gain for EVERY divisor 1..65535: dividends around multiples of d (where an
+    // off-by-one would show), the extremes, and random ones -- 64 (quick) or 1 024 (exhaustive) dividends per divisor and thread slot
+    {
+        const int per = exhaustive ? 1024 : 64;
+        for (uint64_t i = gid; i < 65535ull * (unsigned)per; i += stride) {
+            const unsigned d = 1u + (unsigned)(i % 65535ull), j = (unsigned)(i / 65535ull);
+            const unsigned h = Mix((unsigned)i * 2654435761u + 12345u);
+            unsigned n;
+            switch (j & 7u) {
+                case 0: n = h; break;
+                case 1: n = (h / d) * d; break;                       // an exact multiple
+                case 2: n = (h / d) * d - 1u; break;                  // one below a multiple (wraps to 2^32 - 1 for h < d)
+                case 3: n = (h / d) * d + d - 1u; break;
+                case 4: n = 0xffffffffu - (h & 0xffffu); break;       // the top of the range
+                case 5: n = h & 0xffffu; break;                       // small dividends
+                case 6: n = (0xffffffffu / d) * d - (j >> 3 & 1u); break;
+                default: n = h >> (h & 31u); break;
+            }
+            if ((unsigned)F::divu_u32_u16((int)n, (int)d) != n / d) bump(6);
+        }
     }
     // edge values
     if (gid == 0) {

@@ -46,6 +46,14 @@ AECM_HD int iabs(int a) { return a < 0 ? neg(a) : a; }
 AECM_HD bool ltu(int a, int b) { return (unsigned)a < (unsigned)b; }
 AECM_HD bool gtu(int a, int b) { return (unsigned)a > (unsigned)b; }
 AECM_HD int clz32(int a) { return a == 0 ? 32 : __builtin_clz((unsigned)a); }
+// Leading zeros of an operand the caller knows to be non-zero -- or whose count it then ignores (any value for 0).
+AECM_HD int clz32_nz(int a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_clz((unsigned)a);            // no zero fix-up (s_flbit_i32_b32 / v_ffbh_u32 alone)
+#else
+    return a == 0 ? 32 : __builtin_clz((unsigned)a);
+#endif
+}
 AECM_HD int popc(int a) { return __builtin_popcount((unsigned)a); }
 // Truncating signed / unsigned division with the reference's divide-by-zero results.
 AECM_HD int divi(int a, int b) {
@@ -132,6 +140,12 @@ AECM_HD int dot2_i16_cm1(int a, int b) { int r; asm("v_dot2_i32_i16 %0, %1, %2, 
 #else
 AECM_HD int dot2_i16_c0(int a, int b) { return dot2_i16(a, b, 0); }
 AECM_HD int dot2_i16_cm1(int a, int b) { return dot2_i16(a, b, -1); }
+#endif
+// The same with a wave-uniform addend (an SGPR operand of the three-source form).
+#if defined(__HIP_DEVICE_COMPILE__)
+AECM_HD int dot2_i16_uc(int a, int b, int c) { int r; asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c)); return r; }
+#else
+AECM_HD int dot2_i16_uc(int a, int b, int c) { return dot2_i16(a, b, c); }
 #endif
 // sext(a.lo) * sext(k.lo) + c resp. sext(a.hi) * sext(k.lo) + c  (wrapping)    -> v_mad_i32_i16 (op_sel picks the half)
 // The _uc forms take a wave-uniform c (kept in an SGPR on the GPU).

@@ -39,6 +39,23 @@
 
 // Branch layout hints for the inverse transform's per-stage scaling: "no scaling" is the common case
 // (the suppressed output is small), so that path should be the fall-through (measured +0.5 %).
+// Kernel A/B switches (tools/ab_build.py); the defaults are the shipped forms.
+#ifndef AECM_FWD_STAGE1_REAL
+#define AECM_FWD_STAGE1_REAL 1        // forward stage 1 of a real signal knows its imaginary inputs are zero
+#endif
+#ifndef AECM_WIENER_DIV_FLOAT
+#define AECM_WIENER_DIV_FLOAT 1       // the Wiener gain's 32-by-16-bit division in two float steps (W::divu_u32_u16)
+#endif
+// Joint scaling tests of the inverse transform's stages (see fft128); 0 = one test per stage.
+#ifndef AECM_IFFT_GROUPED_SCALE_TESTS
+#define AECM_IFFT_GROUPED_SCALE_TESTS 2
+#endif
+#ifndef AECM_IFFT_GROUPED_SCALE_TESTS_TICK
+#define AECM_IFFT_GROUPED_SCALE_TESTS_TICK 1   // tick kernel (64 VGPRs), ms per tick at 65 536 sessions: 0 0.2682, 1 0.2649, 2 0.2668
+#endif
+#ifndef AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN
+#define AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN 0
+#endif
 #if defined(__GNUC__)
 #define AECM_UNLIKELY(c) __builtin_expect(!!(c), 0)
 #define AECM_LIKELY(c) __builtin_expect(!!(c), 1)
@@ -93,6 +110,12 @@ template <class W, bool kHasClean>
 struct BlockEngine {
     using vi = typename W::vi;
     using vb = typename W::vb;
+
+    // Joint scaling tests of the inverse transform (fft128).  The kernel with a clean near-end input is at its register
+    // budget (72 VGPRs for 7 waves per SIMD): the duplicated stage bodies of the joint tests push it into scratch, so it
+    // keeps one test per stage.
+    static constexpr int kIfftGroupedTests = kHasClean ? AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN
+                                             : W::kTight ? AECM_IFFT_GROUPED_SCALE_TESTS_TICK : AECM_IFFT_GROUPED_SCALE_TESTS;
 
     // Everything a wave keeps in registers across the blocks of one launch.
     struct Regs {
@@ -225,25 +248,33 @@ struct BlockEngine {
     //     T = -T' - s with T' the dot product on b' and s the sum of the twiddle's halves:
     //     B + 1 + T = ((1 - s) - (x_a' << 15)) - T',      B - T = (s - (x_a' << 15)) + T'.
     // All exact modulo 2^32.  Six stages: the last one (even) ends in true values.
-    template <int S, int N>
+    // kRealInput and S == 1: both operands are still purely real (stage 0 of a real signal leaves zero imaginary parts),
+    // so the imaginary accumulators' bases x_a.im * K + c are just c: a uniform addend of the dot product.
+    template <int S, int N, bool kRealInput>
     static AECM_HD void fft_stage_forward(vi (&aa)[N], vi (&bb)[N]) {
         static_assert(S >= 1 && S <= 6, "forward stages 1..6");
         constexpr bool kTrueIn = (S & 1) != 0;
+        constexpr bool kImagZero = kRealInput && S == 1 && AECM_FWD_STAGE1_REAL;
         constexpr bool kNeedImB = S != 6;       // bins 65..127: only the real part of bin 64 is used (aecm_core_c.cc:297)
         vi w_re, w_im, nw_re, nw_im;
         W::template fwd_twiddles<S>(w_re, w_im, nw_re, nw_im);
         vi s_re = vi(0), c_re = vi(0), s_im = vi(0), c_im = vi(0);
         if constexpr (!kTrueIn) W::template fwd_offsets<kTrueIn ? 2 : S>(s_re, c_re, s_im, c_im);
         const vi k = vi(-32768);
+        W::template exchange_all<6 - S, N>(aa, bb);
         for (int n = 0; n < N; ++n) {
             vi &a = aa[n], &b = bb[n];
-            W::template exchange<6 - S>(a, b);
             vi p_re, p_im, m_re, m_im = vi(0);
             if constexpr (kTrueIn) {
                 p_re = dot2_i16(b, nw_re, mad16_lo_uc(a, k, -32770));
                 m_re = dot2_i16(b, w_re, mad16_lo_uc(a, k, -32769));
-                p_im = dot2_i16(b, nw_im, mad16_hi_uc(a, k, -32770));
-                m_im = dot2_i16(b, w_im, mad16_hi_uc(a, k, -32769));
+                if constexpr (kImagZero) {
+                    p_im = dot2_i16_uc(b, nw_im, -32770);
+                    m_im = dot2_i16_uc(b, w_im, -32769);
+                } else {
+                    p_im = dot2_i16(b, nw_im, mad16_hi_uc(a, k, -32770));
+                    m_im = dot2_i16(b, w_im, mad16_hi_uc(a, k, -32769));
+                }
             } else {
                 p_re = dot2_i16(b, nw_re, mad16_lo(a, k, c_re));
                 m_re = dot2_i16(b, w_re, mad16_lo(a, k, s_re));
@@ -257,7 +288,38 @@ struct BlockEngine {
 
     // The generic stage: every inverse stage (data-dependent scaling, complex_fft.c:382-396) and forward
     // stage 0 of a complex signal.  Returns the sum of the shifts applied (inverse only).
-    template <bool kInverse, int S, int N>
+    // max |x| <= T over the 256 int16 of a transform held as packed operands a, b.  For an int16 x, |x| > T  <=>
+    // (uint16)(x + T) > 2T (|-32768| counts as above every T), so per packed word: add, unsigned max over a and b,
+    // saturating subtract of 2T, and "some half non-zero" is one compare + ballot -- no abs, no unpacking.
+    template <int T>
+    static AECM_HD bool fft_max_abs_within(const vi &a, const vi &b) {
+        constexpr int kT = T * 0x10001, k2T = (int)((unsigned)(2 * T) * 0x10001u);
+        const vi over = pk_sub_sat_u16(pk_max_u16(pk_add_u16(a, vi(kT)), pk_add_u16(b, vi(kT))), vi(k2T));
+        return W::ballot(over != 0) == 0;
+    }
+    // How far one unscaled inverse stage can grow the largest magnitude M of a transform (complex_fft.c:465-482 with
+    // shift 0): out = (x_a * 2^14 +- t + 2^13) >> 14 with t = (wr x_b - wi y_b + 1) >> 1 and |wr| + |wi| <= L for every
+    // twiddle of the table (L = 46342 > sqrt(2) * 32768; tests/test_sim.py checks the table against it), so
+    //     |out| <= (2^14 M + (L M + 1) / 2 + 1 + 2^13) / 2^14 + 1 < M (32768 + L) / 32768 + 2.
+    // kNoScaleBound<K>: the largest M for which K consecutive stages provably all see max |x| <= 13573, i.e. none of
+    // them scales (complex_fft.c:382-396) -- their per-stage tests can be skipped.
+    static constexpr int fft_growth(int m) { return (int)(((int64_t)m * (32768 + 46342)) >> 15) + 2; }
+    static constexpr int kScaleThreshold1 = 13573, kScaleThreshold2 = 27146;
+    template <int K>
+    static constexpr int no_scale_bound() {
+        int best = 0;
+        for (int m = 1; m <= kScaleThreshold1; ++m) {
+            int v = m;
+            bool ok = true;
+            for (int k = 1; k < K; ++k) { v = fft_growth(v); if (v > kScaleThreshold1) { ok = false; break; } }
+            if (!ok) break;
+            best = m;
+        }
+        return best;
+    }
+
+    // kProvenNoScale (inverse only): the caller has shown that this stage's max |x| is <= 13573.
+    template <bool kInverse, int S, int N, bool kProvenNoScale = false>
     static AECM_HD int fft_stage_generic(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
         int scale = 0;
         vi w_re, w_im, nw_re = vi(0), nw_im = vi(0);
@@ -266,27 +328,19 @@ struct BlockEngine {
         // Last stage: the caller only consumes the real parts (inverse: real_fft.c:97-99) resp. bins
         // 0..63 complex and the real part of bin 64 (forward: aecm_core_c.cc:297)
         constexpr bool kNeedImA = !(S == 6 && kInverse), kNeedImB = S != 6;
+        if constexpr (S > 0) W::template exchange_all<6 - (S > 0 ? S : 1), N>(aa, bb);
         for (int n = 0; n < N; ++n) {
             vi &a = aa[n], &b = bb[n];
-            if constexpr (S > 0) W::template exchange<6 - (S > 0 ? S : 1)>(a, b);
             // Data-dependent scaling of the inverse transform (complex_fft.c:382-396): shift = [max|x| > 13573] +
             // [max|x| > 27146] over all 256 int16 of the transform (|-32768| counts as 32767: above both thresholds
-            // either way).  For an int16 x, |x| > T  <=>  (uint16)(x + T) > 2T, so per packed word: add, unsigned max
-            // over a and b, saturating subtract of 2T, and "some half non-zero" is one compare + ballot -- no abs, no
-            // unpacking.  "No scaling" is the usual case (the suppressed output is small) and the fall-through path;
+            // either way).  "No scaling" is the usual case (the suppressed output is small) and the fall-through path;
             // the second threshold is only looked at when the first one fired.
             bool rescale = !kInverse;                      // the forward transform always scales by one bit (sh = 15)
-            if (kInverse) {
-                constexpr int kT1 = 13573 * 0x10001, kT2 = 27146 * 0x10001;
-                const vi over1 = pk_sub_sat_u16(pk_max_u16(pk_add_u16(a, vi(kT1)), pk_add_u16(b, vi(kT1))), vi(kT2));
-                rescale = W::ballot(over1 != 0) != 0;
-            }
+            if (kInverse && !kProvenNoScale) rescale = !fft_max_abs_within<kScaleThreshold1>(a, b);
             if (AECM_STEADY_NEVER(AECM_UNLIKELY(rescale))) {
                 int shift = 1;
                 if (kInverse) {
-                    constexpr int kT2 = 27146 * 0x10001, kT4 = (int)(54292u * 0x10001u);
-                    const vi over2 = pk_sub_sat_u16(pk_max_u16(pk_add_u16(a, vi(kT2)), pk_add_u16(b, vi(kT2))), vi(kT4));
-                    shift = W::ballot(over2 != 0) != 0 ? 2 : 1;
+                    shift = fft_max_abs_within<kScaleThreshold2>(a, b) ? 1 : 2;
                     scale += shift;
                 }
                 if (shift == 1) {
@@ -339,25 +393,58 @@ struct BlockEngine {
 
     // k_p: the constant 32770 pinned in a VGPR for the whole launch (Regs::k_p; only the inverse stages use it: one
     // register constant serves both their shift-or and their and-or, which take a single scalar operand).
-    template <bool kInverse, bool kRealInput, int N, int S>
+    template <bool kInverse, bool kRealInput, int N, int S, bool kProvenNoScale = false>
     static AECM_HD int fft_stage(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
         if constexpr (S == 0 && kRealInput && !kInverse) {
             for (int n = 0; n < N; ++n) fft_stage0_real(aa[n], bb[n]);
             return 0;
         } else if constexpr (S > 0 && !kInverse) {
-            fft_stage_forward<S, N>(aa, bb);
+            fft_stage_forward<S, N, kRealInput>(aa, bb);
             return 0;
         } else {
-            return fft_stage_generic<kInverse, S, N>(aa, bb, k_p);
+            return fft_stage_generic<kInverse, S, N, kProvenNoScale>(aa, bb, k_p);
         }
     }
 
     // N independent transforms advance in lockstep (the far-end, near-end and optional clean
     // near-end windows of a block): each stage's twiddles are fetched once and are dead again before
     // the next stage, which keeps the register footprint of the tables at one stage's worth.
+    //
+    // Inverse transform: instead of testing every stage for scaling (5 instructions each), stages 0..2 are tested
+    // together -- max |x| <= no_scale_bound<3>() = 2327 at stage 0 proves that none of them scales -- and so are stages 3
+    // and 4 (bound 5621); a group whose joint test fails falls back to the per-stage tests, stages 5 and 6 always test
+    // for themselves.  On speech-like data the joint tests pass for ~95 % / ~92 % of the blocks: 4.3 tests per block on
+    // average instead of 7.  Bit-exact by construction: a skipped test is one whose outcome is proven.
     template <bool kInverse, bool kRealInput, int N>
     static AECM_HD int fft128(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
         int scale = 0;
+        if constexpr (kInverse && N == 1 && kIfftGroupedTests > 0) {
+            static_assert(no_scale_bound<1>() == 13573 && no_scale_bound<2>() == 5621 && no_scale_bound<3>() == 2327, "growth bound");
+            if (AECM_STEADY_ALWAYS(AECM_LIKELY(fft_max_abs_within<no_scale_bound<3>()>(aa[0], bb[0])))) {
+                fft_stage<kInverse, kRealInput, N, 0, true>(aa, bb, k_p);
+                fft_stage<kInverse, kRealInput, N, 1, true>(aa, bb, k_p);
+                fft_stage<kInverse, kRealInput, N, 2, true>(aa, bb, k_p);
+            } else {
+                scale += fft_stage<kInverse, kRealInput, N, 0>(aa, bb, k_p);
+                scale += fft_stage<kInverse, kRealInput, N, 1>(aa, bb, k_p);
+                scale += fft_stage<kInverse, kRealInput, N, 2>(aa, bb, k_p);
+            }
+            if (AECM_STEADY_ALWAYS(AECM_LIKELY(fft_max_abs_within<no_scale_bound<2>()>(aa[0], bb[0])))) {
+                fft_stage<kInverse, kRealInput, N, 3, true>(aa, bb, k_p);
+                fft_stage<kInverse, kRealInput, N, 4, true>(aa, bb, k_p);
+            } else {
+                scale += fft_stage<kInverse, kRealInput, N, 3>(aa, bb, k_p);
+                scale += fft_stage<kInverse, kRealInput, N, 4>(aa, bb, k_p);
+            }
+            if (kIfftGroupedTests >= 2 && AECM_STEADY_ALWAYS(fft_max_abs_within<no_scale_bound<2>()>(aa[0], bb[0]))) {
+                fft_stage<kInverse, kRealInput, N, 5, true>(aa, bb, k_p);
+                fft_stage<kInverse, kRealInput, N, 6, true>(aa, bb, k_p);
+            } else {
+                scale += fft_stage<kInverse, kRealInput, N, 5>(aa, bb, k_p);
+                scale += fft_stage<kInverse, kRealInput, N, 6>(aa, bb, k_p);
+            }
+            return scale;
+        }
         scale += fft_stage<kInverse, kRealInput, N, 0>(aa, bb, k_p);
         scale += fft_stage<kInverse, kRealInput, N, 1>(aa, bb, k_p);
         scale += fft_stage<kInverse, kRealInput, N, 2>(aa, bb, k_p);
@@ -478,9 +565,12 @@ struct BlockEngine {
     }
 
     static AECM_HD int log_energy_q8(int energy, int q) {                             // :612-628
-        const int zeros = clz32(energy);                                              // 32 for 0: harmless, the result is replaced
-        const int frac = lsr(shl(energy, zeros), 23) & 0xff;                           // bits 30..23 of the normalised energy
-        const int v = sext16((7 << 7) + ((31 - zeros) << 8) + frac - (q << 8));
+        // (7 << 7) + ((31 - zeros) << 8) + frac - (q << 8) with frac = bits 30..23 of the normalised energy.  Taking
+        // bit 31 (the leading one, 256) along saves the mask; the value lies in [-5760, 9087] for 0 <= q <= 26, so the
+        // reference's (int16_t) is the identity.  zeros of 0 is never used (the result is replaced): no zero fix-up of the count.
+        const int zeros = clz32_nz(energy);
+        const int mant = lsr(shl(energy, zeros), 23);                                  // 256 + frac
+        const int v = as_i16(mant - shl(zeros, 8) + (((31 - q) << 8) + (7 << 7) - 256));
         return energy != 0 ? v : (7 << 7);
     }
 
@@ -739,7 +829,10 @@ struct BlockEngine {
         s.near_filt = sel(weird, I(32767), sext16(shl(t_b, neg(q_diff))));                     // q_diff <= 0; a shift by 0 leaves the int16 t_b
 
         I g2 = add(gained, sar(s.near_filt, 1));                                              // :582-611
-        I t32 = shift_u31(divu(g2, zext16(s.near_filt)), res_diff);                           // -20 <= res_diff <= 23
+        I quot;                                                                               // WebRtcSpl_DivU32U16 (:584); nearFilt == 0 is overridden below
+        if constexpr (kUni || !AECM_WIENER_DIV_FLOAT) quot = divu(g2, zext16(s.near_filt));
+        else quot = W::divu_u32_u16(g2, zext16(s.near_filt));
+        I t32 = shift_u31(quot, res_diff);                                                    // -20 <= res_diff <= 23
         // :597-611: hnl = ONE_Q14 - t32 clipped to [0, ONE_Q14], ONE_Q14 for a t32 that wrapped negative: ONE_Q14 - clamp(t32)
         I h;
         if constexpr (kUni) {
@@ -885,6 +978,7 @@ struct BlockEngine {
 
         Spectrum xf, df, cf;
         AECM_PHASE_MARK(0, far_new, near_new);
+        W::template phase_priority<1>();
         // TimeToFrequencyDomain of the far-end, near-end and (optional) clean near-end windows
         // (:439, :442, :452), transformed in lockstep.
         {
@@ -901,10 +995,12 @@ struct BlockEngine {
             fft128<false, true, kSignals>(fa, fb, r.k_p);
             spectrum(r, fa[0], fb[0], q[0], xf);
             AECM_PHASE_MARK(1, xf.mag, xf.re);
+            W::template phase_priority<2>();
             spectrum(r, fa[1], fb[1], q[1], df);
             if (kHasClean) spectrum(r, fa[kSignals - 1], fb[kSignals - 1], q[2], cf);
         }
         AECM_PHASE_MARK(2, df.mag, df.re);
+        W::template phase_priority<3>();
         u.dfa_noisy_q_old = u.dfa_noisy_q;
         u.dfa_noisy_q = df.q;
         if (kHasClean) {                                                              // :449-464
@@ -934,12 +1030,14 @@ struct BlockEngine {
             r.bh1 = W::shift_up1(r.bh1, carry);
         }
         AECM_PHASE_MARK(3, r.bh0, r.mean_far);
+        W::template phase_priority<4>();
         // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
         int delay = process_binary(r, binary_spectrum(r, df.mag, df.q, r.mean_near, u.near_init));
         if (delay == -2) delay = 0;                                                   // :479-483
         if (W::per_block(u.fixed_delay) >= 0) delay = u.fixed_delay;                  // :485-488
 
         AECM_PHASE_MARK(4, r.m0, r.mean_near);
+        W::template phase_priority<5>();
         // AlignedFarend (aecm_core.cc:157-172)
         int pos = u.hist_pos - delay;
         if (pos < 0) pos += kHistory;
@@ -952,12 +1050,15 @@ struct BlockEngine {
         vi echo_est;
         int echo_est64;
         AECM_PHASE_MARK(5, far, r.m1);
+        W::template phase_priority<6>();
         calc_energies(r, far, far64, far_q, df.mag, df.mag64, echo_est, echo_est64);  // :498
         const int mu = calc_step_size(u);                                             // :503
         u.tot_count = add(u.tot_count, 1);                                            // :506
         AECM_PHASE_MARK(6, echo_est, r.near_log);
+        W::template phase_priority<7>();
         update_channel(r, far, far64, far_q, df.mag, df.mag64, mu, echo_est, echo_est64);   // :511
         AECM_PHASE_MARK(7, r.b.ch_adapt32, echo_est);
+        W::template phase_priority<8>();
         const int sup_gain = calc_suppression_gain(r);                                // :514
 
         vi hnl = wiener_bin<vi>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
@@ -965,6 +1066,7 @@ struct BlockEngine {
         const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
 
         AECM_PHASE_MARK(8, hnl, r.b.near_filt);
+        W::template phase_priority<9>();
         if (AECM_STEADY_ALWAYS(W::per_block(u.mult) == 2)) {                          // :618-648
             hnl = as_i16(sar(mul24(hnl, hnl), 14));
             hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
@@ -984,6 +1086,7 @@ struct BlockEngine {
         int e_im64 = 0;
 
         AECM_PHASE_MARK(9, e_re, e_im);
+        W::template phase_priority<10>();
         if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1)) {                           // :702-705
             int shift_n = sext16(15 - u.dfa_clean_q);
             int min_track = 9;
@@ -1008,6 +1111,7 @@ struct BlockEngine {
         }
 
         AECM_PHASE_MARK(10, e_re, e_im);
+        W::template phase_priority<11>();
         // InverseFFTAndWindow (:193-246) + RealInverseFFT (real_fft.c:74-102):
         // Y[c] = (re[c], -im[c]) for c <= 64, conj-symmetric extension for c > 64 (T7).
         vi y = pack(e_re, sext16(neg(e_im)));
@@ -1017,6 +1121,7 @@ struct BlockEngine {
         vi b = sel(r.lane == 0, vi(y64), mirrored);
         const int out_cfft = fft128<true, false>(a, b, r.k_p);
         AECM_PHASE_MARK(11, a, b);
+        W::template phase_priority<12>();
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
         vi first = as_i16(sar(mul24(lo16(a), lane_const<LC_HANN_SYN_LO>(r)) + 8192, 14));               // :219-221
@@ -1024,6 +1129,7 @@ struct BlockEngine {
         vi second = sar(mul24(lo16(b), lane_const<LC_HANN_SYN_HI>(r)), 14);                             // :229-234
         r.out_ovl = sat16(shift_i31(second, vi(sh)));
         AECM_PHASE_MARK(12, out, r.out_ovl);
+        W::template phase_priority<13>();
         r.x_old = far_new;                                                            // :239-245
         r.d_old = near_new;
         if (kHasClean) r.c_old = clean_new;
@@ -1050,6 +1156,9 @@ struct BlockEngine {
         vi far_next = io.far(r, 0);
         vi near_next = io.near(r, 0);
         vi clean_next = kHasClean ? io.clean(r, 0) : vi(0);
+#if defined(AECM_BLOCK_LOOP_UNROLL)
+#pragma unroll AECM_BLOCK_LOOP_UNROLL
+#endif
         for (int blk = 0; blk < n_blocks; ++blk) {
             vi far_cur = far_next, near_cur = near_next, clean_cur = clean_next;
             if (blk + 1 < n_blocks) {             // prefetch the next block's 3 x 128 bytes

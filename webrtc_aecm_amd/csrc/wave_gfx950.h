@@ -38,6 +38,22 @@ extern __shared__ LdsTables g_lds[];   // one instance (dynamic LDS)
 #ifndef AECM_PRIORITY_ROTATION_MIN_BLOCKS
 #define AECM_PRIORITY_ROTATION_MIN_BLOCKS 8
 #endif
+#ifndef AECM_PRIORITY_ROTATION_PERIOD_LOG2
+#define AECM_PRIORITY_ROTATION_PERIOD_LOG2 0   // measured (r3): every block 839, every 4th 834, every 16th 835, never 829 M frames/s
+#endif
+// Issue priority by phase of the block: entry k = phase k of tools/isa_phase_breakdown.py (the code after marker k - 1 of
+// aecm_wave.h; entry 0 is unused): 1-2 forward transforms + magnitudes, 3-5 delay estimator, 6 energies / VAD, 7 NLMS,
+// 8 Wiener gain, 9-10 NLP + comfort noise, 11 inverse transform, 12 synthesis, 13 output store.
+// Measured (r3, 65 536 streams, M frames/s): per-block rotation 841; middle of the block (3..10) at 3 and the transforms
+// at 0: 851; the inverse transform + synthesis at 1: 875, at 3: 884; everything but the forward transforms at 3: 893;
+// priorities ascending through the block (0,1,1,1,2,..,3): 891; the forward transforms HIGH and the middle low: 831; comfort
+// noise one level below its neighbours: 788 (!).  A wave that has begun its block's scalar-heavy part has few vector
+// instructions, each on the critical path between scalar ones: serving those first gets it through quickly, while the
+// forward transforms (dense, independent vector work) of the waves that yield soak up whatever issue slots remain --
+// the vector port then runs at the rate its instruction classes allow (see profiles/r03_*).
+#ifndef AECM_PHASE_PRIOS
+#define AECM_PHASE_PRIOS 0, 0, 0, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3
+#endif
 #ifndef AECM_LANE_CONSTS_IN_LDS
 #define AECM_LANE_CONSTS_IN_LDS 1
 #endif
@@ -61,8 +77,15 @@ enum : int {
 // v_writelane_b32 has no clang builtin in this toolchain: the LLVM intrinsic through its assembler name (like v_ffbh_i32, aecm_ops.h)
 extern "C" __device__ int aecm_llvm_amdgcn_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
-template <bool kFast>
+// kPhasePrio: issue priority by phase of the block (AECM_PHASE_PRIOS) instead of the per-block rotation.  The launcher
+// picks it for launches of more waves than the chip holds at once (measured, M frames/s, phase priority vs rotation:
+// 65 536 streams 893 vs 841, 16 384 streams 827 vs 799, 8 kHz 878 vs 841, with a clean input 779 vs 746; but 4 096
+// streams -- fewer waves than the chip has slots, all running in lock step -- 673 vs 697) and for session ticks (0.267 vs 0.270 ms).
+// kTightRegisters: the kernel instantiating this policy runs at 64 VGPRs (the tick kernel, 8 waves per SIMD): code-size for
+// register trades (the inverse transform's joint scaling tests) are taken or not by AECM_IFFT_GROUPED_SCALE_TESTS_TICK.
+template <bool kFast, bool kPhasePrio = true, bool kTightRegisters = false>
 struct Gfx950Wave {
+    static constexpr bool kTight = kTightRegisters;
     using vi = int;
     using vb = bool;
     static constexpr bool kPrecomputedConstants = true;    // lane constants and LDS tables come from the host-built blob
@@ -101,10 +124,36 @@ struct Gfx950Wave {
         asm volatile("" : "+s"(x));
         return x;
     }
+    static constexpr int kPhasePrios[] = {AECM_PHASE_PRIOS, -1};
+#if defined(AECM_PRIORITY_ROTATION)
+    static constexpr bool kPhasePriority = false;         // A/B: the per-block rotation of rounds 1-2 everywhere
+#else
+    static constexpr bool kPhasePriority = kPhasePrio;
+#endif
+    // Called where phase PHASE begins (after marker PHASE - 1 ... the marker ids of aecm_wave.h).
+    template <int PHASE>
+    static __device__ __forceinline__ void phase_priority() {
+        if constexpr (kPhasePriority) {
+            constexpr int n = (int)(sizeof(kPhasePrios) / sizeof(int)) - 1;             // entries 0 (unused) .. 13
+            static_assert(n == 14 && PHASE >= 1 && PHASE <= 13, "one priority per phase 1..13 (entry 0 is unused)");
+            constexpr int now = kPhasePrios[PHASE];
+            constexpr int before = PHASE == 1 ? kPhasePrios[n - 1] : kPhasePrios[PHASE - 1];   // phase 13 of the block before (a launch starts at 0: keep entry 13 at 0)
+            if constexpr (now != before) {
+                if constexpr (now == 0) __builtin_amdgcn_s_setprio(0);
+                else if constexpr (now == 1) __builtin_amdgcn_s_setprio(1);
+                else if constexpr (now == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
+        }
+    }
     static __device__ __forceinline__ void begin_block(int blk, int n_blocks) {
+        if (kPhasePriority) return;
         if (per_block(n_blocks) < AECM_PRIORITY_ROTATION_MIN_BLOCKS) return;   // a 2-3 block tick launch is over before shares even out
+        // the priority changes every 2^AECM_PRIORITY_ROTATION_PERIOD_LOG2 blocks: the four-way switch below is three
+        // branches, paid once per period instead of once per block
+        if (AECM_PRIORITY_ROTATION_PERIOD_LOG2 > 0 && (blk & ((1 << AECM_PRIORITY_ROTATION_PERIOD_LOG2) - 1)) != 0) return;
         const unsigned h = (blockIdx.x * 2654435761u) >> 16;
-        switch (((unsigned)blk + h) & 3u) {
+        switch ((((unsigned)blk >> AECM_PRIORITY_ROTATION_PERIOD_LOG2) + h) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -214,6 +263,53 @@ struct Gfx950Wave {
         }
     }
 
+    // The same for the N transforms that advance in lock step.  For the two quad stages (lane bits 1 and 0) DPP row /
+    // bank masks cannot tell the two lanes of a pair apart, so exchange<Q> above needs two DPP moves and two selects per
+    // transform.  v_cndmask_b32 is a VOP2 instruction and takes a DPP source: with VCC = "lane bit Q clear"
+    //     a' = vcc ? a : quad_perm(b)        and, with VCC complemented,        b' = vcc ? b : quad_perm(a)
+    // -- two VALU instructions per transform; the mask moves (s_mov / s_not, shared by the N transforms) run on the
+    // scalar unit, the less loaded port.  The compiler never forms this (it keeps the mask in an SGPR pair and emits the
+    // VOP3 v_cndmask, which has no DPP form on gfx9), hence the assembly.  s_mov + s_nop are the two wait states a DPP
+    // read needs after a VALU write of its source (the hazard recognizer does not look inside inline assembly).
+#ifndef AECM_QUAD_EXCHANGE_DPP_SELECT
+#define AECM_QUAD_EXCHANGE_DPP_SELECT 0   // measured (r3): 828 vs 833 M frames/s -- the mask moves and the wait state cost more than the two VALU slots they free
+#endif
+#define AECM_QX_HEAD "s_mov_b64 vcc, %[m]\n\ts_nop 0\n\t"
+#define AECM_QX_A(i, QP) "v_cndmask_b32_dpp %[na" #i "], %[b" #i "], %[a" #i "], vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"
+#define AECM_QX_B(i, QP) "v_cndmask_b32_dpp %[nb" #i "], %[a" #i "], %[b" #i "], vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"
+#define AECM_QX_OUT(i) [na##i] "=&v"(na[i]), [nb##i] "=&v"(nb[i])
+#define AECM_QX_IN(i) [a##i] "v"(aa[i]), [b##i] "v"(bb[i])
+#define AECM_QX_ASM(QP)                                                                                                          \
+    if constexpr (N == 1)                                                                                                        \
+        asm(AECM_QX_HEAD AECM_QX_A(0, QP) "s_not_b64 vcc, vcc\n\t" AECM_QX_B(0, QP)                                               \
+            : AECM_QX_OUT(0) : AECM_QX_IN(0), [m] "s"(keep_a) : "vcc", "scc");                                                   \
+    else if constexpr (N == 2)                                                                                                   \
+        asm(AECM_QX_HEAD AECM_QX_A(0, QP) AECM_QX_A(1, QP) "s_not_b64 vcc, vcc\n\t" AECM_QX_B(0, QP) AECM_QX_B(1, QP)             \
+            : AECM_QX_OUT(0), AECM_QX_OUT(1) : AECM_QX_IN(0), AECM_QX_IN(1), [m] "s"(keep_a) : "vcc", "scc");                    \
+    else                                                                                                                         \
+        asm(AECM_QX_HEAD AECM_QX_A(0, QP) AECM_QX_A(1, QP) AECM_QX_A(2, QP) "s_not_b64 vcc, vcc\n\t" AECM_QX_B(0, QP)             \
+            AECM_QX_B(1, QP) AECM_QX_B(2, QP)                                                                                    \
+            : AECM_QX_OUT(0), AECM_QX_OUT(1), AECM_QX_OUT(2) : AECM_QX_IN(0), AECM_QX_IN(1), AECM_QX_IN(2), [m] "s"(keep_a)      \
+            : "vcc", "scc")
+    template <int Q, int N>
+    static __device__ __forceinline__ void exchange_all(int (&aa)[N], int (&bb)[N]) {
+        if constexpr (kFast && AECM_QUAD_EXCHANGE_DPP_SELECT && Q <= 1 && N <= 3) {
+            const unsigned long long keep_a = Q == 0 ? 0x5555555555555555ull : 0x3333333333333333ull;   // lane bit Q clear
+            int na[N], nb[N];
+            if constexpr (Q == 0) { AECM_QX_ASM("[1,0,3,2]"); }
+            else { AECM_QX_ASM("[2,3,0,1]"); }
+            for (int n = 0; n < N; ++n) { aa[n] = na[n]; bb[n] = nb[n]; }
+        } else {
+            for (int n = 0; n < N; ++n) exchange<Q>(aa[n], bb[n]);
+        }
+    }
+#undef AECM_QX_ASM
+#undef AECM_QX_IN
+#undef AECM_QX_OUT
+#undef AECM_QX_B
+#undef AECM_QX_A
+#undef AECM_QX_HEAD
+
     // ---- reductions: every lane of a 16-lane row gets the row result (4 DPP steps), then the rows are
     // chained with row_bcast15 / row_bcast31 into lane 63 and read back with one v_readlane.
     // `identity` is what lanes not written by a masked DPP step see (op(v, identity) == v).
@@ -314,6 +410,31 @@ struct Gfx950Wave {
         unsigned r = (unsigned)(__builtin_amdgcn_sqrtf((float)ux) + 0.02f);
         r -= (r * r > ux) ? 1u : 0u;
         return (int)r;
+    }
+
+    // floor(n / d) for an unsigned 32-bit n and 1 <= d < 2^16 (the Wiener gain's WebRtcSpl_DivU32U16, reference
+    // aecm_core_c.cc:584; for d == 0 the caller never looks at the result) in two float steps, 14 instructions instead of
+    // the compiler's 20-instruction 32-by-32 expansion behind a zero test:
+    //   r  = v_rcp_f32(d)                     d is exact in float, r within 1 ulp: relative error <= 2^-22 (margin included)
+    //   q1 = trunc(float(n) * r)              relative error of the product <= 2^-24 + 2^-22 + 2^-24, so |q1 - n/d| <= 1537
+    //   r1 = n - q1 * d                       exact modulo 2^32, and the true value fits: |r1| <= 1537 d < 2^27
+    //   q2 = floor(float(r1) * r + 2^-10)     |r1 / d| <= 1538: absolute error < 6.7e-4 < 2^-10, so the biased value lies in
+    //                                         (x, x + 2^-9) for x = r1 / d, whose fractional part is at most 1 - 2^-16:
+    //                                         q2 is floor(x) or floor(x) + 1
+    //   r2 = r1 - q2 * d in [-d, d)           negative exactly when q2 is one too large
+    //   n / d = q1 + q2 + (r2 >> 31)
+    // v_cvt_u32_f32 saturates (n / d near 2^32 with d == 1).  Checked on the device by the self test (every divisor, edge
+    // and random dividends) against the integer division.
+    static __device__ __forceinline__ int divu_u32_u16(int n, int d) {
+        const float r = __builtin_amdgcn_rcpf((float)(unsigned)d);
+        const float t = (float)(unsigned)n * r;
+        int q1, q2;
+        asm("v_cvt_u32_f32 %0, %1" : "=v"(q1) : "v"(t));
+        const int r1 = sub(n, mul(q1, d));
+        const float t1 = __builtin_fmaf((float)r1, r, 0x1p-10f);
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(q2) : "v"(t1));
+        const int r2 = sub(r1, __mul24(q2, d));
+        return add(add(q1, q2), sar(r2, 31));
     }
 
     // ---- memory ----

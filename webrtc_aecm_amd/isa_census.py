@@ -120,7 +120,7 @@ def census_of_text(text: str):
     return out
 
 
-def census(lib_path, kernel_substr: str = "aecm_process_kernelILb1ELb0"):
+def census(lib_path, kernel_substr: str = "aecm_process_kernelILb1ELb0ELb1"):
     """Census of the first kernel whose mangled name contains kernel_substr (default: the headline block kernel)."""
     all_k = census_of_text(disassemble(lib_path))
     for name, c in all_k.items():
@@ -132,6 +132,6 @@ def census(lib_path, kernel_substr: str = "aecm_process_kernelILb1ELb0"):
 if __name__ == "__main__":
     from . import build as _build
     lib = sys.argv[1] if len(sys.argv) > 1 else _build.LIB
-    c = census(lib, sys.argv[2] if len(sys.argv) > 2 else "aecm_process_kernelILb1ELb0")
+    c = census(lib, sys.argv[2] if len(sys.argv) > 2 else "aecm_process_kernelILb1ELb0ELb1")
     c["opcodes"] = dict(list(c["opcodes"].items())[:40])
     print(json.dumps(c, indent=1))
