@@ -31,7 +31,7 @@ sys.path.insert(0, str(ROOT))
 
 ALGO_BYTES_PER_FRAME = 384            # 128 far in + 128 near in + 128 out
 HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_SUMMARY = ROOT / "profiles" / "r02_rocprof_summary.json"
+PROFILE_SUMMARY = ROOT / "profiles" / "r03_rocprof_summary.json"
 
 
 def synth_on_device(torch, S, L, seed, device, chunk=8192):
@@ -214,7 +214,7 @@ def load_profile_record(lib_path, workload_key):
                 model="denominators: one wave64 VALU instruction per SIMD per 4 shader cycles (measured for the integer VOP3 / "
                       "multiply / DPP class this kernel is mostly made of) resp. per 2 cycles (the SIMD-32 rate of "
                       "MI355X_MICROARCH.md, reached only by back-to-back simple VOP2 ops)",
-                source=f"profiles/{PROFILE_SUMMARY.name} (rocprofv3 SQ_* PMC passes), profiles/r02_valu_class_census.md")
+                source=f"profiles/{PROFILE_SUMMARY.name} (rocprofv3 SQ_* PMC passes), profiles/r03_issue_rate.md")
     traffic = rec.get("traffic_by_workload", {}).get(workload_key)
     return traffic, note
 

@@ -55,6 +55,13 @@ SIM_BIN(divi, divi(x, y))
 SIM_BIN(divu, divu(x, y))
 SIM_BIN(pack_hi16, pack_hi16(x, y))
 SIM_BIN(pk_max_i16, pk_max_i16(x, y))
+SIM_BIN(pk_add_i16, pk_add_i16(x, y))
+SIM_BIN(pk_sub_i16, pk_sub_i16(x, y))
+SIM_BIN(pk_mul_lo_u16, pk_mul_lo_u16(x, y))
+SIM_BIN(pk_shl_b16, pk_shl_b16(x, y))
+SIM_BIN(pk_lshr_b16, pk_lshr_b16(x, y))
+SIM_BIN(pk_ashr_i16, pk_ashr_i16(x, y))
+SIM_BIN(pk_min_u16, pk_min_u16(x, y))
 SIM_BIN(pk_add_u16, pk_add_u16(x, y))
 SIM_BIN(pk_max_u16, pk_max_u16(x, y))
 SIM_BIN(pk_sub_sat_u16, pk_sub_sat_u16(x, y))
@@ -80,6 +87,8 @@ SIM_UN(ffbh_i, ffbh_i(x))
 SIM_UN(low_mask, low_mask(x))
 SIM_UN(popc, popc(x))
 SIM_UN(pk_abs_sat_i16, pk_abs_sat_i16(x))
+SIM_UN(pk_neg_i16, pk_neg_i16(x))
+SIM_UN(opaque_v, opaque_v(x))
 SIM_UN(max_halves_i16, max_halves_i16(x))
 #undef SIM_UN
 
@@ -137,6 +146,11 @@ SIM_MAD16(mad16_hi)
 SIM_MAD16(mad16_lo_uc)
 SIM_MAD16(mad16_hi_uc)
 #undef SIM_MAD16
+inline VecI pk_mad_u16(const VecI &a, const VecI &b, const VecI &c) {
+    VecI r;
+    for (int i = 0; i < 64; ++i) r.v[i] = pk_mad_u16(a.v[i], b.v[i], c.v[i]);
+    return r;
+}
 inline VecI dot2_i16(const VecI &a, const VecI &b, const VecI &c) {
     VecI r;
     for (int i = 0; i < 64; ++i) r.v[i] = dot2_i16(a.v[i], b.v[i], c.v[i]);
@@ -165,6 +179,7 @@ struct SimWave {
     static constexpr bool kPrecomputedConstants = false;   // the simulator evaluates the definitions
     static constexpr bool kLaneConstsInTable = false;
     static constexpr bool kTight = false;
+    static constexpr bool kPhasePriority = false;
     template <int ROW> static vi table_lane_const(const vi &) { return vi(0); }   // never used (kLaneConstsInTable == false)
     static vi table_index_for_this_block() { return vi(0); }
     static void begin_block(int, int) {}

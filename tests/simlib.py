@@ -174,10 +174,13 @@ def sim_recordings(far, near, fs, frame, cng, echo_mode, ms, clean=None):
     return rc, out
 
 
+N_LANE_CONST_ROWS = 11          # aecm_state.h: kLaneConstRows
+
+
 def constants():
     """(host-built blob, lane-constant rows from their definitions, twiddle pairs from their definitions)."""
-    blob = np.zeros(8 * 64 + 7 * 64 * 4 + 6 * 64 * 4 + 3 * 64 * 4 + 360 + 68, dtype=np.uint32)
-    rows = np.zeros(8 * 64, dtype=np.uint32)
+    blob = np.zeros(N_LANE_CONST_ROWS * 64 + 7 * 64 * 4 + 6 * 64 * 4 + 3 * 64 * 4 + 360 + 68, dtype=np.uint32)
+    rows = np.zeros(N_LANE_CONST_ROWS * 64, dtype=np.uint32)
     tw = np.zeros(7 * 64 * 4 + 6 * 64 * 4 + 3 * 64 * 4, dtype=np.uint32)
     lib().sim_constants(blob, rows, tw)
     return blob, rows, tw

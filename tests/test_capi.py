@@ -63,8 +63,8 @@ def test_product_does_not_use_the_oracle():
 
 
 def test_block_kernel_register_budget(tmp_path):
-    """The headline kernels are built for 7 waves per SIMD (72 VGPRs): the fast variants must fit without
-    spilling to scratch, or the occupancy the measurements rely on is silently gone."""
+    """The headline kernels are built for 7 waves per SIMD (72 VGPRs; the small-launch variants for 6 = 80): the fast
+    variants must fit without spilling to scratch, or the occupancy the measurements rely on is silently gone."""
     import re
     import subprocess
     from webrtc_aecm_amd import build
@@ -80,7 +80,9 @@ def test_block_kernel_register_budget(tmp_path):
         body = body[:body.index(".end_amdhsa_kernel")]
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = len(re.findall(r"^\s*scratch_(load|store)", body, re.M))
-        assert vgprs <= 72 and scratch == 0, (has_clean, phase_prio, vgprs, scratch)
+        # phase-priority variants (launches larger than the chip): 7 waves per SIMD = 72 VGPRs; rotation variants (launches
+        # of at most 6 waves per SIMD): 80
+        assert vgprs <= (72 if phase_prio == "1" else 80) and scratch == 0, (has_clean, phase_prio, vgprs, scratch)
     # The tick kernel: the engine's 64 scalar state words must arrive through scalar loads.  A conditional fence, or a
     # store wider than the rings' int16 (vector types alias everything), ahead of load_state silently turns them into
     # vector loads + v_readfirstlane (profiles/r02_experiments.md).  The only 16-byte vector loads it may contain are the

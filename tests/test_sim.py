@@ -235,9 +235,10 @@ def test_host_built_kernel_constants_equal_their_definitions():
     """The GPU kernels read lane constants and LDS tables from a blob built on the host
     (BuildKernelConstants); it must equal what aecm_wave.h / the simulator compute from the definitions."""
     blob, rows, tw = simlib.constants()
-    assert np.array_equal(blob[:512], rows)
-    assert np.array_equal(blob[512:512 + tw.size], tw)
-    hann = blob[512 + tw.size + 360:]
+    n = simlib.N_LANE_CONST_ROWS * 64
+    assert np.array_equal(blob[:n], rows)
+    assert np.array_equal(blob[n:n + tw.size], tw)
+    hann = blob[n + tw.size + 360:]
     assert hann.size == 68 and hann[0] == 0 and hann[64] == 16384
 
 

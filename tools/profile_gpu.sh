@@ -9,7 +9,7 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 PARTS=${PARTS:-"stats hbm sq cal tick"}
-BENCH="python $R/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
+BENCH="python $R/bench.py --no-cpu-baseline --no-parity ${BENCH_ARGS:-}"
 PMC_STEPS="--steps 2 --warmup 1"
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 pmc() {   # pmc <dir> <counters...>

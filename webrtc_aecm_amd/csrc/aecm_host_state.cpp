@@ -94,7 +94,7 @@ const char *ValidateStateImage(const uint32_t *vec, const int32_t *scal, int fs)
         if (((w >> 22) & 31u) > 14u || (t < kSecondPass && (w >> 27) > 14u)) return "far_q_domains";
         if ((int32_t)vec[V_NOISE * kLanes + t] < 0) return "noiseEst";
         const uint32_t m = vec[V_M01 * kLanes + t];
-        if ((m & 0xffffu) > (32u << 9) || (t < kSecondPass && (m >> 16) > (32u << 9))) return "mean_bit_counts";
+        if ((m & 0xffffu) > (32u << 9) || (m >> 16) > (t < kSecondPass ? (32u << 9) : 0u)) return "mean_bit_counts";   // no slot t + 64 for t >= 36: the half stays 0
     }
     return nullptr;
 }
@@ -174,6 +174,9 @@ void BuildKernelConstants(std::vector<uint32_t> *blob) {
         lc[LC_HANN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - t];
         lc[LC_HANN_SYN_LO * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[brev];
         lc[LC_HANN_SYN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - brev];
+        lc[LC_BIN0_REAL * kLanes + t] = t == 0 ? 0x0000ffffu : 0xffffffffu;
+        lc[LC_NLP_AVG_BAND * kLanes + t] = (t >= 4 && t <= 24) ? 0xffffffffu : 0u;
+        lc[LC_NLP_LOW_BINS * kLanes + t] = t < 24 ? 0x7fff0000u : 0u;
     }
     // LDS image: packed twiddles (w_re = (wr, -wi), w_im = (wi, wr)) of the inverse transform per
     // [stage][lane]: wr = cos, wi = +sin of entry m << k, m = position & (2^stage - 1) (reference

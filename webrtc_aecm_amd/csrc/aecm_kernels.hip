@@ -82,8 +82,18 @@ __device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
 #ifndef AECM_MAX_WAVES_PER_EU
 #define AECM_MAX_WAVES_PER_EU 8
 #endif
+// The rotation variants only ever run launches of at most kRotationWavesPerEu waves per SIMD (LaunchProcessBlocks): they
+// are built for that occupancy and get the larger register budget (80 VGPRs) that goes with it.
+#ifndef AECM_ROTATION_WAVES_PER_EU
+#if defined(AECM_CHECKED)
+#define AECM_ROTATION_WAVES_PER_EU 4
+#else
+#define AECM_ROTATION_WAVES_PER_EU 6
+#endif
+#endif
 template <bool kFast, bool kHasClean, bool kPhasePrio = true>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup) __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup)
+__attribute__((amdgpu_waves_per_eu(kPhasePrio ? AECM_WAVES_PER_EU : AECM_ROTATION_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, const int32_t *blocks_per_stream) {
     FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -112,7 +122,7 @@ hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_stre
     if (resident_waves[dev] == 0) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        resident_waves[dev] = cus * 4 * AECM_WAVES_PER_EU;
+        resident_waves[dev] = cus * 4 * AECM_ROTATION_WAVES_PER_EU;
     }
     const bool phase = n_streams > resident_waves[dev];
 #define AECM_LAUNCH(F, C, P) hipLaunchKernelGGL((aecm_process_kernel<F, C, P>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream)

@@ -182,6 +182,66 @@ AECM_HD int pk_abs_sat_i16(int a) {
     return (lo & 0xffff) | (int)((unsigned)hi << 16);
 #endif
 }
+// per half: -x, wrapping (-(-32768) == -32768)                               -> v_pk_sub_i16
+AECM_HD int pk_neg_i16(int a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short aecm_short2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, (aecm_short2)((aecm_short2){0, 0} - __builtin_bit_cast(aecm_short2, a)));
+#else
+    return (int)(((0u - (unsigned)a) & 0xffffu) | ((0u - ((unsigned)a & 0xffff0000u)) & 0xffff0000u));
+#endif
+}
+// More per-half (packed 16-bit) arithmetic, each one gfx950 instruction: a + b, a - b (wrapping), a * b (low 16 bits),
+// a << n / a >> n with per-half counts (n & 15), arithmetic a >> n, unsigned min.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AECM_PK_BINOP(NAME, T, EXPR)                                                         \
+    AECM_HD int NAME(int a, int b) {                                                         \
+        typedef T aecm_v2 __attribute__((ext_vector_type(2)));                               \
+        const aecm_v2 x = __builtin_bit_cast(aecm_v2, a), y = __builtin_bit_cast(aecm_v2, b); \
+        return __builtin_bit_cast(int, (aecm_v2)(EXPR));                                     \
+    }
+AECM_PK_BINOP(pk_add_i16, short, x + y)
+AECM_PK_BINOP(pk_sub_i16, short, x - y)
+AECM_PK_BINOP(pk_mul_lo_u16, unsigned short, x * y)
+AECM_PK_BINOP(pk_shl_b16, unsigned short, x << y)          // counts are < 16 at every call site (the instruction takes them modulo 16)
+AECM_PK_BINOP(pk_lshr_b16, unsigned short, x >> y)
+AECM_PK_BINOP(pk_ashr_i16, short, x >> y)
+AECM_PK_BINOP(pk_min_u16, unsigned short, __builtin_elementwise_min(x, y))
+#undef AECM_PK_BINOP
+// per half: a * b + c (low 16 bits)                                          -> v_pk_mad_u16
+AECM_HD int pk_mad_u16(int a, int b, int c) {
+    typedef unsigned short aecm_v2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, (aecm_v2)(__builtin_bit_cast(aecm_v2, a) * __builtin_bit_cast(aecm_v2, b) + __builtin_bit_cast(aecm_v2, c)));
+}
+#else
+AECM_HD int pk_mad_u16(int a, int b, int c) {
+    const unsigned lo = ((unsigned)a & 0xffffu) * ((unsigned)b & 0xffffu) + ((unsigned)c & 0xffffu);
+    const unsigned hi = ((unsigned)a >> 16) * ((unsigned)b >> 16) + ((unsigned)c >> 16);
+    return (int)((lo & 0xffffu) | (hi << 16));
+}
+#define AECM_PK_BINOP(NAME, LO, HI)                                                          \
+    AECM_HD int NAME(int a, int b) {                                                         \
+        const int al = sext16(a), ah = sar(a, 16), bl = sext16(b), bh = sar(b, 16);          \
+        const unsigned ul = (unsigned)al & 0xffffu, uh = (unsigned)ah & 0xffffu, vl = (unsigned)bl & 0xffffu, vh = (unsigned)bh & 0xffffu; \
+        (void)al; (void)ah; (void)bl; (void)bh; (void)ul; (void)uh; (void)vl; (void)vh;      \
+        return (int)(((unsigned)(LO) & 0xffffu) | ((unsigned)(HI) << 16));                   \
+    }
+AECM_PK_BINOP(pk_add_i16, al + bl, ah + bh)
+AECM_PK_BINOP(pk_sub_i16, al - bl, ah - bh)
+AECM_PK_BINOP(pk_mul_lo_u16, ul * vl, uh * vh)
+AECM_PK_BINOP(pk_shl_b16, ul << (vl & 15u), uh << (vh & 15u))
+AECM_PK_BINOP(pk_lshr_b16, ul >> (vl & 15u), uh >> (vh & 15u))
+AECM_PK_BINOP(pk_ashr_i16, al >> (bl & 15), ah >> (bh & 15))
+AECM_PK_BINOP(pk_min_u16, ul < vl ? ul : vl, uh < vh ? uh : vh)
+#undef AECM_PK_BINOP
+#endif
+// x, as a value the optimiser cannot see through (it otherwise rewrites packed arithmetic it recognises -- a multiply by a
+// 0 / 1 factor -- into per-half compares, selects and a re-pack: six instructions for one)
+#if defined(__HIP_DEVICE_COMPILE__)
+AECM_HD int opaque_v(int x) { asm("" : "+v"(x)); return x; }
+#else
+AECM_HD int opaque_v(int x) { return x; }
+#endif
 // per half signed max                                                        -> v_pk_max_i16
 AECM_HD int pk_max_i16(int a, int b) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -43,6 +43,12 @@
 #ifndef AECM_FWD_STAGE1_REAL
 #define AECM_FWD_STAGE1_REAL 1        // forward stage 1 of a real signal knows its imaginary inputs are zero
 #endif
+#ifndef AECM_NOISE_TRACKING_FAST_PATH
+#define AECM_NOISE_TRACKING_FAST_PATH 1   // comfort noise: short update when every estimate is >= 2^11 (one wave-uniform test)
+#endif
+#ifndef AECM_NOISE_TRACKING_FAST_PATH_TICK
+#define AECM_NOISE_TRACKING_FAST_PATH_TICK 1
+#endif
 #ifndef AECM_WIENER_DIV_FLOAT
 #define AECM_WIENER_DIV_FLOAT 1       // the Wiener gain's 32-by-16-bit division in two float steps (W::divu_u32_u16)
 #endif
@@ -54,7 +60,7 @@
 #define AECM_IFFT_GROUPED_SCALE_TESTS_TICK 1   // tick kernel (64 VGPRs), ms per tick at 65 536 sessions: 0 0.2682, 1 0.2649, 2 0.2668
 #endif
 #ifndef AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN
-#define AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN 0
+#define AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN 2
 #endif
 #if defined(__GNUC__)
 #define AECM_UNLIKELY(c) __builtin_expect(!!(c), 0)
@@ -104,6 +110,12 @@ struct Uniform {
     int sup_gain, sup_gain_old, noise_ctr;
     int far_init, near_init, min_prob, last_prob, last_delay;
     int mult, cng, nlp, fixed_delay, sg_a, sg_d, sg_dab, sg_dbd;
+    // Not persistent: where the newest entry of the three log-energy histories sits in lanes 0..19.  The reference
+    // shifts its arrays by one every block (aecm_core.cc:665-669) but only ever looks at the newest entry and at sums
+    // over the first 20 (:943-952), so in registers they are 20-slot rings: one v_writelane per history and block
+    // instead of a move + a whole-wave shift.  Entry k (0 = newest) is lane (log_pos + k) mod 20; load_state starts at 0
+    // and store_state writes the canonical order back.
+    int log_pos;
 };
 
 template <class W, bool kHasClean>
@@ -111,11 +123,15 @@ struct BlockEngine {
     using vi = typename W::vi;
     using vb = typename W::vb;
 
-    // Joint scaling tests of the inverse transform (fft128).  The kernel with a clean near-end input is at its register
-    // budget (72 VGPRs for 7 waves per SIMD): the duplicated stage bodies of the joint tests push it into scratch, so it
-    // keeps one test per stage.
+    // Joint scaling tests of the inverse transform (fft128): per kernel family, because the duplicated stage bodies cost
+    // registers (the tick kernel runs at 64 VGPRs).
     static constexpr int kIfftGroupedTests = kHasClean ? AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN
                                              : W::kTight ? AECM_IFFT_GROUPED_SCALE_TESTS_TICK : AECM_IFFT_GROUPED_SCALE_TESTS;
+
+    // The comfort-noise estimator's short update (noise_bin<.., kTracking>) duplicates the phase's code: the one fast
+    // kernel that then no longer fits its register budget (clean input + rotation: small launches only) keeps the long form.
+    static constexpr bool kNoiseTrackingFastPath = AECM_NOISE_TRACKING_FAST_PATH && (W::kTight ? AECM_NOISE_TRACKING_FAST_PATH_TICK != 0 : true) &&
+                                                   !(kHasClean && !W::kPhasePriority);
 
     // Everything a wave keeps in registers across the blocks of one launch.
     struct Regs {
@@ -123,7 +139,7 @@ struct BlockEngine {
         BinState<vi> b;       // bins 0..63
         BinState<int> b64;    // bin 64
         vi x_old, d_old, c_old, out_ovl;
-        vi mean_far, mean_near, bh0, bh1, m0, m1, hq0, hq1;
+        vi mean, bh0, bh1, m01, hq0, hq1;   // mean: binary-spectrum thresholds, far end in lanes 12..43, near end in the others (binary_spectra)
         vi near_log, adapt_log, stored_log;
         // lane constants
         vi lane, brev;
@@ -183,6 +199,9 @@ struct BlockEngine {
         r.lc[LC_LCG_MUL] = a;
         r.lc[LC_LCG_ADD] = c;
         W::div_magic_lanes(r.lane + 1, r.lc[LC_DIV_MAGIC], r.lc[LC_DIV_SHIFT]);
+        r.lc[LC_BIN0_REAL] = sel(r.lane == 0, vi(0xffff), vi(-1));
+        r.lc[LC_NLP_AVG_BAND] = sel((r.lane >= 4) & (r.lane <= 24), vi(-1), vi(0));
+        r.lc[LC_NLP_LOW_BINS] = sel(r.lane < 24, vi(0x7fff0000), vi(0));
     }
 
     // The lane id for conditions inside the block loop: on the device a copy the compiler cannot see through, renewed
@@ -488,9 +507,9 @@ struct BlockEngine {
         // lane t holds X[bitrev6(t)] in a and X[bitrev6(t)+64] in b
         int x64 = W::readlane(b, 0);
         vi x = W::bpermute(a, r.brev);                      // bin t -> lane t
-        x = sel(r.lane == 0, zext16(x), x);                 // bin 0: imaginary part forced to 0 (:296)
+        x = x & lane_const<LC_BIN0_REAL>(r);                // bin 0: imaginary part forced to 0 (:296)
         sp.re = lo16(x);
-        sp.im = sext16(neg(hi16(x)));                       // conjugate (:188-190), int16 wrap
+        sp.im = hi16(pk_neg_i16(x));                        // conjugate (:188-190), int16 wrap
         sp.re64 = sext16(x64);                              // bin 64: imag forced to 0 (:297)
         // magnitudes (:298-362, AECM_WITH_ABS_APPROX off).  The reference special-cases re == 0 /
         // im == 0 (|.| of the other part) and saturates re^2+im^2 at 2^31-1; both are subsumed by an
@@ -507,33 +526,53 @@ struct BlockEngine {
     // Delay estimator (reference aecm/delay_estimator_wrapper.cc:92-125, delay_estimator.cc:369-382,
     // 521-664; the float "robust validation" half is disabled and output-dead)
     // ------------------------------------------------------------------------------------------
-    static AECM_HD int binary_spectrum(const Regs &r, vi mag, int q, vi &threshold, int &initialized) {
-        vb in_band = (r.lane >= kBandFirst) & (r.lane <= kBandLast);
-        vi v = shl(mag, 15 - q);                                        // Q15
-        if (AECM_STEADY_NEVER(!initialized)) {
-            vb seed = in_band & (mag > 0);
-            threshold = sel(seed, sar(v, 1), threshold);
-            if (W::ballot(seed) != 0) initialized = 1;
+    // Both binary spectra of a block in one pass.  Only bins 12..43 of either spectrum take part, so the far-end
+    // thresholds live in lanes 12..43 of r.mean and the near-end ones in the other 32 lanes (bin b in lane (b + 32) & 63:
+    // the layout of the V_MEAN state word); the near-end magnitudes are brought there by one lane rotation (ds_bpermute,
+    // off the vector ALU) and every instruction of the threshold update then works on 64 live lanes instead of twice on 32.
+    // Returns the far word; near_word by reference.
+    static AECM_HD int binary_spectra(Regs &r, vi far_mag, int far_q, vi near_mag, int near_q, int &near_word) {
+        Uniform &u = r.u;
+        const vb far_lanes = (lane_now(r) >= kBandFirst) & (lane_now(r) <= kBandLast);
+        // Q15 (:100-103); each spectrum is shifted by its own Q before the merge (a uniform count), mag <= 46340 so v > 0 <=> mag > 0
+        const vi v = sel(far_lanes, shl(far_mag, 15 - far_q), W::bpermute(shl(near_mag, 15 - near_q), (r.lane + 32) & 63));
+        if (AECM_STEADY_NEVER(!(u.far_init & u.near_init))) {                                 // delay_estimator_wrapper.cc:106-114, per spectrum
+            const vb fresh = (far_lanes & (u.far_init == 0)) | (!far_lanes & (u.near_init == 0));
+            const vb seed = fresh & (v > 0);
+            r.mean = sel(seed, sar(v, 1), r.mean);
+            if (W::ballot(seed & far_lanes) != 0) u.far_init = 1;
+            if (W::ballot(seed & !far_lanes) != 0) u.near_init = 1;
         }
-        threshold = sel(in_band, mean_step(v, 6, threshold), threshold);
-        uint64_t bits = W::ballot(in_band & (v > threshold));
+        r.mean = mean_step(v, 6, r.mean);
+        const uint64_t bits = W::ballot(v > r.mean);
+        near_word = (int)(uint32_t)((bits >> (kBandFirst + 32)) | (bits << (32 - kBandFirst)));   // bins 12..31 from lanes 44..63, bins 32..43 from lanes 0..11
         return (int)(uint32_t)(bits >> kBandFirst);
     }
 
     static AECM_HD int process_binary(Regs &r, int near_word) {
         Uniform &u = r.u;
         vb valid1 = lane_now(r) < (kHistory - 64);       // compared here (one instruction), not hoisted into a spilled mask
-        vi fb0 = popc(r.bh0), fb1 = popc(r.bh1);
-        vi bc0 = shl(popc(r.bh0 ^ vi(near_word)), 9), bc1 = shl(popc(r.bh1 ^ vi(near_word)), 9);
-        vb upd0 = fb0 > 0, upd1 = valid1 & (fb1 > 0);
-        r.m0 = sel(upd0, mean_step(bc0, vi(13) - sar(fb0 * 3, 4), r.m0), r.m0);     // :550-564
-        r.m1 = sel(upd1, mean_step(bc1, vi(13) - sar(fb1 * 3, 4), r.m1), r.m1);
-        bool any_far = W::ballot(upd0 | upd1) != 0;                                  // :623-626
+        vb nz0 = r.bh0 != 0, nz1 = r.bh1 != 0;                                     // far_bit_counts > 0
+        // :623-626; combined on the scalar side (a ballot of the or-ed conditions makes the compiler turn the mask into
+        // an integer per lane and compare it again)
+        bool any_far = (W::ballot(nz0) | (W::ballot(nz1) & ((uint64_t(1) << (kHistory - 64)) - 1))) != 0;
+        // The 100 means are Q9 values <= 32 << 9 = 2^14 and their update (:550-564, delay_estimator.cc:690-702) never
+        // leaves 16 bits: slots t and t + 64 are advanced together as the two halves of one word (r.m01, the layout of the
+        // V_M01 state word), with packed 16-bit instructions.  Upper halves of lanes >= 36 (no slot) stay 0: their far
+        // bit count is masked to 0, which freezes them.
+        const vi fb = popc(r.bh0) | shl(sel(valid1, popc(r.bh1), vi(0)), 16);                     // far_bit_counts
+        const vi bc = pk_shl_b16(popc(r.bh0 ^ vi(near_word)) | shl(popc(r.bh1 ^ vi(near_word)), 16), vi(0x00090009));   // Q9
+        const vi factor = pk_sub_i16(vi(0x000d000d), pk_lshr_b16(pk_mul_lo_u16(fb, vi(0x00030003)), vi(0x00040004)));   // 13 - (3 fb >> 4), 7..13
+        const vi diff = pk_sub_i16(bc, r.m01);                                                    // |.| <= 2^14
+        const vi round = pk_ashr_i16(diff, vi(0x000f000f)) & pk_sub_i16(pk_shl_b16(vi(0x00010001), factor), vi(0x00010001));
+        const vi step = pk_ashr_i16(pk_add_i16(diff, round), factor);                             // truncating toward zero
+        r.m01 = pk_mad_u16(step, opaque_v(pk_min_u16(fb, vi(0x00010001))), r.m01);                          // only where the far word has a bit set (:558)
         // first minimum / maximum over the 100 means (:568-576): (mean << 7 | slot) is a total order
-        vi key0 = shl(r.m0, 7) | r.lane;
-        vi key1 = sel(valid1, shl(r.m1, 7) | (r.lane + 64), vi(0x7fffffff));
+        const vi m0 = zext16(r.m01), m1 = lsr(r.m01, 16);
+        vi key0 = shl(m0, 7) | r.lane;
+        vi key1 = sel(valid1, shl(m1, 7) | (r.lane + 64), vi(0x7fffffff));
         int kmin, worst;
-        W::reduce_min_max(imin(key0, key1), imax(r.m0, sel(valid1, r.m1, vi(0))), kmin, worst);
+        W::reduce_min_max(imin(key0, key1), imax(m0, m1), kmin, worst);
         int best = kmin >> 7, candidate = kmin & 127;
         if (best >= kMaxBitCountsQ9) { best = kMaxBitCountsQ9; candidate = -1; }
         worst = imax(0, worst);
@@ -587,10 +626,16 @@ struct BlockEngine {
         e_far = add(e_far, far64);
         e_adapt = add(e_adapt, mul(r.b64.ch_adapt16, far64));
         e_stored = add(e_stored, echo_est64);
-        r.near_log = W::shift_up1(r.near_log, log_energy_q8(e_near, u.dfa_noisy_q));        // :665-669
+        // :665-669 as a ring (see Uniform::log_pos); pinned to the scalar unit (with the scalar registers as full as they
+        // are the compiler otherwise keeps this counter in a VGPR: three vector instructions and a v_readfirstlane per block)
+        {
+            const int p = W::per_block(u.log_pos) - 1;
+            u.log_pos = W::per_block(p < 0 ? kLogEntries - 1 : p);
+        }
+        r.near_log = W::writelane(r.near_log, log_energy_q8(e_near, u.dfa_noisy_q), u.log_pos);
         u.far_log = log_energy_q8(e_far, far_q);
-        r.adapt_log = W::shift_up1(r.adapt_log, log_energy_q8(e_adapt, kResChannel16 + far_q));
-        r.stored_log = W::shift_up1(r.stored_log, log_energy_q8(e_stored, kResChannel16 + far_q));
+        r.adapt_log = W::writelane(r.adapt_log, log_energy_q8(e_adapt, kResChannel16 + far_q), u.log_pos);
+        r.stored_log = W::writelane(r.stored_log, log_energy_q8(e_stored, kResChannel16 + far_q), u.log_pos);
 
         if (AECM_STEADY_ALWAYS(u.far_log > kFarEnergyMin)) {                          // :692-730
             int inc_max = 4, dec_max = 11, inc_min = 11, dec_min = 3;
@@ -618,11 +663,11 @@ struct BlockEngine {
         }
         if (AECM_STEADY_NEVER(u.cur_vad && u.first_vad)) {                            // :741-754
             u.first_vad = 0;
-            int adapt0 = W::readlane(r.adapt_log, 0), near0 = W::readlane(r.near_log, 0);
+            int adapt0 = W::readlane(r.adapt_log, u.log_pos), near0 = W::readlane(r.near_log, u.log_pos);
             if (adapt0 > near0) {
                 r.b.ch_adapt16 = sar(r.b.ch_adapt16, 3);
                 r.b64.ch_adapt16 = sar(r.b64.ch_adapt16, 3);
-                r.adapt_log = W::writelane(r.adapt_log, sext16(adapt0 - (3 << 8)), 0);
+                r.adapt_log = W::writelane(r.adapt_log, sext16(adapt0 - (3 << 8)), u.log_pos);
                 u.first_vad = 1;
             }
         }
@@ -760,7 +805,7 @@ struct BlockEngine {
         if (AECM_STEADY_NEVER(!u.cur_vad)) {
             sup = 0;
         } else {
-            int near0 = W::readlane(r.near_log, 0), stored0 = W::readlane(r.stored_log, 0);
+            int near0 = W::readlane(r.near_log, u.log_pos), stored0 = W::readlane(r.stored_log, u.log_pos);
             int dE = sext16(iabs(sext16(near0 - stored0)));
             if (dE < kEnergyDevTol) {
                 if (dE < kSupgainEpcDt) {
@@ -848,10 +893,22 @@ struct BlockEngine {
     // ------------------------------------------------------------------------------------------
     // Comfort noise of one bin (reference aecm/aecm_core_c.cc:52-164); returns (uReal, uImag)
     // ------------------------------------------------------------------------------------------
-    template <class I>
+    // kTracking: the caller has established that every noise estimate of the block is >= 2^11 (the usual state once the
+    // estimator has found a noise floor: 2^11 in its Q15-like domain is 1/16 of an LSB of the spectrum).  Then neither
+    // "small estimate" rule (:88-98 the decrement every 5th block below 2^minTrackShift <= 2^9, :117-125 the slow
+    // increment below 2^11) can fire, which leaves one select between the tracking step down and the 1/2048 step up.
+    template <class I, bool kTracking = false>
     static AECM_HD void noise_bin(BinState<I> &s, I dfa, I hnl, I rnd, int shift_n, int min_track, I &u_re, I &u_im) {
         I in = shl(dfa, shift_n);                                                             // :81-127
         auto lt = in < s.noise_est;
+        I ne;
+        if constexpr (kTracking) {
+            I ne_lt = sub(s.noise_est, sar(sub(s.noise_est, in), min_track));
+            I ne_ge = sel(sar(s.noise_est, 19) > 0, mul24(sar(s.noise_est, 11), I(2049)), sar(mul24(s.noise_est & 0x7ffff, I(2049)), 11));
+            ne = sel(lt, ne_lt, ne_ge);
+            s.low_ctr = sel(lt, I(0), s.low_ctr);
+            s.high_ctr = sel(lt, s.high_ctr, I(0));
+        } else {
         auto small = s.noise_est < (1 << min_track);
         I high_inc = s.high_ctr + 1;
         auto dec = high_inc >= 5;
@@ -865,9 +922,10 @@ struct BlockEngine {
                       sel(c11, sar(mul24(s.noise_est & 0x7ffff, I(2049)), 11),   // c11 && !c19: noise_est < 2^19
                           sel(inc, s.noise_est + sar(s.noise_est, 9) + 1, s.noise_est)));
         I low_ge = sel(c11, s.low_ctr, sel(inc, I(0), low_inc));              // c19 implies c11
-        I ne = sel(lt, ne_lt, ne_ge);
+        ne = sel(lt, ne_lt, ne_ge);
         s.low_ctr = sel(lt, I(0), low_ge);
         s.high_ctr = sel(lt, high_lt, I(0));
+        }
         I t32 = sar(ne, shift_n);                                                             // :129-140
         auto clamp = t32 > 32767;
         t32 = sel(clamp, I(32767), t32);
@@ -900,16 +958,16 @@ struct BlockEngine {
         r.stored_log = sext16(W::bpermute(lsr(hq, 16), up36));
         r.b.noise_est = V(V_NOISE);
         w = V(V_MEAN);
-        r.mean_far = w;                                          // only lanes 12..43 of either threshold set are ever used
-        r.mean_near = W::bpermute(w, (r.lane + 32) & 63);
+        r.mean = w;                                              // far-end thresholds in lanes 12..43, near-end ones in the others
         r.bh0 = V(V_BH0);
         w = V(V_BH1);
         r.bh1 = sel(r.lane < kSecondPass, w, vi(0));
         w = W::bpermute(w, up36);
         r.near_log = lo16(w); r.adapt_log = hi16(w);
         w = V(V_M01);
-        r.m0 = zext16(w); r.m1 = lsr(w, 16);
+        r.m01 = w;
         Uniform &u = r.u;
+        u.log_pos = 0;
         u.tot_count = W::uni(scal[S_TOTCOUNT]); u.seed = W::uni(scal[S_SEED]); u.startup = W::uni(scal[S_STARTUP]); u.hist_pos = W::uni(scal[S_HISTPOS]);
         u.dfa_noisy_q = W::uni(scal[S_DFANOISYQ]); u.dfa_noisy_q_old = W::uni(scal[S_DFANOISYQ_OLD]);
         u.dfa_clean_q = W::uni(scal[S_DFACLEANQ]); u.dfa_clean_q_old = W::uni(scal[S_DFACLEANQ_OLD]);
@@ -932,7 +990,9 @@ struct BlockEngine {
         auto V = [&](int f, vi w) { W::store_u32(vec + f * kLanes, r.lane, w); };
         const vb second = r.lane < kSecondPass;                  // live lanes of the second-pass words
         const vb logs = (r.lane >= kSecondPass) & (r.lane < kSecondPass + kLogEntries);
-        const vi down36 = (r.lane - kSecondPass) & 63;           // lane t reads what lane t - 36 holds
+        // lane t (36..55) takes log entry k = t - 36, which lives in ring lane (log_pos + k) mod 20
+        const vi ring = (r.lane - kSecondPass) + r.u.log_pos;
+        const vi down36 = sel(ring >= kLogEntries, ring - kLogEntries, ring) & 63;
         V(V_XD_OLD, pack(r.x_old, r.d_old));
         V(V_OUTBUF, pack(r.out_ovl, r.c_old));
         V(V_CH16, pack(r.b.ch_stored, r.b.ch_adapt16));
@@ -941,10 +1001,10 @@ struct BlockEngine {
         V(V_NEARFILT, zext16(r.b.near_filt) | shl(r.b.low_ctr & 7, 16) | shl(r.b.high_ctr & 7, 19) | shl(lsr(r.hq0, 16) & 31, 22) |
                           sel(second, shl(lsr(r.hq1, 16), 27), vi(0)));
         V(V_NOISE, r.b.noise_est);
-        V(V_MEAN, sel((r.lane >= kBandFirst) & (r.lane <= kBandLast), r.mean_far, W::bpermute(r.mean_near, (r.lane + 32) & 63)));
+        V(V_MEAN, r.mean);
         V(V_BH0, r.bh0);
         V(V_BH1, sel(second, r.bh1, sel(logs, W::bpermute(pack(r.near_log, r.adapt_log), down36), vi(0))));
-        V(V_M01, zext16(r.m0) | sel(second, shl(r.m1, 16), vi(0)));
+        V(V_M01, r.m01);
         V(V_HQ, zext16(r.hq0) | shl(sel(second, r.hq1, sel(logs, W::bpermute(r.stored_log, down36), vi(0))), 16));
         if (W::is_first_lane()) {
             const Uniform &u = r.u;
@@ -1022,21 +1082,23 @@ struct BlockEngine {
             else r.hq1 = W::writelane(r.hq1, side, u.hist_pos - 64);
         }
 
-        // far binary spectrum -> history (delay_estimator_wrapper.cc:233-263, delay_estimator.cc:369-382)
+        // far and near binary spectra (delay_estimator_wrapper.cc:92-125); the far word -> history (:233-263,
+        // delay_estimator.cc:369-382)
+        int near_word;
         {
-            int word = binary_spectrum(r, xf.mag, xf.q, r.mean_far, u.far_init);
+            int word = binary_spectra(r, xf.mag, xf.q, df.mag, df.q, near_word);
             int carry = W::readlane(r.bh0, 63);
             r.bh0 = W::shift_up1(r.bh0, word);
             r.bh1 = W::shift_up1(r.bh1, carry);
         }
-        AECM_PHASE_MARK(3, r.bh0, r.mean_far);
+        AECM_PHASE_MARK(3, r.bh0, r.mean);
         W::template phase_priority<4>();
         // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
-        int delay = process_binary(r, binary_spectrum(r, df.mag, df.q, r.mean_near, u.near_init));
+        int delay = process_binary(r, near_word);
         if (delay == -2) delay = 0;                                                   // :479-483
         if (W::per_block(u.fixed_delay) >= 0) delay = u.fixed_delay;                  // :485-488
 
-        AECM_PHASE_MARK(4, r.m0, r.mean_near);
+        AECM_PHASE_MARK(4, r.m01, r.mean);
         W::template phase_priority<5>();
         // AlignedFarend (aecm_core.cc:157-172)
         int pos = u.hist_pos - delay;
@@ -1049,7 +1111,7 @@ struct BlockEngine {
 
         vi echo_est;
         int echo_est64;
-        AECM_PHASE_MARK(5, far, r.m1);
+        AECM_PHASE_MARK(5, far, r.m01);
         W::template phase_priority<6>();
         calc_energies(r, far, far64, far_q, df.mag, df.mag64, echo_est, echo_est64);  // :498
         const int mu = calc_step_size(u);                                             // :503
@@ -1070,9 +1132,10 @@ struct BlockEngine {
         if (AECM_STEADY_ALWAYS(W::per_block(u.mult) == 2)) {                          // :618-648
             hnl = as_i16(sar(mul24(hnl, hnl), 14));
             hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
-            int avg = W::reduce_add(sel((lane_now(r) >= 4) & (lane_now(r) <= 24), hnl, vi(0)));
+            int avg = W::reduce_add(hnl & lane_const<LC_NLP_AVG_BAND>(r));          // bins 4..24
             avg = sext16(divi(avg, 21));
-            hnl = sel((lane_now(r) >= 24) & (hnl > avg), vi(avg), hnl);
+            // bins 24..63 are clamped to the average: 0 <= avg < 2^15, so for the bins below 24 avg | 0x7fff0000 is above every gain
+            hnl = imin(hnl, vi(avg) | lane_const<LC_NLP_LOW_BINS>(r));
             if (hnl64 > avg) hnl64 = avg;
         }
         if (AECM_STEADY_ALWAYS(W::per_block(u.nlp))) {                                // :651-686
@@ -1099,8 +1162,15 @@ struct BlockEngine {
             u.seed = s64;
             vi u_re, u_im;
             int u_re64, u_im64;
-            noise_bin<vi>(r.b, clean.mag, hnl, rnd, shift_n, min_track, u_re, u_im);
-            noise_bin<int>(r.b64, clean.mag64, hnl64, rnd64, shift_n, min_track, u_re64, u_im64);
+            // every estimate at or above 2^11: the short form of the update (see noise_bin)
+            const bool tracking = kNoiseTrackingFastPath && (W::ballot(r.b.noise_est > vi(2047)) == ~0ull) & (r.b64.noise_est > 2047);
+            if (AECM_STEADY_ALWAYS(AECM_LIKELY(tracking))) {
+                noise_bin<vi, true>(r.b, clean.mag, hnl, rnd, shift_n, min_track, u_re, u_im);
+                noise_bin<int, true>(r.b64, clean.mag64, hnl64, rnd64, shift_n, min_track, u_re64, u_im64);
+            } else {
+                noise_bin<vi>(r.b, clean.mag, hnl, rnd, shift_n, min_track, u_re, u_im);
+                noise_bin<int>(r.b64, clean.mag64, hnl64, rnd64, shift_n, min_track, u_re64, u_im64);
+            }
             u_re = sel(r.lane == 0, vi(0), u_re);                                     // :146-147
             u_im = sel(r.lane == 0, vi(0), u_im);
             u_im64 = 0;                                                               // :158
@@ -1156,10 +1226,7 @@ struct BlockEngine {
         vi far_next = io.far(r, 0);
         vi near_next = io.near(r, 0);
         vi clean_next = kHasClean ? io.clean(r, 0) : vi(0);
-#if defined(AECM_BLOCK_LOOP_UNROLL)
-#pragma unroll AECM_BLOCK_LOOP_UNROLL
-#endif
-        for (int blk = 0; blk < n_blocks; ++blk) {
+        auto step = [&](int blk) __attribute__((always_inline)) {
             vi far_cur = far_next, near_cur = near_next, clean_cur = clean_next;
             if (blk + 1 < n_blocks) {             // prefetch the next block's 3 x 128 bytes
                 far_next = io.far(r, blk + 1);
@@ -1170,7 +1237,19 @@ struct BlockEngine {
             vi out = process_block(r, hist, far_cur, near_cur, clean_cur);
             io.out(r, blk, out);
             AECM_PHASE_MARK(13, r.out_ovl, r.x_old);
+        };
+#if defined(AECM_BLOCK_LOOP_UNROLL2)
+        // two blocks per trip: the values a block hands to the next one (prefetched samples, the lane vectors a DPP shift
+        // rebuilds in a fresh register) change registers instead of being copied back at the loop's end
+        int blk = 0;
+        for (; blk + 1 < n_blocks; blk += 2) {
+            step(blk);
+            step(blk + 1);
         }
+        if (blk < n_blocks) step(blk);
+#else
+        for (int blk = 0; blk < n_blocks; ++blk) step(blk);
+#endif
         AECM_PHASE_MARK(14, r.out_ovl, r.x_old);
         store_state(r, vec, scal);
     }
