@@ -44,15 +44,18 @@ extern __shared__ LdsTables g_lds[];   // one instance (dynamic LDS)
 // Issue priority by phase of the block: entry k = phase k of tools/isa_phase_breakdown.py (the code after marker k - 1 of
 // aecm_wave.h; entry 0 is unused): 1-2 forward transforms + magnitudes, 3-5 delay estimator, 6 energies / VAD, 7 NLMS,
 // 8 Wiener gain, 9-10 NLP + comfort noise, 11 inverse transform, 12 synthesis, 13 output store.
-// Measured (r3, 65 536 streams, M frames/s): per-block rotation 841; middle of the block (3..10) at 3 and the transforms
-// at 0: 851; the inverse transform + synthesis at 1: 875, at 3: 884; everything but the forward transforms at 3: 893;
-// priorities ascending through the block (0,1,1,1,2,..,3): 891; the forward transforms HIGH and the middle low: 831; comfort
-// noise one level below its neighbours: 788 (!).  A wave that has begun its block's scalar-heavy part has few vector
-// instructions, each on the critical path between scalar ones: serving those first gets it through quickly, while the
-// forward transforms (dense, independent vector work) of the waves that yield soak up whatever issue slots remain --
-// the vector port then runs at the rate its instruction classes allow (see profiles/r03_*).
+// Rule: the priority never falls as the block advances -- a wave closer to finishing its block is served first, and the
+// forward transforms (dense, independent vector work at the start of a block) of the waves that yield soak up whatever
+// issue slots remain.  A wave in the scalar-heavy middle has few vector instructions, each on the critical path between
+// scalar ones: serving those first gets it through quickly.  Measured (r3, 65 536 streams, M frames/s, one box per group):
+//   per-block rotation 841 | phases 3..10 at 3, transforms at 0: 851 | + inverse transform / synthesis at 1: 875, at 3: 884,
+//   + phase 13 at 3: 893 | forward transforms HIGH, middle low: 831 | comfort noise one level below its neighbours: 788 (!) |
+//   falling after the middle (3,3,3,3,3,2,2,2,1,1,1): 775 (!)
+//   after the round's instruction-count work (second box): all 3 but the transforms 892 | 1,1,1,2,2,2,2,2,3,...: 901 |
+//   2,2,2,2,2,3,...: 908 | 1,1,1,2,2,3,... (shipped): 916 | 2,2,2,1,1,2,3,...: 916 | 1,1,1,1,1,3,...: 912
+// profiles/r03_experiments.md has the full tables.
 #ifndef AECM_PHASE_PRIOS
-#define AECM_PHASE_PRIOS 0, 0, 0, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3
+#define AECM_PHASE_PRIOS 0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 3, 3, 3, 3
 #endif
 #ifndef AECM_LANE_CONSTS_IN_LDS
 #define AECM_LANE_CONSTS_IN_LDS 1
