@@ -160,6 +160,34 @@ int32_t WebRtcAecmSessions_TickFlagsHost(AecmSessions *s, const int16_t *far_hos
                                          size_t nrOfSamples, const int16_t *msInSndCardBuf_host, const uint8_t *flags_host,
                                          int32_t *codes_host);
 
+/* The asynchronous form: the tick's two launches are enqueued on the object's own HIP stream and the call returns
+ * without waiting for them, so a caller that keeps its audio on the device can issue tick t + 1 (and its own producer /
+ * consumer kernels) while tick t runs.  Device pointers only (or device aliases of registered host buffers, below).
+ *   msInSndCardBuf_host == NULL : every session gets msInSndCardBuf; else S entries, read before the call returns
+ *   flags_host                  : NULL or S entries (needs msInSndCardBuf_host), read before the call returns
+ *   codes_host                  : NULL or S entries, written before the call returns (the codes do not depend on the device)
+ *   wait_hip_event (hipEvent_t) : NULL, or an event the tick's kernels wait for (the caller's producer of far / near)
+ *   done_hip_event (hipEvent_t) : NULL, or an event recorded behind the tick (the caller's consumer of out waits for it)
+ * The far / near / out buffers must stay untouched until the tick has run (done_hip_event or WebRtcAecmSessions_Synchronize).
+ * Every other WebRtcAecmSessions_* call is ordered behind the ticks enqueued so far; the synchronous Tick forms
+ * wait for everything. */
+int32_t WebRtcAecmSessions_TickAsync(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev, const int16_t *near_clean_dev,
+                                     int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf,
+                                     const int16_t *msInSndCardBuf_host, const uint8_t *flags_host, int32_t *codes_host,
+                                     void *wait_hip_event, void *done_hip_event);
+int32_t WebRtcAecmSessions_Synchronize(AecmSessions *s);
+/* AECM_KERNEL_FAST (default) / AECM_KERNEL_SAFE for the object's block engine.  The tick kernel is built on the fast
+ * primitives only: with the safe variant selected, ticks return AECM_UNSUPPORTED_FUNCTION_ERROR (and change nothing). */
+int32_t WebRtcAecmSessions_SetKernelVariant(AecmSessions *s, int32_t variant);
+
+/* Zero-copy host audio.  A caller-owned host buffer is pinned and mapped into the device's address space once
+ * (hipHostRegister); *device_alias is then a device pointer that every *_dev argument of this header accepts
+ * (WebRtcAecmBatch_ProcessBlocks, WebRtcAecmSessions_Tick / TickAsync ...): the kernels read the samples and write the
+ * output in place over the link -- no staging copies, no pageable-memory transfers (the *Host forms stage through
+ * pageable copies: 1.44 ms per tick of 65 536 sessions against the numbers in INTEGRATION.md for this form). */
+int32_t WebRtcAecmBatch_RegisterHostBuffer(int32_t device_id, void *host, size_t size_bytes, void **device_alias);
+int32_t WebRtcAecmBatch_UnregisterHostBuffer(int32_t device_id, void *host);
+
 /* Per-session control while the other sessions keep running (a media server recycling one slot when a call
  * ends).  `session` in [0, S); same return codes as the single-session functions they mirror:
  *   InitSession           <-> WebRtcAecm_Init(inst_s, same sampFreq)   (echo_control_mobile.h:70): fresh core state,

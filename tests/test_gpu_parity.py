@@ -1241,3 +1241,97 @@ def test_c_abi_under_ubsan():
         open(os.environ["AECM_SANITIZER_LOG"], "w").write(log)
     assert r.returncode == 0 and "runtime error" not in log, log[-4000:]
     assert " passed" in log
+
+
+@_needs_ref
+def test_async_ticks_and_registered_host_audio_equal_reference_sessions():
+    """WebRtcAecmSessions_TickAsync: ticks enqueued back to back (per-session delays and flags change every tick, so both
+    argument slots are reused while ticks are still in flight), one synchronisation at the end; every session's output of
+    every tick must equal a reference session driven with the same calls.  Then the same through caller-owned host
+    buffers registered once (WebRtcAecmBatch_RegisterHostBuffer): the kernels read and write them in place."""
+    import torch
+    S, fs, frame, n_calls = 6, 16000, 160, 120
+    pairs = [synth_pair(4000 + k, n_calls * frame // 64 + 1, fs, "mixed") for k in range(S)]
+    far = np.stack([p[0][:n_calls * frame] for p in pairs])
+    near = np.stack([p[1][:n_calls * frame] for p in pairs])
+    pats = [call_pattern(400 + k, n_calls) for k in range(S)]
+    ms = np.stack([p[0] for p in pats], axis=1)                      # [n_calls][S]
+    present = np.stack([p[1] for p in pats], axis=1)
+    exp = np.stack([drive_session(pyoracle.RefSession(fs, 1, 3), far[k], near[k], frame, ms[:, k], present[:, k])[0] for k in range(S)])
+    exp_codes = np.stack([drive_session(pyoracle.RefSession(fs, 1, 3), far[k], near[k], frame, ms[:, k], present[:, k])[1] for k in range(S)], axis=1)
+
+    # (a) device-resident audio, every tick reads its own slice and writes its own slice of one big output buffer
+    dfar, dnear = torch.from_numpy(far).cuda(), torch.from_numpy(near).cuda()
+    dout = torch.zeros_like(dnear)
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    lib = aecm.load()
+    codes = np.zeros((n_calls, S), dtype=np.int32)
+    for i in range(n_calls):
+        off = i * frame * 2
+        fl = np.where(present[i] != 0, 0, aecm.ffi.SESSION_NO_FAREND).astype(np.uint8)
+        m = np.ascontiguousarray(ms[i])
+        rc = lib.WebRtcAecmSessions_TickAsync(sb.h, dfar.data_ptr() + off, dnear.data_ptr() + off, None, dout.data_ptr() + off, far.shape[1],
+                                              frame, 0, m.ctypes.data, fl.ctypes.data, codes[i].ctypes.data, None, None)
+        assert rc in (0, aecm.ffi.AECM_BAD_PARAMETER_WARNING), (i, rc)
+    assert sb.synchronize() == 0
+    assert np.array_equal(codes, exp_codes)
+    assert np.array_equal(dout.cpu().numpy(), exp)
+    sb.close()
+
+    # (b) the same calls through registered host buffers (zero copy), synchronous and asynchronous ticks alternating
+    hfar, hnear = far.copy(), near.copy()
+    hout = np.zeros_like(hnear)
+    pf, pn, po = (aecm.register_host_buffer(a) for a in (hfar, hnear, hout))
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    for i in range(n_calls):
+        off = i * frame * 2
+        fl = np.where(present[i] != 0, 0, aecm.ffi.SESSION_NO_FAREND).astype(np.uint8)
+        m = np.ascontiguousarray(ms[i])
+        if i % 3 == 0:
+            rc = lib.WebRtcAecmSessions_TickFlags(sb.h, pf + off, pn + off, None, po + off, far.shape[1], frame, m.ctypes.data, fl.ctypes.data, None)
+        else:
+            rc = lib.WebRtcAecmSessions_TickAsync(sb.h, pf + off, pn + off, None, po + off, far.shape[1], frame, 0, m.ctypes.data, fl.ctypes.data,
+                                                  None, None, None)
+        assert rc in (0, aecm.ffi.AECM_BAD_PARAMETER_WARNING), (i, rc)
+    assert sb.synchronize() == 0
+    assert np.array_equal(hout, exp)
+    sb.close()
+    for a in (hfar, hnear, hout):
+        aecm.unregister_host_buffer(a)
+    # a block batch on registered host buffers: ProcessBlocks reads and writes them in place
+    T = 300
+    bfar, bnear = synth_streams([4100, 4101, 4102], T, fs)
+    bout = np.zeros_like(bnear)
+    pf, pn, po = (aecm.register_host_buffer(a) for a in (bfar, bnear, bout))
+    b = aecm.AecmBatch(3, fs, 1, 2)
+    b.process_device(pf, pn, po, T * 64, 64, T)
+    b.synchronize()
+    for k in range(3):
+        assert np.array_equal(bout[k], pyoracle.RefCoreStream(fs, 1, 2).process(bfar[k], bnear[k])), k
+    b.close()
+    for a in (bfar, bnear, bout):
+        aecm.unregister_host_buffer(a)
+    with pytest.raises(aecm.AecmError):
+        aecm.unregister_host_buffer(bout)                      # not registered any more
+
+
+def test_ticks_refuse_the_safe_variant_without_poisoning():
+    """The tick kernel exists for the fast cross-lane primitives only: a session batch switched to the safe variant gets
+    AECM_UNSUPPORTED_FUNCTION_ERROR from its ticks and works again after switching back (it used to be poisoned)."""
+    lib = aecm.load()
+    sb = aecm.AecmSessions(2, 16000)
+    rs = np.random.RandomState(5)
+    x = rs.randint(-3000, 3000, size=(2, 160 * 12)).astype(np.int16)
+    ref = aecm.AecmSessions(2, 16000)
+    for i in range(12):
+        sl = slice(i * 160, (i + 1) * 160)
+        if i == 6:
+            assert lib.WebRtcAecmSessions_SetKernelVariant(sb.h, aecm.KERNEL_SAFE) == 0
+            assert sb.tick_host(x[:, sl], x[:, sl])[0] == aecm.ffi.AECM_UNSUPPORTED_FUNCTION_ERROR
+            assert lib.WebRtcAecmSessions_SetKernelVariant(sb.h, 7) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+            assert lib.WebRtcAecmSessions_SetKernelVariant(sb.h, aecm.KERNEL_FAST) == 0
+        rc, out = sb.tick_host(x[:, sl], x[:, sl])
+        rc2, out2 = ref.tick_host(x[:, sl], x[:, sl])
+        assert rc == rc2 == 0 and np.array_equal(out, out2), i
+    sb.close()
+    ref.close()

@@ -19,6 +19,11 @@ def main():
     ap.add_argument("--classes", type=int, default=1,
                     help="distinct msInSndCardBuf values among the sessions (> 1: WebRtcAecmSessions_TickPerSession, one value per session)")
     ap.add_argument("--host", action="store_true", help="audio in host memory (WebRtcAecmSessions_TickHost): the PCIe-inclusive tick")
+    ap.add_argument("--pinned", action="store_true",
+                    help="audio in caller-owned host memory registered once (WebRtcAecmBatch_RegisterHostBuffer): the kernels read and "
+                         "write it in place over the link, no staging copies")
+    ap.add_argument("--async", dest="asynchronous", action="store_true",
+                    help="WebRtcAecmSessions_TickAsync: ticks are enqueued back to back, one synchronisation at the end")
     args = ap.parse_args()
     import torch
 
@@ -35,31 +40,43 @@ def main():
     import numpy as np
     ms = (40 + (np.arange(S) % args.classes)).astype(np.int16)          # distinct values in [40, 40 + classes)
 
-    if args.host:
+    if args.host or args.pinned:
         hfar = np.ascontiguousarray(far.cpu().numpy()[:, :n])
         hnear = np.ascontiguousarray(near.cpu().numpy()[:, :n])
+    if args.pinned:
+        hout = np.zeros_like(hnear)
+        pf, pn, po = (aecm.register_host_buffer(a) for a in (hfar, hnear, hout))
 
     def tick(i):
+        if args.pinned:
+            rc = sess.tick_async(pf, pn, po, n, n, 40) if args.asynchronous else sess.tick_device(pf, pn, po, n, n, 40)
+            assert rc == 0, rc
+            return
         if args.host:
             rc = sess.tick_host_per_session(hfar, hnear, ms)[0] if args.classes > 1 else sess.tick_host(hfar, hnear, 40)[0]
             assert rc == 0, rc
             return
         off = (i % 8) * n * 2
-        if args.classes > 1:
+        if args.asynchronous:
+            rc = sess.tick_async(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, 40,
+                                 ms_per_session=ms if args.classes > 1 else None)
+        elif args.classes > 1:
             rc = sess.tick_device_per_session(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, ms)
         else:
             rc = sess.tick_device(far.data_ptr() + off, near.data_ptr() + off, out.data_ptr(), far.shape[1], n, 40)
         assert rc == 0, rc
     for i in range(40):                               # through the start-up phase
         tick(i)
+    assert sess.synchronize() == 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.ticks):
         tick(40 + i)
+    assert sess.synchronize() == 0
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.ticks
     blocks_per_tick = n / 64.0
-    print(json.dumps({"streams": S, "fs": fs, "audio": "host" if args.host else "device", "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
+    print(json.dumps({"streams": S, "fs": fs, "audio": "pinned host (zero copy)" if args.pinned else "host" if args.host else "device", "async": bool(args.asynchronous), "ms_per_tick": dt * 1e3, "frames_per_s": S * blocks_per_tick / dt,
                       "realtime_streams_per_gpu": int(S * 0.010 / dt)}))
 
 

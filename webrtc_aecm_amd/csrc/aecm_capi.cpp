@@ -341,6 +341,55 @@ int32_t WebRtcAecmSessions_TickFlagsHost(AecmSessions *s, const int16_t *far_hos
                           msInSndCardBuf_host, flags_host, codes_host, true);
 }
 
+int32_t WebRtcAecmSessions_TickAsync(AecmSessions *s, const int16_t *far_dev, const int16_t *near_dev, const int16_t *near_clean_dev,
+                                     int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf,
+                                     const int16_t *msInSndCardBuf_host, const uint8_t *flags_host, int32_t *codes_host,
+                                     void *wait_hip_event, void *done_hip_event) {
+    if (!s) return -1;
+    if (flags_host && !msInSndCardBuf_host) return AECM_NULL_POINTER_ERROR;
+    return s->batch->TickAsync(far_dev, near_dev, near_clean_dev, out_dev, stream_stride, nrOfSamples, msInSndCardBuf,
+                               msInSndCardBuf_host, flags_host, codes_host, wait_hip_event, done_hip_event);
+}
+
+int32_t WebRtcAecmSessions_Synchronize(AecmSessions *s) { return s ? s->batch->Synchronize() : -1; }
+
+int32_t WebRtcAecmSessions_SetKernelVariant(AecmSessions *s, int32_t variant) {
+    if (!s) return -1;
+    if (variant != AECM_KERNEL_SAFE && variant != AECM_KERNEL_FAST) return AECM_BAD_PARAMETER_ERROR;
+    s->batch->engine()->set_variant(variant);
+    return 0;
+}
+
+// Caller-owned host audio, pinned and mapped once: the alias returned is a device pointer every *_dev argument accepts.
+int32_t WebRtcAecmBatch_RegisterHostBuffer(int32_t device_id, void *host, size_t size_bytes, void **device_alias) {
+    if (!host || !device_alias) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes == 0) return AECM_BAD_PARAMETER_ERROR;
+    if (hipSetDevice(device_id) != hipSuccess) return AECM_BAD_PARAMETER_ERROR;
+    const hipError_t e = hipHostRegister(host, size_bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return e == hipErrorHostMemoryAlreadyRegistered ? AECM_BAD_PARAMETER_ERROR : AECM_UNSPECIFIED_ERROR;
+    }
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || !dev) {
+        (void)hipHostUnregister(host);
+        return AECM_UNSPECIFIED_ERROR;
+    }
+    *device_alias = dev;
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_UnregisterHostBuffer(int32_t device_id, void *host) {
+    if (!host) return AECM_NULL_POINTER_ERROR;
+    if (hipSetDevice(device_id) != hipSuccess) return AECM_BAD_PARAMETER_ERROR;
+    if (hipDeviceSynchronize() != hipSuccess) return AECM_UNSPECIFIED_ERROR;      // nothing may still be reading or writing it
+    if (hipHostUnregister(host) != hipSuccess) {
+        (void)hipGetLastError();                       // not a registered buffer: the caller's mistake, not a sticky device error
+        return AECM_BAD_PARAMETER_ERROR;
+    }
+    return 0;
+}
+
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]) {
     if (!failures) return AECM_NULL_POINTER_ERROR;
     if (hipSetDevice(device_id) != hipSuccess) return AECM_UNSPECIFIED_ERROR;

@@ -25,13 +25,16 @@ SessionBatch *SessionBatch::Create(int num_streams, int device_id) {
                     AECM_HIP_OK(hipMalloc((void **)&b->flow_state_, S * kFlowFieldsUsed * sizeof(int32_t))) &&
                     AECM_HIP_OK(hipMalloc((void **)&b->flow_plans_, S * kFlowPlanWords * sizeof(int32_t))) &&
                     AECM_HIP_OK(hipMalloc((void **)&b->far_frames_, S * kFlowFarFrameRing * 2)) &&
-                    AECM_HIP_OK(hipMalloc((void **)&b->far_old_, S * 2 * kFlowFrame * 2)) &&
-                    // per-session msInSndCardBuf / flags of a tick: pinned host arrays the planning kernel reads in place
-                    AECM_HIP_OK(hipHostMalloc((void **)&b->ms_host_, S * sizeof(int16_t), hipHostMallocMapped)) &&
-                    AECM_HIP_OK(hipHostMalloc((void **)&b->flags_host_, S, hipHostMallocMapped)) &&
-                    AECM_HIP_OK(hipHostGetDevicePointer((void **)&b->ms_dev_, b->ms_host_, 0)) &&
-                    AECM_HIP_OK(hipHostGetDevicePointer((void **)&b->flags_dev_, b->flags_host_, 0));
-    if (!ok) {
+                    // (the per-session msInSndCardBuf / flags slots: pinned host arrays the planning kernel reads in place, below)
+                    AECM_HIP_OK(hipMalloc((void **)&b->far_old_, S * 2 * kFlowFrame * 2));
+    bool slots = ok;
+    for (int k = 0; k < kArgSlots && slots; ++k)
+        slots = AECM_HIP_OK(hipHostMalloc((void **)&b->ms_host_[k], S * sizeof(int16_t), hipHostMallocMapped)) &&
+                AECM_HIP_OK(hipHostMalloc((void **)&b->flags_host_[k], S, hipHostMallocMapped)) &&
+                AECM_HIP_OK(hipHostGetDevicePointer((void **)&b->ms_dev_[k], b->ms_host_[k], 0)) &&
+                AECM_HIP_OK(hipHostGetDevicePointer((void **)&b->flags_dev_[k], b->flags_host_[k], 0)) &&
+                AECM_HIP_OK(hipEventCreateWithFlags(&b->slot_read_[k], hipEventDisableTiming));
+    if (!slots) {
         delete b;
         return nullptr;
     }
@@ -50,8 +53,11 @@ SessionBatch::~SessionBatch() {
     (void)hipFree(flow_plans_);
     (void)hipFree(far_frames_);
     (void)hipFree(far_old_);
-    if (ms_host_) (void)hipHostFree(ms_host_);
-    if (flags_host_) (void)hipHostFree(flags_host_);
+    for (int k = 0; k < kArgSlots; ++k) {
+        if (ms_host_[k]) (void)hipHostFree(ms_host_[k]);
+        if (flags_host_[k]) (void)hipHostFree(flags_host_[k]);
+        if (slot_read_[k]) (void)hipEventDestroy(slot_read_[k]);
+    }
 }
 
 // WebRtcAecm_Init of the wrapper side of sessions [first, first + count): one launch (aecm_kernels.h).
@@ -137,14 +143,23 @@ int32_t SessionBatch::SetConfig(int16_t cng_mode, int16_t echo_mode) {
 // happens on the host beyond handing over the tick's msInSndCardBuf / flags.  The return codes need no device either:
 // the only thing a call of an initialised session with valid arguments can return is the warning for an out-of-range
 // msInSndCardBuf (echo_control_mobile.cc:258-265).
-int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
-                           int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
-                           bool host_pointers) {
+int32_t SessionBatch::Fail() {
+    poisoned_ = true;
+    (void)hipStreamSynchronize(engine_->stream());      // async copies from caller / pinned memory may still be in flight
+    return AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
+                              int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
+                              bool host_pointers, void *wait_event, void *done_event, bool *staged_out) {
     if (far == nullptr || near == nullptr || out == nullptr) return AECM_NULL_POINTER_ERROR;
     if (fs_ == 0) return AECM_UNINITIALIZED_ERROR;
     if (n_samples != 80 && n_samples != 160) return AECM_BAD_PARAMETER_ERROR;       // compared as size_t: 2^32 + 80 is not 80
     if (stride < (int64_t)n_samples) return AECM_BAD_PARAMETER_ERROR;
     if (poisoned_) return AECM_UNSPECIFIED_ERROR;
+    // the tick kernel exists for the fast cross-lane primitives only: a batch switched to the safe variant is told so (and
+    // stays usable after switching back) instead of being poisoned
+    if (engine_->variant() != kVariantFast) return AECM_UNSUPPORTED_FUNCTION_ERROR;
     const int n = (int)n_samples;
     if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
@@ -159,11 +174,14 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st)))
             return AECM_UNSPECIFIED_ERROR;
     }
-    auto fail = [&]() -> int32_t {
-        poisoned_ = true;
-        (void)hipStreamSynchronize(st);              // async copies from caller / pinned memory may still be in flight
-        return AECM_UNSPECIFIED_ERROR;
-    };
+    auto fail = [&]() -> int32_t { return Fail(); };
+    // this tick's argument slot: wait (normally not at all) until the planning kernel that last read it has run
+    const int slot = slot_;
+    slot_ = (slot_ + 1) % kArgSlots;
+    if ((ms_per_session || flags_per_session) && slot_busy_[slot]) {
+        if (!AECM_HIP_OK(hipEventSynchronize(slot_read_[slot]))) return fail();
+        slot_busy_[slot] = false;
+    }
     auto code_of = [](int16_t v) -> int32_t { return (v < 0 || v > 500) ? AECM_BAD_PARAMETER_WARNING : 0; };
     int32_t first_rc = 0;
     if (ms_per_session) {
@@ -181,14 +199,14 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         } else if (codes) {
             memset(codes, 0, (size_t)S * sizeof(int32_t));
         }
-        memcpy(ms_host_, ms_per_session, (size_t)S * sizeof(int16_t));      // pinned + mapped; the previous tick ended with a synchronisation
+        memcpy(ms_host_[slot], ms_per_session, (size_t)S * sizeof(int16_t));      // pinned + mapped
     } else {
         first_rc = code_of(ms);
         if (codes)
             for (int s = 0; s < S; ++s) codes[s] = first_rc;
     }
     if (flags_per_session) {
-        memcpy(flags_host_, flags_per_session, (size_t)S);
+        memcpy(flags_host_[slot], flags_per_session, (size_t)S);
     }
     const int16_t *dfar = far, *dnear = near, *dclean = clean;
     int16_t *dout = out;
@@ -213,14 +231,44 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
         if (clean) dclean = c;
     }
     TickIo tio{dfar, dnear, dclean, dout, dstride, n, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, near_pos_};
-    TickFlowIo fio{flow_state_, flow_plans_, far_frames_, far_old_, ms_per_session ? ms_dev_ : nullptr, flags_per_session ? flags_dev_ : nullptr,
-                   ms, 0, fs_};
-    const bool ok = engine_->variant() == kVariantFast && AECM_HIP_OK(LaunchTickFlow(engine_->state_ptrs(), tio, fio, S, st));
+    TickFlowIo fio{flow_state_, flow_plans_, far_frames_, far_old_, ms_per_session ? ms_dev_[slot] : nullptr,
+                   flags_per_session ? flags_dev_[slot] : nullptr, ms, 0, fs_};
+    if (wait_event && !AECM_HIP_OK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(wait_event), 0))) return fail();
+    const bool ok = AECM_HIP_OK(LaunchTickFlow(engine_->state_ptrs(), tio, fio, S, st));
     near_pos_ += n;
     if (!ok) return fail();
+    if (ms_per_session || flags_per_session) {            // both launches of the tick are behind this event; only the first reads the slot
+        if (!AECM_HIP_OK(hipEventRecord(slot_read_[slot], st))) return fail();
+        slot_busy_[slot] = true;
+    }
     if (host_pointers && !copy_rows(out, (size_t)stride * 2, dout, (size_t)n * 2, hipMemcpyDeviceToHost)) return fail();
-    if (!AECM_HIP_OK(hipStreamSynchronize(st))) return fail();
+    if (done_event && !AECM_HIP_OK(hipEventRecord(static_cast<hipEvent_t>(done_event), st))) return fail();
+    if (staged_out) *staged_out = host_pointers;
     return first_rc;
+}
+
+int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
+                           int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
+                           bool host_pointers) {
+    const int32_t rc = Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, host_pointers,
+                               nullptr, nullptr, nullptr);
+    if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) return rc;            // nothing was enqueued (or the object is poisoned)
+    if (!AECM_HIP_OK(hipStreamSynchronize(engine_->stream()))) return Fail();
+    return rc;
+}
+
+int32_t SessionBatch::TickAsync(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride,
+                                size_t n_samples, int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session,
+                                int32_t *codes, void *wait_event, void *done_event) {
+    return Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, false, wait_event, done_event,
+                   nullptr);
+}
+
+int32_t SessionBatch::Synchronize() {
+    if (fs_ == 0) return AECM_UNINITIALIZED_ERROR;
+    if (poisoned_) return AECM_UNSPECIFIED_ERROR;
+    if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(engine_->stream()))) return Fail();
+    return 0;
 }
 
 }  // namespace aecm

@@ -48,6 +48,14 @@ public:
     //     echo_control_mobile.cc:282-283, 384-385).
     int32_t Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
                  int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers);
+    // The same tick, enqueued on the object's stream without waiting for it (device pointers, or host memory the device
+    // can address: see RegisterHostAudio): the two launches of tick t + 1 may be issued while tick t still runs.
+    // wait_event (hipEvent_t, may be null): the tick's kernels wait for it first (the caller's producer of far / near);
+    // done_event (hipEvent_t, may be null): recorded behind the tick (the caller's consumer of out waits for it).
+    int32_t TickAsync(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
+                      int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, void *wait_event,
+                      void *done_event);
+    int32_t Synchronize();
     static constexpr uint8_t kNoFarend = kFlowNoFarend, kSplitCalls = kFlowSplitCalls;
 
 private:
@@ -68,8 +76,19 @@ private:
     int32_t *flow_plans_ = nullptr;            // [S][kFlowPlanWords]: this tick's plan of every session
     int16_t *far_frames_ = nullptr;            // [S][kFlowFarFrameRing]
     int16_t *far_old_ = nullptr;               // [S][2 * 80]
-    int16_t *ms_host_ = nullptr, *ms_dev_ = nullptr;          // [S] per-session msInSndCardBuf of the tick: pinned host memory and
-    uint8_t *flags_host_ = nullptr, *flags_dev_ = nullptr;    // [S] per-session flags          its address on the device (read in place)
+    // Per-session msInSndCardBuf / flags of a tick: pinned host memory the planning kernel reads in place.  Two slots used
+    // alternately, each guarded by an event recorded behind the planning launch that reads it, so that an asynchronous
+    // tick can fill the other slot while the previous tick is still in flight.
+    static constexpr int kArgSlots = 2;
+    int16_t *ms_host_[kArgSlots] = {nullptr, nullptr}, *ms_dev_[kArgSlots] = {nullptr, nullptr};          // [S] each
+    uint8_t *flags_host_[kArgSlots] = {nullptr, nullptr}, *flags_dev_[kArgSlots] = {nullptr, nullptr};    // [S] each
+    hipEvent_t slot_read_[kArgSlots] = {nullptr, nullptr};
+    bool slot_busy_[kArgSlots] = {false, false};
+    int slot_ = 0;
+    int32_t Enqueue(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
+                    int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers,
+                    void *wait_event, void *done_event, bool *staged_out);
+    int32_t Fail();
     int device_ = 0;
 };
 

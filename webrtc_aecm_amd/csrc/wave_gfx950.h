@@ -206,8 +206,13 @@ struct Gfx950Wave {
         const int4 o = g_lds[0].fwd_offset[S / 2 - 1][lane_id()];
         s_re = o.x; one_minus_s_re = o.y; s_im = o.z; one_minus_s_im = o.w;
     }
+#if defined(AECM_PROBE_COSSIN_NO_GATHER)     // counter attribution only (wrong results): the comfort-noise phase gather reads entry = lane instead
+    static __device__ __forceinline__ int cos360(int i) { return sext16(g_lds[0].cossin[lane_id() + (i & 0)]); }
+    static __device__ __forceinline__ int sin360(int i) { return g_lds[0].cossin[lane_id() + (i & 0)] >> 16; }
+#else
     static __device__ __forceinline__ int cos360(int i) { return sext16(g_lds[0].cossin[i]); }
     static __device__ __forceinline__ int sin360(int i) { return g_lds[0].cossin[i] >> 16; }
+#endif
 
     // ---- xor shuffles ----
     template <int M>

@@ -41,13 +41,15 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
     "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
+    "WebRtcAecmBatch_RegisterHostBuffer", "WebRtcAecmBatch_UnregisterHostBuffer",
 ]
 SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_Create", "WebRtcAecmSessions_Free", "WebRtcAecmSessions_Init", "WebRtcAecmSessions_set_config",
     "WebRtcAecmSessions_Tick", "WebRtcAecmSessions_TickHost", "WebRtcAecmSessions_TickPerSession",
     "WebRtcAecmSessions_TickPerSessionHost", "WebRtcAecmSessions_TickFlags", "WebRtcAecmSessions_TickFlagsHost",
     "WebRtcAecmSessions_InitSession", "WebRtcAecmSessions_set_config_session", "WebRtcAecmSessions_InitEchoPath",
-    "WebRtcAecmSessions_GetEchoPath",
+    "WebRtcAecmSessions_GetEchoPath", "WebRtcAecmSessions_TickAsync", "WebRtcAecmSessions_Synchronize",
+    "WebRtcAecmSessions_SetKernelVariant",
 ]
 SESSION_NO_FAREND = 1
 SESSION_SPLIT_CALLS = 2
@@ -132,6 +134,11 @@ def load():
     lib.WebRtcAecmSessions_set_config_session.argtypes = [vp, C.c_int32, AecmConfig]
     lib.WebRtcAecmSessions_InitEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmSessions_GetEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmSessions_TickAsync.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16, vp, vp, vp, vp, vp]
+    lib.WebRtcAecmSessions_Synchronize.argtypes = [vp]
+    lib.WebRtcAecmSessions_SetKernelVariant.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmBatch_RegisterHostBuffer.argtypes = [C.c_int32, vp, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.WebRtcAecmBatch_UnregisterHostBuffer.argtypes = [C.c_int32, vp]
     lib.WebRtcAecmBatch_GetCheckCounters.argtypes = [C.c_int32, vp, C.c_int32]
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
     lib.WebRtcAecmBatch_DebugFft128.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
@@ -425,6 +432,22 @@ class AecmSessions:
         return self.lib.WebRtcAecmSessions_TickPerSession(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n,
                                                           ms.ctypes.data, None)
 
+    def tick_async(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms=40, clean_ptr=None, ms_per_session=None, flags=None,
+                   wait_event=None, done_event=None):
+        """Enqueue one tick and return without waiting for it (device pointers); see include/aecm_batch.h."""
+        msp = flp = None
+        if ms_per_session is not None:
+            ms_per_session = np.ascontiguousarray(ms_per_session, dtype=np.int16)
+            msp = ms_per_session.ctypes.data
+        if flags is not None:
+            flags = np.ascontiguousarray(flags, dtype=np.uint8)
+            flp = flags.ctypes.data
+        return self.lib.WebRtcAecmSessions_TickAsync(self.h, far_ptr, near_ptr, clean_ptr, out_ptr, stream_stride, n, ms, msp, flp, None,
+                                                     wait_event, done_event)
+
+    def synchronize(self):
+        return self.lib.WebRtcAecmSessions_Synchronize(self.h)
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.WebRtcAecmSessions_Free(self.h)
@@ -435,6 +458,22 @@ class AecmSessions:
             self.close()
         except Exception:
             pass
+
+
+def register_host_buffer(array, device: int = 0) -> int:
+    """Pin + map a caller-owned numpy array (zero-copy host audio); returns its device alias for the *_dev arguments."""
+    lib = load()
+    dev = C.c_void_p()
+    rc = lib.WebRtcAecmBatch_RegisterHostBuffer(device, array.ctypes.data, array.nbytes, C.byref(dev))
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_RegisterHostBuffer")
+    return dev.value
+
+
+def unregister_host_buffer(array, device: int = 0) -> None:
+    rc = load().WebRtcAecmBatch_UnregisterHostBuffer(device, array.ctypes.data)
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_UnregisterHostBuffer")
 
 
 def self_test(device: int = 0, exhaustive: bool = False):
