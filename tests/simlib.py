@@ -174,7 +174,7 @@ def sim_recordings(far, near, fs, frame, cng, echo_mode, ms, clean=None):
     return rc, out
 
 
-N_LANE_CONST_ROWS = 11          # aecm_state.h: kLaneConstRows
+N_LANE_CONST_ROWS = 12          # aecm_state.h: kLaneConstRows
 
 
 def constants():

@@ -175,6 +175,7 @@ void BuildKernelConstants(std::vector<uint32_t> *blob) {
         lc[LC_HANN_SYN_LO * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[brev];
         lc[LC_HANN_SYN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - brev];
         lc[LC_BIN0_REAL * kLanes + t] = t == 0 ? 0x0000ffffu : 0xffffffffu;
+        lc[LC_NOT_BIN0 * kLanes + t] = t == 0 ? 0u : 0xffffffffu;
         lc[LC_NLP_AVG_BAND * kLanes + t] = (t >= 4 && t <= 24) ? 0xffffffffu : 0u;
         lc[LC_NLP_LOW_BINS * kLanes + t] = t < 24 ? 0x7fff0000u : 0u;
     }

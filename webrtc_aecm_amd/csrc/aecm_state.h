@@ -86,6 +86,7 @@ enum LaneConstRow : int {
     LC_HANN_LO, LC_HANN_HI,              // analysis window hann[t], hann[64-t]
     LC_HANN_SYN_LO, LC_HANN_SYN_HI,      // synthesis window in IFFT output lane order
     LC_BIN0_REAL,                        // 0x0000ffff in lane 0, all ones elsewhere: and-mask that clears bin 0's imaginary half (aecm_core_c.cc:296)
+    LC_NOT_BIN0,                         // 0 in lane 0, all ones elsewhere: bin 0 gets no comfort noise (aecm_core_c.cc:146-147)
     LC_NLP_AVG_BAND,                     // all ones in lanes 4..24, 0 elsewhere: the bins the wideband NLP averages (aecm_core_c.cc:628-636)
     LC_NLP_LOW_BINS,                     // 0x7fff0000 in lanes 0..23, 0 from lane 24 on: or-ed onto the average it exempts the low bins from the clamp (:638-646)
     kLaneConstRows

@@ -200,6 +200,7 @@ struct BlockEngine {
         r.lc[LC_LCG_ADD] = c;
         W::div_magic_lanes(r.lane + 1, r.lc[LC_DIV_MAGIC], r.lc[LC_DIV_SHIFT]);
         r.lc[LC_BIN0_REAL] = sel(r.lane == 0, vi(0xffff), vi(-1));
+        r.lc[LC_NOT_BIN0] = sel(r.lane == 0, vi(0), vi(-1));
         r.lc[LC_NLP_AVG_BAND] = sel((r.lane >= 4) & (r.lane <= 24), vi(-1), vi(0));
         r.lc[LC_NLP_LOW_BINS] = sel(r.lane < 24, vi(0x7fff0000), vi(0));
     }
@@ -898,7 +899,7 @@ struct BlockEngine {
     // "small estimate" rule (:88-98 the decrement every 5th block below 2^minTrackShift <= 2^9, :117-125 the slow
     // increment below 2^11) can fire, which leaves one select between the tracking step down and the 1/2048 step up.
     template <class I, bool kTracking = false>
-    static AECM_HD void noise_bin(BinState<I> &s, I dfa, I hnl, I rnd, int shift_n, int min_track, I &u_re, I &u_im) {
+    static AECM_HD void noise_bin(BinState<I> &s, I dfa, I hnl, I rnd, I gate, int shift_n, int min_track, I &u_re, I &u_im) {
         I in = shl(dfa, shift_n);                                                             // :81-127
         auto lt = in < s.noise_est;
         I ne;
@@ -931,6 +932,7 @@ struct BlockEngine {
         t32 = sel(clamp, I(32767), t32);
         s.noise_est = sel(clamp, shl(I(32767), shift_n), ne);
         I n16 = as_i16(sar(mul24(as_i16(I(kOneQ14) - hnl), as_i16(t32)), 14));               // 0 <= hnl <= 2^14, 0 <= t32 <= 32767
+        n16 = n16 & gate;                                                                     // bin 0 gets no comfort noise (:146-147): one mask instead of two selects
         I idx = as_i16(sar(mul24(I(359), rnd), 15));                                            // :150
         u_re = as_i16(sar(mul24(n16, W::cos360(idx)), 13));     /* |cos|, |sin| <= 2^13 */                                     // :153-156
         u_im = as_i16(sar(mul24(neg(n16), W::sin360(idx)), 13));
@@ -1139,8 +1141,10 @@ struct BlockEngine {
             if (hnl64 > avg) hnl64 = avg;
         }
         if (AECM_STEADY_ALWAYS(W::per_block(u.nlp))) {                                // :651-686
-            hnl = sel(hnl > kNlpCompHigh, vi(kOneQ14), sel(hnl < kNlpCompLow, vi(0), hnl));
-            hnl64 = hnl64 > kNlpCompHigh ? kOneQ14 : (hnl64 < kNlpCompLow ? 0 : hnl64);
+            // hnl <= ONE_Q14 == NLP_COMP_HIGH always (a Wiener gain, its square >> 14, or a clamp to their average), so the
+            // reference's "hnl > NLP_COMP_HIGH -> ONE_Q14" (:655-657) can never fire: only the lower threshold is live
+            hnl = sel(as_i16(hnl) < kNlpCompLow, vi(0), hnl);
+            hnl64 = hnl64 < kNlpCompLow ? 0 : hnl64;
             if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
         }
         vi e_re = as_i16(sar(mul24(clean.re, hnl) + 8192, 14));      // |re| <= 2^15, 0 <= hnl <= 2^14                         // :680-685
@@ -1163,16 +1167,16 @@ struct BlockEngine {
             vi u_re, u_im;
             int u_re64, u_im64;
             // every estimate at or above 2^11: the short form of the update (see noise_bin)
+            const vi gate = lane_const<LC_NOT_BIN0>(r);                                // 0 in lane 0, all ones elsewhere
             const bool tracking = kNoiseTrackingFastPath && (W::ballot(r.b.noise_est > vi(2047)) == ~0ull) & (r.b64.noise_est > 2047);
             if (AECM_STEADY_ALWAYS(AECM_LIKELY(tracking))) {
-                noise_bin<vi, true>(r.b, clean.mag, hnl, rnd, shift_n, min_track, u_re, u_im);
-                noise_bin<int, true>(r.b64, clean.mag64, hnl64, rnd64, shift_n, min_track, u_re64, u_im64);
+                noise_bin<vi, true>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
+                noise_bin<int, true>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
             } else {
-                noise_bin<vi>(r.b, clean.mag, hnl, rnd, shift_n, min_track, u_re, u_im);
-                noise_bin<int>(r.b64, clean.mag64, hnl64, rnd64, shift_n, min_track, u_re64, u_im64);
+                noise_bin<vi>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
+                noise_bin<int>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
             }
-            u_re = sel(r.lane == 0, vi(0), u_re);                                     // :146-147
-            u_im = sel(r.lane == 0, vi(0), u_im);
+
             u_im64 = 0;                                                               // :158
             e_re = sat16(e_re + u_re);                                                // :160-163
             e_im = sat16(e_im + u_im);
