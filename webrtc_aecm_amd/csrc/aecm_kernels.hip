@@ -271,6 +271,9 @@ void aecm_flow_plan_kernel(TickFlowIo fio, int n, unsigned near_pos, int n_strea
 #ifndef AECM_TICK_FLOW_WAVES
 #define AECM_TICK_FLOW_WAVES 8
 #endif
+#ifndef AECM_TICK_SPLIT_PLAN_WORDS
+#define AECM_TICK_SPLIT_PLAN_WORDS 1
+#endif
 #ifndef AECM_TICK_FLOW_WAVES_PER_EU
 #if defined(AECM_CHECKED)
 #define AECM_TICK_FLOW_WAVES_PER_EU 4
@@ -293,6 +296,12 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
     }
     FillLdsTables<64 * kTickFlowWaves>(st.consts);
     if (s >= n_streams) return;
+    // The 16 words arrive as one s_load_dwordx16 register tuple; left like that, the register allocator spills and reloads
+    // the WHOLE tuple (16 v_writelane / v_readlane) around every use in another basic block.  Passing each word through an
+    // empty asm makes them 16 independent scalars that are spilled one by one, and only where needed.
+#if AECM_TICK_SPLIT_PLAN_WORDS
+    for (int k = 0; k < kFlowPlanWords; ++k) asm volatile("" : "+s"(w[k]));
+#endif
     FlowPlan p;
     FlowUnpackPlan(w, p);
     const int mask = (int)io.ring_len - 1;
