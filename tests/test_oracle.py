@@ -82,6 +82,19 @@ def fft_fuzz_cases(n_cases=400, seed=5):
         cases.append((re, im))
     cases.append((np.full(128, -32768, np.int16), np.full(128, -32768, np.int16)))
     cases.append((np.zeros(128, np.int16), np.zeros(128, np.int16)))
+    # amplitudes at and just above the bounds the kernel's joint scaling tests use (aecm_wave.h: no_scale_bound<3>, <2>,
+    # the reference's two thresholds), as +-amplitude sign patterns -- the inputs that grow fastest through the stages
+    n = np.arange(128)
+    for b in (2327, 5621, 13573, 27146):
+        for amp in (b - 1, b, b + 1):
+            pats = [(np.ones(128), np.ones(128)), (1 - 2 * (n % 2), np.ones(128)), (1 - 2 * ((n // 2) % 2), 1 - 2 * (n % 2)),
+                    (1 - 2 * ((n // 4) % 2), 1 - 2 * ((n // 8) % 2))]
+            pats += [(rng.choice([-1, 1], 128), rng.choice([-1, 1], 128)) for _ in range(6)]
+            for sr, si in pats:
+                cases.append(((amp * sr).astype(np.int16), (amp * si).astype(np.int16)))
+            sparse = np.zeros(128, np.int16)
+            sparse[rng.integers(0, 128)] = amp                       # one element at the bound, the rest silent
+            cases.append((sparse, np.zeros(128, np.int16)))
     return cases
 
 

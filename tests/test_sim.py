@@ -318,3 +318,71 @@ def test_wrapped_startup_counters_follow_the_reference():
 def test_reciprocal_division_of_the_nlms_step_is_exact():
     """divu_by_magic with div_magic's 33-bit reciprocals == n / d for d = 1..65 (bin + 1) over [0, 2^31]."""
     assert simlib.lib().sim_div_magic_check() == 0
+
+
+def test_inverse_fft_growth_bound_behind_the_joint_scaling_tests():
+    """aecm_wave.h skips per-stage scaling tests of the inverse transform when max |x| at the group's first stage proves
+    that no stage of the group can reach 13 573: an unscaled stage grows the largest magnitude M to less than
+    M (32768 + L) / 32768 + 2 with L = 46342 >= |wr| + |wi| for every twiddle.  Checked here against an exact integer model
+    of the unscaled stages (complex_fft.c:465-482 with shift 0) on sign patterns and on a greedy adversary that flips signs
+    to maximise the growth -- and the resulting bounds must be the ones the kernel asserts (2 327 / 5 621)."""
+    import math
+    sin1024 = [int(32767.0 * math.sin(2.0 * math.pi * i / 1024.0)) for i in range(1024)]
+    L = max(abs(sin1024[8 * r + 256]) + abs(sin1024[8 * r]) for r in range(64))
+    assert L <= 46342
+
+    def growth(m):
+        return (m * (32768 + 46342) >> 15) + 2
+
+    def bound(k):
+        best = 0
+        for m in range(1, 13574):
+            v = m
+            for _ in range(k - 1):
+                v = growth(v)
+            if v > 13573:
+                break
+            best = m
+        return best
+    assert (bound(1), bound(2), bound(3)) == (13573, 5621, 2327)
+
+    def stage(re, im, st):                       # one unscaled inverse stage on bit-reversed-order data, in place (int64 arrays)
+        l, k = 1 << st, 9 - st
+        for m in range(l):
+            r = (m << k) >> 3
+            wr, wi = sin1024[8 * r + 256], sin1024[8 * r]
+            i = np.arange(m, 128, 2 * l)
+            j = i + l
+            tr = (wr * re[j] - wi * im[j] + 1) >> 1
+            ti = (wr * im[j] + wi * re[j] + 1) >> 1
+            qr, qi = re[i] * 16384, im[i] * 16384
+            re[j], im[j] = (qr - tr + 8192) >> 14, (qi - ti + 8192) >> 14
+            re[i], im[i] = (qr + tr + 8192) >> 14, (qi + ti + 8192) >> 14
+
+    def worst_after(re0, im0, first, n_stages):
+        re, im = re0.astype(np.int64), im0.astype(np.int64)
+        peaks = []
+        for st in range(first, first + n_stages):
+            m_in = int(max(np.abs(re).max(), np.abs(im).max()))
+            stage(re, im, st)
+            m_out = int(max(np.abs(re).max(), np.abs(im).max()))
+            assert m_out <= growth(m_in), (st, m_in, m_out)
+            peaks.append(m_out)
+        return peaks
+    rs = np.random.RandomState(3)
+    for first, n_stages, amp in ((0, 3, 2327), (3, 2, 5621), (5, 2, 5621), (2, 3, 2327), (4, 3, 2327)):
+        best = 0
+        for trial in range(40):
+            sr, si = rs.choice([-1, 1], 128), rs.choice([-1, 1], 128)
+            peak = worst_after(amp * sr, amp * si, first, n_stages)[-2] if n_stages > 1 else amp
+            # greedy adversary: flip one sign at a time while the magnitude entering the group's LAST stage grows
+            for _ in range(60):
+                k = rs.randint(0, 256)
+                (sr if k < 128 else si)[k % 128] *= -1
+                p2 = worst_after(amp * sr, amp * si, first, n_stages)[-2] if n_stages > 1 else amp
+                if p2 >= peak:
+                    peak = p2
+                else:
+                    (sr if k < 128 else si)[k % 128] *= -1
+            best = max(best, peak)
+        assert best <= 13573, (first, n_stages, amp, best)          # the group's last stage never sees a magnitude that scales
