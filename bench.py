@@ -28,6 +28,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# dmabuf IPC only on this driver: RCCL needs it, and the HSA runtime reads it when torch first touches the GPU -- so before
+# anything imports torch (the driver's environment already exports it; this covers a bare shell)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_FRAME = 384            # 128 far in + 128 near in + 128 out
 HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)

@@ -1335,3 +1335,51 @@ def test_ticks_refuse_the_safe_variant_without_poisoning():
         assert rc == rc2 == 0 and np.array_equal(out, out2), i
     sb.close()
     ref.close()
+
+
+@_needs_ref
+def test_async_tick_event_hooks_order_the_callers_streams():
+    """TickAsync's event hooks: the far / near rows are produced by the caller on ITS stream (a slow fill kernel first, so
+    that the data is certainly not there yet when the tick is enqueued) and consumed from `out` on another stream; the tick
+    must wait for the producer's event and the consumer for the tick's -- no host synchronisation in between.  Every
+    session's output of every tick equals a reference session's."""
+    import torch
+    S, fs, frame, n_calls = 4, 16000, 160, 60
+    pairs = [synth_pair(4300 + k, n_calls * frame // 64 + 1, fs, "steady") for k in range(S)]
+    far = np.stack([p[0][:n_calls * frame] for p in pairs])
+    near = np.stack([p[1][:n_calls * frame] for p in pairs])
+    exp = np.stack([pyoracle.RefSession(fs, 1, 3).run(far[k], near[k], frame, 40) for k in range(S)])
+    src_far, src_near = torch.from_numpy(far).cuda(), torch.from_numpy(near).cuda()
+    dfar, dnear = torch.zeros((S, frame), dtype=torch.int16, device="cuda"), torch.zeros((S, frame), dtype=torch.int16, device="cuda")
+    dout = torch.zeros((S, frame), dtype=torch.int16, device="cuda")
+    collected = torch.zeros_like(src_near)
+    ballast = torch.zeros(1 << 26, dtype=torch.float32, device="cuda")            # ~10 ms of fill work ahead of every row copy
+    producer, consumer = torch.cuda.Stream(), torch.cuda.Stream()
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    lib = aecm.load()
+    torch.cuda.synchronize()
+    consumed = None
+    for i in range(n_calls):
+        sl = slice(i * frame, (i + 1) * frame)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        done.record(consumer)                           # torch creates the hipEvent_t lazily, at the first record: the tick re-records it
+        assert done.cuda_event
+        with torch.cuda.stream(producer):
+            if consumed is not None:
+                producer.wait_event(consumed)              # the rows of the previous tick have been read and its output collected
+            ballast.add_(1.0)
+            dfar.copy_(src_far[:, sl])
+            dnear.copy_(src_near[:, sl])
+            ready.record(producer)
+        rc = lib.WebRtcAecmSessions_TickAsync(sb.h, dfar.data_ptr(), dnear.data_ptr(), None, dout.data_ptr(), frame, frame, 40, None, None,
+                                              None, ready.cuda_event, done.cuda_event)
+        assert rc == 0, (i, rc)
+        with torch.cuda.stream(consumer):
+            consumer.wait_event(done)
+            collected[:, sl].copy_(dout)
+            consumed = torch.cuda.Event()
+            consumed.record(consumer)
+    assert sb.synchronize() == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(collected.cpu().numpy(), exp)
+    sb.close()
