@@ -300,7 +300,7 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
     // the WHOLE tuple (16 v_writelane / v_readlane) around every use in another basic block.  Passing each word through an
     // empty asm makes them 16 independent scalars that are spilled one by one, and only where needed.
 #if AECM_TICK_SPLIT_PLAN_WORDS
-    for (int k = 0; k < kFlowPlanWords; ++k) asm volatile("" : "+s"(w[k]));
+    for (int k = 0; k < kFlowPlanWords; ++k) asm("" : "+s"(w[k]));      // not volatile: a volatile asm counts as a memory clobber and turns the engine's scalar state loads into vector loads
 #endif
     FlowPlan p;
     FlowUnpackPlan(w, p);
