@@ -57,6 +57,9 @@ extern __shared__ LdsTables g_lds[];   // one instance (dynamic LDS)
 #ifndef AECM_PHASE_PRIOS
 #define AECM_PHASE_PRIOS 0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 3, 3, 3, 3
 #endif
+#ifndef AECM_QUAD_EXCHANGE_SWIZZLE
+#define AECM_QUAD_EXCHANGE_SWIZZLE 1
+#endif
 #ifndef AECM_LANE_CONSTS_IN_LDS
 #define AECM_LANE_CONSTS_IN_LDS 1
 #endif
@@ -256,6 +259,15 @@ struct Gfx950Wave {
             const int nb = AECM_DPP(b, a, kDppRowShl4, 0xf, 0x5, false);   // banks 0,2 <- a of lane+4
             a = na;
             b = nb;
+        } else if constexpr (kFast && AECM_QUAD_EXCHANGE_SWIZZLE) {
+            // The two quad stages: DPP row / bank masks cannot tell the lanes of a pair apart, so the DPP form is two moves
+            // plus two selects.  ds_swizzle_b32 in quad-permute mode does the moves on the LDS crossbar (no LDS memory, no
+            // vector-ALU slot): two selects remain.  The LDS pipe is 25 % busy (profiles/r03_lds_conflicts.md).
+            const bool hi = (lane_id() >> Q) & 1;
+            const int pb = __builtin_amdgcn_ds_swizzle(b, 0x8000 | (Q == 0 ? kDppQuadXor1 : kDppQuadXor2));
+            const int pa = __builtin_amdgcn_ds_swizzle(a, 0x8000 | (Q == 0 ? kDppQuadXor1 : kDppQuadXor2));
+            a = hi ? pb : a;
+            b = hi ? b : pa;
         } else if constexpr (kFast) {
             const bool hi = (lane_id() >> Q) & 1;
             const int pb = AECM_DPP(0, b, Q == 0 ? kDppQuadXor1 : kDppQuadXor2, 0xf, 0xf, true);
