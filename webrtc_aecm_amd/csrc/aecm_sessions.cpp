@@ -151,7 +151,7 @@ int32_t SessionBatch::Fail() {
 
 int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
                               int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
-                              bool host_pointers, void *wait_event, void *done_event, bool *staged_out) {
+                              bool host_pointers, void *wait_event, void *done_event) {
     if (far == nullptr || near == nullptr || out == nullptr) return AECM_NULL_POINTER_ERROR;
     if (fs_ == 0) return AECM_UNINITIALIZED_ERROR;
     if (n_samples != 80 && n_samples != 160) return AECM_BAD_PARAMETER_ERROR;       // compared as size_t: 2^32 + 80 is not 80
@@ -243,7 +243,6 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
     }
     if (host_pointers && !copy_rows(out, (size_t)stride * 2, dout, (size_t)n * 2, hipMemcpyDeviceToHost)) return fail();
     if (done_event && !AECM_HIP_OK(hipEventRecord(static_cast<hipEvent_t>(done_event), st))) return fail();
-    if (staged_out) *staged_out = host_pointers;
     return first_rc;
 }
 
@@ -251,7 +250,7 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
                            int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
                            bool host_pointers) {
     const int32_t rc = Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, host_pointers,
-                               nullptr, nullptr, nullptr);
+                               nullptr, nullptr);
     if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) return rc;            // nothing was enqueued (or the object is poisoned)
     if (!AECM_HIP_OK(hipStreamSynchronize(engine_->stream()))) return Fail();
     return rc;
@@ -260,8 +259,7 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
 int32_t SessionBatch::TickAsync(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride,
                                 size_t n_samples, int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session,
                                 int32_t *codes, void *wait_event, void *done_event) {
-    return Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, false, wait_event, done_event,
-                   nullptr);
+    return Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, false, wait_event, done_event);
 }
 
 int32_t SessionBatch::Synchronize() {

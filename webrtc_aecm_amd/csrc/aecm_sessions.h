@@ -87,7 +87,7 @@ private:
     int slot_ = 0;
     int32_t Enqueue(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
                     int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers,
-                    void *wait_event, void *done_event, bool *staged_out);
+                    void *wait_event, void *done_event);
     int32_t Fail();
     int device_ = 0;
 };
