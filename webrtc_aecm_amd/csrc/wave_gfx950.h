@@ -283,52 +283,12 @@ struct Gfx950Wave {
         }
     }
 
-    // The same for the N transforms that advance in lock step.  For the two quad stages (lane bits 1 and 0) DPP row /
-    // bank masks cannot tell the two lanes of a pair apart, so exchange<Q> above needs two DPP moves and two selects per
-    // transform.  v_cndmask_b32 is a VOP2 instruction and takes a DPP source: with VCC = "lane bit Q clear"
-    //     a' = vcc ? a : quad_perm(b)        and, with VCC complemented,        b' = vcc ? b : quad_perm(a)
-    // -- two VALU instructions per transform; the mask moves (s_mov / s_not, shared by the N transforms) run on the
-    // scalar unit, the less loaded port.  The compiler never forms this (it keeps the mask in an SGPR pair and emits the
-    // VOP3 v_cndmask, which has no DPP form on gfx9), hence the assembly.  s_mov + s_nop are the two wait states a DPP
-    // read needs after a VALU write of its source (the hazard recognizer does not look inside inline assembly).
-#ifndef AECM_QUAD_EXCHANGE_DPP_SELECT
-#define AECM_QUAD_EXCHANGE_DPP_SELECT 0   // measured (r3): 828 vs 833 M frames/s -- the mask moves and the wait state cost more than the two VALU slots they free
-#endif
-#define AECM_QX_HEAD "s_mov_b64 vcc, %[m]\n\ts_nop 0\n\t"
-#define AECM_QX_A(i, QP) "v_cndmask_b32_dpp %[na" #i "], %[b" #i "], %[a" #i "], vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"
-#define AECM_QX_B(i, QP) "v_cndmask_b32_dpp %[nb" #i "], %[a" #i "], %[b" #i "], vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"
-#define AECM_QX_OUT(i) [na##i] "=&v"(na[i]), [nb##i] "=&v"(nb[i])
-#define AECM_QX_IN(i) [a##i] "v"(aa[i]), [b##i] "v"(bb[i])
-#define AECM_QX_ASM(QP)                                                                                                          \
-    if constexpr (N == 1)                                                                                                        \
-        asm(AECM_QX_HEAD AECM_QX_A(0, QP) "s_not_b64 vcc, vcc\n\t" AECM_QX_B(0, QP)                                               \
-            : AECM_QX_OUT(0) : AECM_QX_IN(0), [m] "s"(keep_a) : "vcc", "scc");                                                   \
-    else if constexpr (N == 2)                                                                                                   \
-        asm(AECM_QX_HEAD AECM_QX_A(0, QP) AECM_QX_A(1, QP) "s_not_b64 vcc, vcc\n\t" AECM_QX_B(0, QP) AECM_QX_B(1, QP)             \
-            : AECM_QX_OUT(0), AECM_QX_OUT(1) : AECM_QX_IN(0), AECM_QX_IN(1), [m] "s"(keep_a) : "vcc", "scc");                    \
-    else                                                                                                                         \
-        asm(AECM_QX_HEAD AECM_QX_A(0, QP) AECM_QX_A(1, QP) AECM_QX_A(2, QP) "s_not_b64 vcc, vcc\n\t" AECM_QX_B(0, QP)             \
-            AECM_QX_B(1, QP) AECM_QX_B(2, QP)                                                                                    \
-            : AECM_QX_OUT(0), AECM_QX_OUT(1), AECM_QX_OUT(2) : AECM_QX_IN(0), AECM_QX_IN(1), AECM_QX_IN(2), [m] "s"(keep_a)      \
-            : "vcc", "scc")
+    // The same for the N transforms that advance in lock step.  (A v_cndmask_b32_dpp form of the quad stages -- two VALU
+    // per transform, mask moves on the scalar unit -- was measured slower and removed: profiles/r03_experiments.md.)
     template <int Q, int N>
     static __device__ __forceinline__ void exchange_all(int (&aa)[N], int (&bb)[N]) {
-        if constexpr (kFast && AECM_QUAD_EXCHANGE_DPP_SELECT && Q <= 1 && N <= 3) {
-            const unsigned long long keep_a = Q == 0 ? 0x5555555555555555ull : 0x3333333333333333ull;   // lane bit Q clear
-            int na[N], nb[N];
-            if constexpr (Q == 0) { AECM_QX_ASM("[1,0,3,2]"); }
-            else { AECM_QX_ASM("[2,3,0,1]"); }
-            for (int n = 0; n < N; ++n) { aa[n] = na[n]; bb[n] = nb[n]; }
-        } else {
-            for (int n = 0; n < N; ++n) exchange<Q>(aa[n], bb[n]);
-        }
+        for (int n = 0; n < N; ++n) exchange<Q>(aa[n], bb[n]);
     }
-#undef AECM_QX_ASM
-#undef AECM_QX_IN
-#undef AECM_QX_OUT
-#undef AECM_QX_B
-#undef AECM_QX_A
-#undef AECM_QX_HEAD
 
     // ---- reductions: every lane of a 16-lane row gets the row result (4 DPP steps), then the rows are
     // chained with row_bcast15 / row_bcast31 into lane 63 and read back with one v_readlane.
