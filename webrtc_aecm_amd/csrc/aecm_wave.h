@@ -46,6 +46,12 @@
 #ifndef AECM_NOISE_TRACKING_FAST_PATH
 #define AECM_NOISE_TRACKING_FAST_PATH 1   // comfort noise: short update when every estimate is >= 2^11 (one wave-uniform test)
 #endif
+#ifndef AECM_NEAR_FILT_STEADY_PATH
+#define AECM_NEAR_FILT_STEADY_PATH 1      // Wiener gain: short nearFilt update when the block's Q domain did not rise (wave-uniform)
+#endif
+#ifndef AECM_NEAR_FILT_STEADY_PATH_TICK
+#define AECM_NEAR_FILT_STEADY_PATH_TICK 0      // tick kernel: 0.2495 ms with it, 0.2469 without (the duplicated Wiener body costs it scalar spills)
+#endif
 #ifndef AECM_NOISE_TRACKING_FAST_PATH_TICK
 #define AECM_NOISE_TRACKING_FAST_PATH_TICK 1
 #endif
@@ -132,6 +138,8 @@ struct BlockEngine {
     // kernel that then no longer fits its register budget (clean input + rotation: small launches only) keeps the long form.
     static constexpr bool kNoiseTrackingFastPath = AECM_NOISE_TRACKING_FAST_PATH && (W::kTight ? AECM_NOISE_TRACKING_FAST_PATH_TICK != 0 : true) &&
                                                    !(kHasClean && !W::kPhasePriority);
+
+    static constexpr bool kNearFiltSteadyPath = AECM_NEAR_FILT_STEADY_PATH && (W::kTight ? AECM_NEAR_FILT_STEADY_PATH_TICK != 0 : true);
 
     // Everything a wave keeps in registers across the blocks of one launch.
     struct Regs {
@@ -835,7 +843,36 @@ struct BlockEngine {
         if constexpr (kUni) return I(W::pin_uniform((int)x));
         else return x;
     }
-    template <class I, bool kUni = false>
+    // nearFilt of one bin (reference aecm/aecm_core_c.cc:552-579): the filter is brought to the block's Q domain and moved
+    // 1/16 of the way to the near-end magnitude.
+    // kQSteady: the caller has established dfaCleanQDomain <= dfaCleanQDomainOld (a wave-uniform fact; 94 % of the blocks of
+    // the bench signal, instrumented oracle).  Then "zeros16 < dq" (:554) is false for every bin (a norm is >= 0), qDomainDiff
+    // is 0, the old filter is shifted RIGHT by the uniform difference and the saturation test of :572 cannot fire: five
+    // instructions instead of twenty-five.
+    template <class I, bool kQSteady>
+    static AECM_HD void near_filt_update(BinState<I> &s, I dfa_clean, int clean_q, int clean_q_old) {
+        const int dqq = sext16(clean_q - clean_q_old);
+        if constexpr (kQSteady) {
+            const I t_a = as_i16(sar(s.near_filt, neg(dqq)));                                 // dqq in [-14, 0]
+            const I t_b = sext16(dfa_clean);                                                  // the reference's (int16_t) of the uint16 magnitude
+            s.near_filt = as_i16(as_i16(sar(sub(t_b, t_a), 4)) + t_a);                        // between t_a and t_b: no narrowing can change it
+            return;
+        }
+        // nearFilt == 0 reads as norm 15 here, which no Q-domain step (|dqq| <= 14) exceeds: the reference's
+        // "&& nearFilt" needs no test of its own.
+        I zn = norm_w16_nz(s.near_filt);
+        auto c = zn < dqq;
+        I a_else = sext16(shift_i31(s.near_filt, I(dqq)));
+        I q_diff = sel(c, zn - dqq, I(0));
+        I t_a = sel(c, sext16(shl(s.near_filt, zn)), a_else);
+        I t_b = sext16(lsr(dfa_clean, neg(q_diff)));                                          // q_diff == 0 unless c (then < 0)
+        t_b = sext16(sext16(sar(sub(t_b, t_a), 4)) + t_a);
+        I z2 = norm_w16_nz(t_b);                                                              // t_b == 0 has bit 0 clear: its norm does not matter
+        auto weird = (t_b & sel(neg(q_diff) > z2, I(1), I(0))) != 0;                           // :572 literally
+        s.near_filt = sel(weird, I(32767), sext16(shl(t_b, neg(q_diff))));                     // q_diff <= 0; a shift by 0 leaves the int16 t_b
+    }
+
+    template <class I, bool kUni = false, bool kQSteady = false>
     static AECM_HD I wiener_bin(BinState<I> &s, I echo_est, I dfa_clean, int sup_gain, int clean_q, int clean_q_old,
                                 int zeros_xbuf) {
         // echoFilt += ((int64)(echoEst - echoFilt) * 50) >> 8 (:523-525): the arithmetic shift of the 64-bit product is
@@ -860,19 +897,7 @@ struct BlockEngine {
         I rhs = sar(I(as_nonneg(sup_gain)), tpos - sh_l);
         I gained = mul(lhs, rhs);
 
-        // :552-579.  nearFilt == 0 reads as norm 15 here, which no Q-domain step (|dqq| <= 14) exceeds: the reference's
-        // "&& nearFilt" needs no test of its own.
-        I zn = norm_w16_nz(s.near_filt);
-        int dqq = sext16(clean_q - clean_q_old);
-        auto c = zn < dqq;
-        I a_else = sext16(shift_i31(s.near_filt, I(dqq)));
-        I q_diff = sel(c, zn - dqq, I(0));
-        I t_a = sel(c, sext16(shl(s.near_filt, zn)), a_else);
-        I t_b = sext16(lsr(dfa_clean, neg(q_diff)));                                          // q_diff == 0 unless c (then < 0)
-        t_b = sext16(sext16(sar(sub(t_b, t_a), 4)) + t_a);
-        I z2 = norm_w16_nz(t_b);                                                              // t_b == 0 has bit 0 clear: its norm does not matter
-        auto weird = (t_b & sel(neg(q_diff) > z2, I(1), I(0))) != 0;                           // :572 literally
-        s.near_filt = sel(weird, I(32767), sext16(shl(t_b, neg(q_diff))));                     // q_diff <= 0; a shift by 0 leaves the int16 t_b
+        near_filt_update<I, kQSteady>(s, dfa_clean, clean_q, clean_q_old);                    // :552-579
 
         I g2 = add(gained, sar(s.near_filt, 1));                                              // :582-611
         I quot;                                                                               // WebRtcSpl_DivU32U16 (:584); nearFilt == 0 is overridden below
@@ -1125,8 +1150,15 @@ struct BlockEngine {
         W::template phase_priority<8>();
         const int sup_gain = calc_suppression_gain(r);                                // :514
 
-        vi hnl = wiener_bin<vi>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
-        int hnl64 = wiener_bin<int, true>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+        vi hnl;
+        int hnl64;
+        if (AECM_STEADY_ALWAYS(AECM_LIKELY(kNearFiltSteadyPath && u.dfa_clean_q <= u.dfa_clean_q_old))) {      // see near_filt_update
+            hnl = wiener_bin<vi, false, true>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+            hnl64 = wiener_bin<int, true, true>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+        } else {
+            hnl = wiener_bin<vi>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+            hnl64 = wiener_bin<int, true>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+        }
         const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
 
         AECM_PHASE_MARK(8, hnl, r.b.near_filt);
