@@ -46,6 +46,12 @@
 #ifndef AECM_NOISE_TRACKING_FAST_PATH
 #define AECM_NOISE_TRACKING_FAST_PATH 1   // comfort noise: short update when every estimate is >= 2^11 (one wave-uniform test)
 #endif
+#ifndef AECM_GAIN_ZERO_PATH
+#define AECM_GAIN_ZERO_PATH 1             // supGain == 0 (wave-uniform): the spectrum passes through, only filters / estimator / seed move
+#endif
+#ifndef AECM_GAIN_ZERO_PATH_TICK
+#define AECM_GAIN_ZERO_PATH_TICK 1
+#endif
 #ifndef AECM_NEAR_FILT_STEADY_PATH
 #define AECM_NEAR_FILT_STEADY_PATH 1      // Wiener gain: short nearFilt update when the block's Q domain did not rise (wave-uniform)
 #endif
@@ -139,6 +145,7 @@ struct BlockEngine {
     static constexpr bool kNoiseTrackingFastPath = AECM_NOISE_TRACKING_FAST_PATH && (W::kTight ? AECM_NOISE_TRACKING_FAST_PATH_TICK != 0 : true) &&
                                                    !(kHasClean && !W::kPhasePriority);
 
+    static constexpr bool kGainZeroPath = AECM_GAIN_ZERO_PATH && (W::kTight ? AECM_GAIN_ZERO_PATH_TICK != 0 : true);
     static constexpr bool kNearFiltSteadyPath = AECM_NEAR_FILT_STEADY_PATH && (W::kTight ? AECM_NEAR_FILT_STEADY_PATH_TICK != 0 : true);
 
     // Everything a wave keeps in registers across the blocks of one launch.
@@ -872,13 +879,19 @@ struct BlockEngine {
         s.near_filt = sel(weird, I(32767), sext16(shl(t_b, neg(q_diff))));                     // q_diff <= 0; a shift by 0 leaves the int16 t_b
     }
 
-    template <class I, bool kUni = false, bool kQSteady = false>
+    // kGainZero: the caller has established supGain == 0 (wave-uniform).  Whatever the regime of :527-550 the gained echo
+    // estimate is then 0 and the gain ONE_Q14 (:582): only the two filters move.
+    template <class I, bool kUni = false, bool kQSteady = false, bool kGainZero = false>
     static AECM_HD I wiener_bin(BinState<I> &s, I echo_est, I dfa_clean, int sup_gain, int clean_q, int clean_q_old,
                                 int zeros_xbuf) {
         // echoFilt += ((int64)(echoEst - echoFilt) * 50) >> 8 (:523-525): the arithmetic shift of the 64-bit product is
         // the upper word of d * (50 << 24), one multiply-high
         I d = sub(echo_est, s.echo_filt);
         s.echo_filt = add(s.echo_filt, mulhi_i32(d, I(50 << 24)));
+        if constexpr (kGainZero) {
+            near_filt_update<I, kQSteady>(s, dfa_clean, clean_q, clean_q_old);                // :552-579
+            return I(kOneQ14);
+        }
 
         // echoFilt == 0: the product below is 0 whatever the regime and the gain is then ONE_Q14 (:582): its norm is never looked at
         I zeros32 = norm_w32_nz(s.echo_filt) + 1;                                             // :527-550
@@ -923,7 +936,9 @@ struct BlockEngine {
     // estimator has found a noise floor: 2^11 in its Q15-like domain is 1/16 of an LSB of the spectrum).  Then neither
     // "small estimate" rule (:88-98 the decrement every 5th block below 2^minTrackShift <= 2^9, :117-125 the slow
     // increment below 2^11) can fire, which leaves one select between the tracking step down and the 1/2048 step up.
-    template <class I, bool kTracking = false>
+    // kSilent: the caller has established that the gain of every bin is ONE_Q14: the noise amplitude (ONE_Q14 - hnl) * est is 0
+    // whatever the estimate (:142-147), so only the estimator moves and u_re, u_im are left alone.
+    template <class I, bool kTracking = false, bool kSilent = false>
     static AECM_HD void noise_bin(BinState<I> &s, I dfa, I hnl, I rnd, I gate, int shift_n, int min_track, I &u_re, I &u_im) {
         I in = shl(dfa, shift_n);                                                             // :81-127
         auto lt = in < s.noise_est;
@@ -956,11 +971,49 @@ struct BlockEngine {
         auto clamp = t32 > 32767;
         t32 = sel(clamp, I(32767), t32);
         s.noise_est = sel(clamp, shl(I(32767), shift_n), ne);
+        if constexpr (kSilent) return;
         I n16 = as_i16(sar(mul24(as_i16(I(kOneQ14) - hnl), as_i16(t32)), 14));               // 0 <= hnl <= 2^14, 0 <= t32 <= 32767
         n16 = n16 & gate;                                                                     // bin 0 gets no comfort noise (:146-147): one mask instead of two selects
         I idx = as_i16(sar(mul24(I(359), rnd), 15));                                            // :150
         u_re = as_i16(sar(mul24(n16, W::cos360(idx)), 13));     /* |cos|, |sin| <= 2^13 */                                     // :153-156
         u_im = as_i16(sar(mul24(neg(n16), W::sin360(idx)), 13));
+    }
+
+    // ComfortNoise of the block (:52-164, called at :702-705) added to the suppressed spectrum (e_re, e_im | e_re64, e_im64).
+    // kSilent: every gain is ONE_Q14, see noise_bin.
+    template <bool kSilent>
+    static AECM_HD void comfort_noise(Regs &r, const Spectrum &clean, vi hnl, int hnl64, vi &e_re, vi &e_im, int &e_re64, int &e_im64) {
+        Uniform &u = r.u;
+        int shift_n = sext16(15 - u.dfa_clean_q);
+        int min_track = 9;
+        if (AECM_STEADY_NEVER(u.noise_ctr < 100)) { u.noise_ctr = sext16(u.noise_ctr + 1); min_track = 6; }
+        // LCG jump-ahead: lane t gets the t-th of this block's 64 draws
+        vi rnd = vi(0);
+        int s64 = add(mul(r.lcg_mul64, u.seed), r.lcg_add64) & 0x7fffffff;
+        if constexpr (!kSilent) {
+            vi st = add(mul(lane_const<LC_LCG_MUL>(r), vi(u.seed)), lane_const<LC_LCG_ADD>(r)) & 0x7fffffff;
+            rnd = as_i16(lsr(st, 16));                                              // st < 2^31
+        }
+        int rnd64 = sext16(lsr(s64, 16));
+        u.seed = s64;
+        vi u_re = vi(0), u_im = vi(0);
+        int u_re64 = 0, u_im64 = 0;
+        // every estimate at or above 2^11: the short form of the update (see noise_bin)
+        const vi gate = lane_const<LC_NOT_BIN0>(r);                                    // 0 in lane 0, all ones elsewhere
+        const bool tracking = kNoiseTrackingFastPath && (W::ballot(r.b.noise_est > vi(2047)) == ~0ull) & (r.b64.noise_est > 2047);
+        if (AECM_STEADY_ALWAYS(AECM_LIKELY(tracking))) {
+            noise_bin<vi, true, kSilent>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
+            noise_bin<int, true, kSilent>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
+        } else {
+            noise_bin<vi, false, kSilent>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
+            noise_bin<int, false, kSilent>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
+        }
+        if constexpr (kSilent) return;
+        u_im64 = 0;                                                                   // :158
+        e_re = sat16(e_re + u_re);                                                    // :160-163
+        e_im = sat16(e_im + u_im);
+        e_re64 = sat16(e_re64 + u_re64);
+        e_im64 = sat16(e_im64 + u_im64);
     }
 
     // ------------------------------------------------------------------------------------------
@@ -1150,9 +1203,29 @@ struct BlockEngine {
         W::template phase_priority<8>();
         const int sup_gain = calc_suppression_gain(r);                                // :514
 
+        vi e_re, e_im;
+        int e_re64, e_im64 = 0;
+        const bool q_steady = kNearFiltSteadyPath && u.dfa_clean_q <= u.dfa_clean_q_old;     // see near_filt_update
+        if (AECM_STEADY_NEVER(kGainZeroPath && sup_gain == 0)) {
+            // No suppression at all: supGain has decayed to 0 (the far end has been silent for a while; 31 % of the blocks of
+            // the bench signal, instrumented oracle).  Every gain is ONE_Q14 (see wiener_bin), which its square >> 14, the
+            // average of the preferred band, the NLP thresholds (65 non-zero gains) and the rounded product with dfw
+            // (:618-686) all leave as it is, and the comfort noise has amplitude 0 (see noise_bin): the spectrum passes through,
+            // the filters, the noise estimator and the random seed move as in any other block.
+            if (AECM_LIKELY(q_steady)) {
+                wiener_bin<vi, false, true, true>(r.b, echo_est, clean.mag, 0, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+                wiener_bin<int, true, true, true>(r.b64, echo_est64, clean.mag64, 0, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+            } else {
+                wiener_bin<vi, false, false, true>(r.b, echo_est, clean.mag, 0, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+                wiener_bin<int, true, false, true>(r.b64, echo_est64, clean.mag64, 0, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
+            }
+            e_re = clean.re; e_im = clean.im; e_re64 = clean.re64;
+            if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1))
+                comfort_noise<true>(r, clean, vi(kOneQ14), kOneQ14, e_re, e_im, e_re64, e_im64);
+        } else {
         vi hnl;
         int hnl64;
-        if (AECM_STEADY_ALWAYS(AECM_LIKELY(kNearFiltSteadyPath && u.dfa_clean_q <= u.dfa_clean_q_old))) {      // see near_filt_update
+        if (AECM_STEADY_ALWAYS(AECM_LIKELY(q_steady))) {
             hnl = wiener_bin<vi, false, true>(r.b, echo_est, clean.mag, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
             hnl64 = wiener_bin<int, true, true>(r.b64, echo_est64, clean.mag64, sup_gain, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
         } else {
@@ -1179,41 +1252,14 @@ struct BlockEngine {
             hnl64 = hnl64 < kNlpCompLow ? 0 : hnl64;
             if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
         }
-        vi e_re = as_i16(sar(mul24(clean.re, hnl) + 8192, 14));      // |re| <= 2^15, 0 <= hnl <= 2^14                         // :680-685
-        vi e_im = as_i16(sar(mul24(clean.im, hnl) + 8192, 14));
-        int e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
-        int e_im64 = 0;
+        e_re = as_i16(sar(mul24(clean.re, hnl) + 8192, 14));      // |re| <= 2^15, 0 <= hnl <= 2^14                         // :680-685
+        e_im = as_i16(sar(mul24(clean.im, hnl) + 8192, 14));
+        e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
 
         AECM_PHASE_MARK(9, e_re, e_im);
         W::template phase_priority<10>();
-        if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1)) {                           // :702-705
-            int shift_n = sext16(15 - u.dfa_clean_q);
-            int min_track = 9;
-            if (AECM_STEADY_NEVER(u.noise_ctr < 100)) { u.noise_ctr = sext16(u.noise_ctr + 1); min_track = 6; }
-            // LCG jump-ahead: lane t gets the t-th of this block's 64 draws
-            vi st = add(mul(lane_const<LC_LCG_MUL>(r), vi(u.seed)), lane_const<LC_LCG_ADD>(r)) & 0x7fffffff;
-            int s64 = add(mul(r.lcg_mul64, u.seed), r.lcg_add64) & 0x7fffffff;
-            vi rnd = as_i16(lsr(st, 16));                                           // st < 2^31
-            int rnd64 = sext16(lsr(s64, 16));
-            u.seed = s64;
-            vi u_re, u_im;
-            int u_re64, u_im64;
-            // every estimate at or above 2^11: the short form of the update (see noise_bin)
-            const vi gate = lane_const<LC_NOT_BIN0>(r);                                // 0 in lane 0, all ones elsewhere
-            const bool tracking = kNoiseTrackingFastPath && (W::ballot(r.b.noise_est > vi(2047)) == ~0ull) & (r.b64.noise_est > 2047);
-            if (AECM_STEADY_ALWAYS(AECM_LIKELY(tracking))) {
-                noise_bin<vi, true>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
-                noise_bin<int, true>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
-            } else {
-                noise_bin<vi>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
-                noise_bin<int>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
-            }
-
-            u_im64 = 0;                                                               // :158
-            e_re = sat16(e_re + u_re);                                                // :160-163
-            e_im = sat16(e_im + u_im);
-            e_re64 = sat16(e_re64 + u_re64);
-            e_im64 = sat16(e_im64 + u_im64);
+        if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1))                             // :702-705
+            comfort_noise<false>(r, clean, hnl, hnl64, e_re, e_im, e_re64, e_im64);
         }
 
         AECM_PHASE_MARK(10, e_re, e_im);
