@@ -68,11 +68,13 @@ def test_block_kernel_register_budget(tmp_path):
     import re
     import subprocess
     from webrtc_aecm_amd import build
-    out = tmp_path / "kernels.s"
     flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    subprocess.check_call([build._hipcc(), *flags, "-S", "--cuda-device-only", f"-I{build.CSRC}", str(build.CSRC / "aecm_kernels.hip"),
-                           "-o", str(out)], stderr=subprocess.DEVNULL)
-    text = out.read_text()
+    text = ""
+    for src in build.KERNEL_SOURCES:                      # each unit with the flags the build gives it
+        out = tmp_path / (src + ".s")
+        subprocess.check_call([build._hipcc(), *flags, *build.SOURCE_FLAGS.get(src, []), "-S", "--cuda-device-only", f"-I{build.CSRC}",
+                               str(build.CSRC / src), "-o", str(out)], stderr=subprocess.DEVNULL)
+        text += out.read_text()
     for has_clean, phase_prio in (("0", "1"), ("1", "1"), ("0", "0"), ("1", "0")):     # <fast, clean, issue priority by phase>
         m = re.search(r"^_ZN4aecm19aecm_process_kernelILb1ELb%sELb%sEEE\w*:.*\n" % (has_clean, phase_prio), text, re.M)
         assert m, "fast block kernel not found in the device assembly"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction census of the block kernel by phase.
 
-Compiles csrc/aecm_kernels.hip for gfx950 with -DAECM_MARKERS (comment markers at the phase
+Compiles csrc/aecm_block_kernels.hip (with its build flags) for gfx950 with -DAECM_MARKERS (comment markers at the phase
 boundaries of BlockEngine::process_block, see aecm_wave.h) and counts VALU / SALU / LDS / VMEM
 instructions between consecutive markers inside the steady-state block loop of
 aecm_process_kernel<true,false>.  The marker build perturbs scheduling slightly (markers are
@@ -54,8 +54,9 @@ def main():
         ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "k.s"
-        cmd = ["/opt/rocm/bin/hipcc", *flags, *a.extra.split(), *(["-DAECM_CENSUS_HOTPATH"] if a.hot else []), "-DAECM_MARKERS", "-S", "--cuda-device-only",
-               f"-I{CSRC}", str(CSRC / "aecm_kernels.hip"), "-o", str(out)]
+        src = "aecm_block_kernels.hip"
+        cmd = ["/opt/rocm/bin/hipcc", *flags, *B.SOURCE_FLAGS.get(src, []), *a.extra.split(), *(["-DAECM_CENSUS_HOTPATH"] if a.hot else []), "-DAECM_MARKERS",
+               "-S", "--cuda-device-only", f"-I{CSRC}", str(CSRC / src), "-o", str(out)]
         subprocess.check_call(cmd)
         text = out.read_text()
         if a.dump:

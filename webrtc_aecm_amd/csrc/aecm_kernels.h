@@ -1,4 +1,4 @@
-// Launchers of the gfx950 kernels (aecm_kernels.hip).  Host-callable, HIP runtime types only.
+// Launchers of the gfx950 kernels (aecm_block_kernels.hip, aecm_kernels.hip).  Host-callable, HIP runtime types only.
 #ifndef AECM_AMD_KERNELS_H_
 #define AECM_AMD_KERNELS_H_
 
@@ -95,6 +95,8 @@ hipError_t LaunchFft128(int16_t *data_dev, int32_t *scales_dev, int variant, int
 // the device since the last reset -- [0] mul24 operands, [1] as_i16 arguments (aecm_ops.h).  Synchronises the
 // device.  hipErrorNotSupported in the shipped build, whose kernels carry no checks.
 hipError_t ReadCheckCounters(uint64_t counters[2], bool reset);
+// The share of aecm_block_kernels.hip (device symbols are per translation unit); ReadCheckCounters adds it in.  Does not synchronise.
+hipError_t ReadBlockKernelCheckCounters(uint64_t counters[2], bool reset);
 
 // Device self test of the wave primitives; counters[0..7] are failure counts (all must be 0):
 //  0 shfl_xor, 1 exchange, 2 reduce_max/min/add, 3 shift_up1, 4 bpermute/readlane/writelane, 5 ballot,

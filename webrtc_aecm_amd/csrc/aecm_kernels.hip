@@ -1,20 +1,9 @@
-// gfx950 kernels of the MI355X AECM engine.
-//
-// aecm_process_kernel: one wavefront per stream, 4 streams per 256-thread workgroup.  The whole
-// persistent state of a stream (~40 lane vectors + ~50 scalars) is loaded into registers once,
-// n_blocks blocks are processed back to back (WebRtcAecm_ProcessBlock-equivalents, aecm_wave.h),
-// and the state is written back once.  Per block a wave touches 3 x 128 B of audio I/O (prefetched
-// one block ahead), writes one 128-byte far-spectrum row and reads at most one.  The constant
-// tables (FFT twiddles, comfort-noise cos/sin, sqrt-Hanning) are staged in LDS by the prologue.
-// No MFMA: nothing here is a dense contraction.
+// gfx950 kernels of the MI355X AECM engine other than the block kernels (aecm_block_kernels.hip): state maintenance,
+// the session schedule's gather / scatter, the streaming-session tick kernels, the device self-test.
 #define AECM_TABLE_ATTR __device__
-#include "aecm_kernels.h"
-
 #include <initializer_list>
 
-#include "aecm_tables.h"
-#include "aecm_wave.h"
-#include "wave_gfx950.h"
+#include "aecm_kernel_common.h"
 
 namespace aecm {
 
@@ -29,8 +18,11 @@ hipError_t ReadCheckCounters(uint64_t counters[2], bool reset) {
     unsigned long long host[2] = {0, 0};
     e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_aecm_check_fail), sizeof host);
     if (e != hipSuccess) return e;
-    counters[0] = host[0];
-    counters[1] = host[1];
+    uint64_t blocks[2] = {0, 0};
+    e = ReadBlockKernelCheckCounters(blocks, reset);       // the block kernels' unit keeps its own pair
+    if (e != hipSuccess) return e;
+    counters[0] = host[0] + blocks[0];
+    counters[1] = host[1] + blocks[1];
     if (reset) {
         const unsigned long long zero[2] = {0, 0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_aecm_check_fail), zero, sizeof zero);
@@ -41,100 +33,6 @@ hipError_t ReadCheckCounters(uint64_t counters[2], bool reset) {
     (void)reset;
     return hipErrorNotSupported;
 #endif
-}
-
-// The LDS tables are an image inside the host-built constants blob: one coalesced copy per workgroup.
-// kThreads = the workgroup size, a compile-time constant: the copy loop then needs nothing from the dispatch packet (a
-// scalar load whose wait would also hold up every other scalar load in flight at kernel entry).
-template <int kThreads>
-__device__ __forceinline__ void FillLdsTables(const uint32_t *consts) {
-    static_assert(kConstBlobWords % 4 == 0, "the constants blob is copied 16 bytes at a time");
-    constexpr int kVecs = kConstBlobWords / 4, kPasses = (kVecs + kThreads - 1) / kThreads;
-    const int4 *src = reinterpret_cast<const int4 *>(consts);
-    int4 *dst = reinterpret_cast<int4 *>(&g_lds[0]);
-    int4 tmp[kPasses];                                   // every load in flight before the first LDS store
-    // Indices are clamped instead of predicated (the last vector is then copied by several threads, harmlessly): with
-    // predicates the compiler sinks each load next to its store and the passes wait for each other.
-#pragma unroll
-    for (int k = 0; k < kPasses; ++k) {
-        const int i = (int)threadIdx.x + k * kThreads;
-        tmp[k] = src[i < kVecs ? i : kVecs - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < kPasses; ++k) {
-        const int i = (int)threadIdx.x + k * kThreads;
-        dst[i < kVecs ? i : kVecs - 1] = tmp[k];
-    }
-    __syncthreads();
-}
-
-// Occupancy target: the kernel is bound by instruction issue with every wave strictly in order, so
-// resident waves are what hides one wave's latencies from the VALU port.  7 waves/SIMD = 72 VGPRs; the
-// fast variants need 68 / 71 (no spills).  Measured: 5 -> 6 -> 7 waves = 609 -> 657 -> 674 M frames/s;
-// 8 waves (64 VGPRs) fit without spills under the default scheduler but cost 3 % more instructions: 668 M.
-#ifndef AECM_WAVES_PER_EU
-#if defined(AECM_CHECKED)
-#define AECM_WAVES_PER_EU 4       // the audit build's checks need registers; its speed does not matter
-#else
-#define AECM_WAVES_PER_EU 7
-#endif
-#endif
-#ifndef AECM_MAX_WAVES_PER_EU
-#define AECM_MAX_WAVES_PER_EU 8
-#endif
-// The rotation variants only ever run launches of at most kRotationWavesPerEu waves per SIMD (LaunchProcessBlocks): they
-// are built for that occupancy and get the larger register budget (80 VGPRs) that goes with it.
-#ifndef AECM_ROTATION_WAVES_PER_EU
-#if defined(AECM_CHECKED)
-#define AECM_ROTATION_WAVES_PER_EU 4
-#else
-#define AECM_ROTATION_WAVES_PER_EU 6
-#endif
-#endif
-template <bool kFast, bool kHasClean, bool kPhasePrio = true>
-__global__ __launch_bounds__(64 * kWavesPerWorkgroup)
-__attribute__((amdgpu_waves_per_eu(kPhasePrio ? AECM_WAVES_PER_EU : AECM_ROTATION_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
-void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, const int32_t *blocks_per_stream) {
-    FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t stream = (int64_t)blockIdx.x * kWavesPerWorkgroup + wave;
-    if (stream >= n_streams) return;
-    if (blocks_per_stream) {
-        n_blocks = __builtin_amdgcn_readfirstlane(blocks_per_stream[stream]);
-        if (n_blocks <= 0) return;
-    }
-    BlockEngine<Gfx950Wave<kFast, kPhasePrio>, kHasClean>::run_stream(st, io, stream, n_blocks);
-}
-
-hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
-                               hipStream_t stream, const int32_t *blocks_per_stream) {
-    if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
-    const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup);
-    const dim3 block(64 * kWavesPerWorkgroup);
-    const size_t lds = sizeof(LdsTables);
-    const bool clean = io.near_clean != nullptr;
-    // Issue priority by phase of the block when the launch is more waves than the chip holds at once (they then run in
-    // rounds and spread over the phases by themselves), the per-block rotation when every wave of the launch is resident
-    // from the start and they would otherwise march in lock step (wave_gfx950.h: kPhasePrio).
-    static int resident_waves[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (resident_waves[dev] == 0) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        resident_waves[dev] = cus * 4 * AECM_ROTATION_WAVES_PER_EU;
-    }
-    const bool phase = n_streams > resident_waves[dev];
-#define AECM_LAUNCH(F, C, P) hipLaunchKernelGGL((aecm_process_kernel<F, C, P>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream)
-    if (variant == kVariantFast) {
-        if (clean) { if (phase) AECM_LAUNCH(true, true, true); else AECM_LAUNCH(true, true, false); }
-        else { if (phase) AECM_LAUNCH(true, false, true); else AECM_LAUNCH(true, false, false); }
-    } else {
-        if (clean) AECM_LAUNCH(false, true, false);
-        else AECM_LAUNCH(false, false, false);
-    }
-#undef AECM_LAUNCH
-    return hipGetLastError();
 }
 
 // ---- state maintenance ---------------------------------------------------------------------------

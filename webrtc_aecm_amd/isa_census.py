@@ -60,7 +60,7 @@ def _base(mnemonic: str):
 
 
 def disassemble(lib_path) -> str:
-    """Disassembly text of the gfx950 code object bundled in the shared library."""
+    """Disassembly text of the gfx950 code objects bundled in the shared library (one per kernel translation unit)."""
     lib_path = Path(lib_path)
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td) / lib_path.name
@@ -70,7 +70,8 @@ def disassemble(lib_path) -> str:
         objs = sorted(Path(td).glob(tmp.name + ".*amdgcn*gfx950*"))
         if not objs:
             raise RuntimeError(f"no gfx950 code object found in {lib_path}")
-        return subprocess.run([_tool("llvm-objdump"), "-d", str(objs[0])], check=True, capture_output=True, text=True).stdout
+        return "\n".join(subprocess.run([_tool("llvm-objdump"), "-d", str(o)], check=True, capture_output=True, text=True).stdout
+                         for o in objs)
 
 
 def census_of_text(text: str):
