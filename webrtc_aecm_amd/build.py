@@ -21,9 +21,11 @@ CLI = LIB_DIR / "aecm_run"
 KERNEL_SOURCES = ["aecm_block_kernels.hip", "aecm_kernels.hip"]
 HOST_SOURCES = ["aecm_engine.cpp", "aecm_session.cpp", "aecm_schedule.cpp", "aecm_sessions.cpp", "aecm_capi.cpp", "aecm_host_state.cpp"]
 SOURCES = KERNEL_SOURCES + HOST_SOURCES
-# Per-source flags.  The block kernels branch on wave-uniform conditions only; leaving those regions unstructurized is
-# worth +6 % on them (aecm_block_kernels.hip) and costs the tick kernel 14 % -- which is why they are separate units.
-SOURCE_FLAGS = {"aecm_block_kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions"]}
+# Per-source flags.  The kernels branch on wave-uniform conditions only; leaving those regions unstructurized is worth +6 %
+# on the block kernels and, at 7 waves per SIMD, 4 % on the tick kernel (profiles/r03_experiments.md section 7).  Two units:
+# they compile in parallel, and the flags of one can be changed without the other (tools/ab_build.py name:source=flags).
+UNIFORM_BRANCH_FLAGS = ["-mllvm", "-structurizecfg-skip-uniform-regions"]
+SOURCE_FLAGS = {"aecm_block_kernels.hip": UNIFORM_BRANCH_FLAGS, "aecm_kernels.hip": UNIFORM_BRANCH_FLAGS}
 # max-ilp machine scheduling measured +1.7 % on the VALU-bound block kernel (MI355X, 65 536 streams)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-shared",
                "-mllvm", "-amdgpu-sched-strategy=max-ilp"]

@@ -6,12 +6,12 @@
 // at most one.  The constant tables (FFT twiddles, comfort-noise cos/sin, sqrt-Hanning) are staged in LDS by the prologue.
 // No MFMA: nothing here is a dense contraction.
 //
-// A translation unit of its own because it is compiled with -mllvm -structurizecfg-skip-uniform-regions (build.py:
-// SOURCE_FLAGS).  Every branch of the block loop is wave-uniform (scalar conditions); the structurizer otherwise
-// rewrites each if / else into guarded single-entry regions joined by flow blocks -- extra scalar mask logic, extra
-// branches and duplicated code that the nested data-dependent short paths of aecm_wave.h multiply: 3294 -> 2933
-// instructions in the kernel, 928 -> 983 M frames/s (profiles/r03_experiments.md section 7).  The tick kernel
-// (aecm_kernels.hip) loses with the same flag (its scalar registers spill: 0.242 -> 0.275 ms per tick), hence two units.
+// Compiled with -mllvm -structurizecfg-skip-uniform-regions (build.py: SOURCE_FLAGS).  Every branch of the block loop is
+// wave-uniform (scalar conditions); the structurizer otherwise rewrites each if / else into guarded single-entry regions
+// joined by flow blocks -- extra scalar mask logic, extra branches and duplicated code that the nested data-dependent
+// short paths of aecm_wave.h multiply: 3294 -> 2933 instructions in the kernel, 928 -> 983 M frames/s
+// (profiles/r03_experiments.md section 7).  A translation unit of its own so that it compiles next to the tick kernels'
+// unit (aecm_kernels.hip) and its flags can be tried separately.
 #define AECM_TABLE_ATTR __device__
 #if defined(AECM_CHECKED)
 #define g_aecm_check_fail g_aecm_check_fail_blocks      // device symbols are per translation unit (no relocatable device code)

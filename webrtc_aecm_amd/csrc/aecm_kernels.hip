@@ -176,7 +176,10 @@ void aecm_flow_plan_kernel(TickFlowIo fio, int n, unsigned near_pos, int n_strea
 #if defined(AECM_CHECKED)
 #define AECM_TICK_FLOW_WAVES_PER_EU 4
 #else
-#define AECM_TICK_FLOW_WAVES_PER_EU 8
+// 7, not 8: the scalar budget of 8 waves per SIMD (78) costs this kernel hundreds of scalar spills; at 94 it has 52.  With the
+// uniform regions left unstructurized (build.py): 8 waves 0.272 ms per tick of 65 536 sessions, 7 waves 0.234, 6 waves 0.237
+// (default pipeline: 0.241 at 8 waves, its best).
+#define AECM_TICK_FLOW_WAVES_PER_EU 7
 #endif
 #endif
 constexpr int kTickFlowWaves = AECM_TICK_FLOW_WAVES;

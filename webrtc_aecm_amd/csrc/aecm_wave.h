@@ -56,7 +56,7 @@
 #define AECM_NEAR_FILT_STEADY_PATH 1      // Wiener gain: short nearFilt update when the block's Q domain did not rise (wave-uniform)
 #endif
 #ifndef AECM_NEAR_FILT_STEADY_PATH_TICK
-#define AECM_NEAR_FILT_STEADY_PATH_TICK 0      // tick kernel: 0.2495 ms with it, 0.2469 without (the duplicated Wiener body costs it scalar spills)
+#define AECM_NEAR_FILT_STEADY_PATH_TICK 1      // tick kernel at 7 waves per SIMD, unstructurized uniform regions: 0.2306 ms with it, 0.2346 without
 #endif
 #ifndef AECM_NOISE_TRACKING_FAST_PATH_TICK
 #define AECM_NOISE_TRACKING_FAST_PATH_TICK 1
@@ -69,7 +69,7 @@
 #define AECM_IFFT_GROUPED_SCALE_TESTS 2
 #endif
 #ifndef AECM_IFFT_GROUPED_SCALE_TESTS_TICK
-#define AECM_IFFT_GROUPED_SCALE_TESTS_TICK 1   // tick kernel (64 VGPRs), ms per tick at 65 536 sessions: 0 0.2682, 1 0.2649, 2 0.2668
+#define AECM_IFFT_GROUPED_SCALE_TESTS_TICK 2   // tick kernel, ms per tick at 65 536 sessions: 1 0.2306, 2 0.2299
 #endif
 #ifndef AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN
 #define AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN 2
