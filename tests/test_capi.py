@@ -87,8 +87,8 @@ def test_block_kernel_register_budget(tmp_path):
         assert vgprs <= (72 if phase_prio == "1" else 80) and scratch == 0, (has_clean, phase_prio, vgprs, scratch)
     # The tick kernel: the engine's 64 scalar state words must arrive through scalar loads.  A conditional fence, or a
     # store wider than the rings' int16 (vector types alias everything), ahead of load_state silently turns them into
-    # vector loads + v_readfirstlane (profiles/r02_experiments.md).  The only 16-byte vector loads it may contain are the
-    # three of the LDS table fill.
+    # vector loads + v_readfirstlane (profiles/r02_experiments.md).  The only 16-byte vector loads it may contain are those
+    # of the LDS table fill (20 KB by the 256 threads of a 4-session workgroup: six).
     for has_clean in ("0", "1"):
         m = re.search(r"^_ZN4aecm21aecm_tick_flow_kernelILb%sEEE\w*:.*\n" % has_clean, text, re.M)
         assert m, "tick kernel not found in the device assembly"
@@ -96,7 +96,7 @@ def test_block_kernel_register_budget(tmp_path):
         body = body[:body.index(".end_amdhsa_kernel")]
         wide_loads = len(re.findall(r"^\s*global_load_dwordx4", body, re.M))
         scalar_loads = len(re.findall(r"^\s*s_load_", body, re.M))
-        assert wide_loads <= 3 and scalar_loads >= 14, (has_clean, wide_loads, scalar_loads)
+        assert wide_loads <= 6 and scalar_loads >= 14, (has_clean, wide_loads, scalar_loads)
 
 
 def test_forwarder_header_and_unmodified_reference_caller_links():

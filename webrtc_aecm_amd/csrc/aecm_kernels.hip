@@ -161,13 +161,13 @@ void aecm_flow_plan_kernel(TickFlowIo fio, int n, unsigned near_pos, int n_strea
     for (int q = 0; q < kFlowPlanWords / 4; ++q) dst[q] = make_int4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
-// Sessions per workgroup and occupancy target of the tick kernel.  A tick is only 2-3 blocks per session, so the 20 KB
-// table fill of the prologue and the launch's tail are a visible share of it: 8 sessions per workgroup halve the fills
-// of 4, and the kernel's I/O state lives in scalar registers, so it fits 64 VGPRs = 8 waves per SIMD (4 such workgroups
-// per CU).  Measured, 65 536 sessions (profiles/r02_experiments.md): 4 sessions / 7 waves 0.339 ms per tick, 8 / 7:
-// 0.324, 4 / 8: 0.323, 8 / 8: 0.306, 16 / 8: 0.312 (with the earlier, host-planned tick kernel; re-checked with this one).
+// Sessions per workgroup of the tick kernel.  A workgroup's waves are placed together, n / 4 per SIMD: with the 7 waves
+// per SIMD the kernel is built for (below), 8-wave workgroups can only ever fill 6 of the 7 slots, 4-wave workgroups all
+// of them -- at the price of one 20 KB table fill (from L2) per 4 sessions instead of per 8.  Measured, 65 536 sessions,
+// ms per tick: 8 sessions 0.2356, 4 sessions 0.2251, 2 sessions 0.3153.  (Round 2, at 8 waves per SIMD, 8 per
+// workgroup was the better size: profiles/r02_experiments.md.)
 #ifndef AECM_TICK_FLOW_WAVES
-#define AECM_TICK_FLOW_WAVES 8
+#define AECM_TICK_FLOW_WAVES 4
 #endif
 #ifndef AECM_TICK_SPLIT_PLAN_WORDS
 #define AECM_TICK_SPLIT_PLAN_WORDS 1
