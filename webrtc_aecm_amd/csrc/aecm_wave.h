@@ -136,7 +136,7 @@ struct BlockEngine {
     using vb = typename W::vb;
 
     // Joint scaling tests of the inverse transform (fft128): per kernel family, because the duplicated stage bodies cost
-    // registers (the tick kernel runs at 64 VGPRs).
+    // registers.
     static constexpr int kIfftGroupedTests = kHasClean ? AECM_IFFT_GROUPED_SCALE_TESTS_CLEAN
                                              : W::kTight ? AECM_IFFT_GROUPED_SCALE_TESTS_TICK : AECM_IFFT_GROUPED_SCALE_TESTS;
 

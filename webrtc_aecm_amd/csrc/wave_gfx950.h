@@ -87,8 +87,10 @@ extern "C" __device__ int aecm_llvm_amdgcn_writelane(int value, int lane, int ol
 // picks it for launches of more waves than the chip holds at once (measured, M frames/s, phase priority vs rotation:
 // 65 536 streams 893 vs 841, 16 384 streams 827 vs 799, 8 kHz 878 vs 841, with a clean input 779 vs 746; but 4 096
 // streams -- fewer waves than the chip has slots, all running in lock step -- 673 vs 697) and for session ticks (0.267 vs 0.270 ms).
-// kTightRegisters: the kernel instantiating this policy runs at 64 VGPRs (the tick kernel, 8 waves per SIMD): code-size for
-// register trades (the inverse transform's joint scaling tests) are taken or not by AECM_IFFT_GROUPED_SCALE_TESTS_TICK.
+// kTightRegisters: the kernel instantiating this policy has little register headroom (the tick kernel, whose I/O plan lives in
+// scalar registers next to the engine's): the code-size-for-registers trades of aecm_wave.h (joint scaling tests of the inverse
+// transform, the data-dependent short paths) are switched by their own AECM_*_TICK macros there.  At present all of them
+// are on in every kernel family.
 template <bool kFast, bool kPhasePrio = true, bool kTightRegisters = false>
 struct Gfx950Wave {
     static constexpr bool kTight = kTightRegisters;
