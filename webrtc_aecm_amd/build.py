@@ -25,7 +25,12 @@ SOURCES = KERNEL_SOURCES + HOST_SOURCES
 # on the block kernels and, at 7 waves per SIMD, 4 % on the tick kernel (profiles/r03_experiments.md section 7).  Two units:
 # they compile in parallel, and the flags of one can be changed without the other (tools/ab_build.py name:source=flags).
 UNIFORM_BRANCH_FLAGS = ["-mllvm", "-structurizecfg-skip-uniform-regions"]
-SOURCE_FLAGS = {"aecm_block_kernels.hip": UNIFORM_BRANCH_FLAGS, "aecm_kernels.hip": UNIFORM_BRANCH_FLAGS}
+# The block kernels also keep their (wave-uniform) branches as branches: no folding of two-entry phis into selects, no
+# speculative hoisting out of conditional blocks -- a skipped block costs nothing, a select form executes both sides on the
+# vector port that bounds the kernel (+2.7 %, section 9 of the experiment log; no effect on the tick kernel).
+KEEP_BRANCHES_FLAGS = ["-mllvm", "-phi-node-folding-threshold=0", "-mllvm", "-two-entry-phi-node-folding-threshold=0",
+                       "-mllvm", "-spec-exec-max-speculation-cost=0"]
+SOURCE_FLAGS = {"aecm_block_kernels.hip": UNIFORM_BRANCH_FLAGS + KEEP_BRANCHES_FLAGS, "aecm_kernels.hip": UNIFORM_BRANCH_FLAGS}
 # max-ilp machine scheduling measured +1.7 % on the VALU-bound block kernel (MI355X, 65 536 streams)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-shared",
                "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
