@@ -10,8 +10,11 @@
 // wave-uniform (scalar conditions); the structurizer otherwise rewrites each if / else into guarded single-entry regions
 // joined by flow blocks -- extra scalar mask logic, extra branches and duplicated code that the nested data-dependent
 // short paths of aecm_wave.h multiply: 3294 -> 2933 instructions in the kernel, 928 -> 983 M frames/s
-// (profiles/r03_experiments.md section 7).  A translation unit of its own so that it compiles next to the tick kernels'
-// unit (aecm_kernels.hip) and its flags can be tried separately.
+// (profiles/r03_experiments.md section 7).  For the same reason this unit is compiled with SimplifyCFG's phi-to-select
+// folding and the speculative-execution pass turned off (build.py: KEEP_BRANCHES_FLAGS): a uniform branch that skips a
+// block costs nothing, its select form executes both sides on the vector port that bounds the kernel (983 -> 1 010 M,
+// section 9).  A translation unit of its own so that it compiles next to the tick kernels' unit (aecm_kernels.hip) and its
+// flags can differ from theirs.
 #define AECM_TABLE_ATTR __device__
 #if defined(AECM_CHECKED)
 #define g_aecm_check_fail g_aecm_check_fail_blocks      // device symbols are per translation unit (no relocatable device code)
@@ -45,8 +48,8 @@ hipError_t ReadBlockKernelCheckCounters(uint64_t counters[2], bool reset) {
 
 // Occupancy target: the kernel is bound by instruction issue with every wave strictly in order, so
 // resident waves are what hides one wave's latencies from the VALU port.  7 waves/SIMD = 72 VGPRs; the
-// fast variants need 68 / 71 (no spills).  Measured: 5 -> 6 -> 7 waves = 609 -> 657 -> 674 M frames/s;
-// 8 waves (64 VGPRs) fit without spills under the default scheduler but cost 3 % more instructions: 668 M.
+// fast variants need 64 / 68 (no spills).  Measured in round 1: 5 -> 6 -> 7 waves = 609 -> 657 -> 674 M frames/s.
+// The hardware's ceiling is 7 as well: a CU's LDS holds seven copies of the 21 KB tables (one per 4-wave workgroup).
 #ifndef AECM_WAVES_PER_EU
 #if defined(AECM_CHECKED)
 #define AECM_WAVES_PER_EU 4       // the audit build's checks need registers; its speed does not matter
