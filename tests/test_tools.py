@@ -28,3 +28,17 @@ def test_first_divergence_on_the_hip_engine():
     assert r.returncode == 0 and "no divergence in 1100 blocks" in r.stdout, r.stdout + r.stderr
     r = _run("--engine", "hip", "--blocks", "400", "--seed", "5", "--perturb-block", "333", "--variant", "safe")
     assert r.returncode == 1 and "FIRST DIVERGENCE at block 333 " in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_soak_parity_tool_on_a_small_batch():
+    """tools/soak_parity.py (every stream of a batch against the CPU checker) at a size that takes seconds: both input
+    forms, and its verdict line must say what was compared."""
+    import json
+    tool = ROOT / "tools" / "soak_parity.py"
+    for extra in ([], ["--clean", "--fs", "8000", "--variant", "safe"]):
+        r = subprocess.run([sys.executable, str(tool), "--streams", "96", "--blocks", "160", "--passes", "2", "--chunk", "64", *extra],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["ok"] and line["streams"] == 96 and line["samples_compared"] == 96 * 160 * 64 and line["digests_compared"] == 96
