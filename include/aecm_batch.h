@@ -47,6 +47,11 @@ int32_t WebRtcAecmBatch_num_streams(const AecmBatch *b);
 int32_t WebRtcAecmBatch_Init(AecmBatch *b, int32_t sampFreq);
 /* Applies config to streams [first, first+count); count < 0 means "to the end". */
 int32_t WebRtcAecmBatch_set_config(AecmBatch *b, AecmConfig config, int32_t first, int32_t count);
+/* WebRtcAecm_Control (aecm_core.cc:477-482) for streams [first, first+count).  Deviation from the reference, on purpose:
+ * the reference stores both arguments unchecked (narrowed to int16_t) and later uses fixedDelay as an offset into the
+ * 100-slot far history (aecm_core.cc:157-172).  Here values the core could not hold or index with are refused with
+ * AECM_BAD_PARAMETER_ERROR instead of being narrowed silently: fixed_delay must lie in [-32768, 100) (negative = "use
+ * the delay estimator", as in the reference), nlp_flag in [-32768, 32767]. */
 int32_t WebRtcAecmBatch_Control(AecmBatch *b, int32_t fixed_delay, int32_t nlp_flag, int32_t first, int32_t count);
 
 /* Runs num_blocks consecutive 64-sample blocks of every stream.  All four pointers are DEVICE

@@ -182,6 +182,7 @@ struct SimWave {
     static constexpr bool kPhasePriority = false;
     template <int ROW> static vi table_lane_const(const vi &) { return vi(0); }   // never used (kLaneConstsInTable == false)
     static vi table_index_for_this_block() { return vi(0); }
+    static void begin_stream() {}
     static void begin_block(int, int) {}
     template <int PHASE> static void phase_priority() {}
     static int pin_uniform(int x) { return x; }                            // device: a uniform value pinned to a scalar register

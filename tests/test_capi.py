@@ -128,3 +128,21 @@ def test_isa_census_of_the_built_library():
     assert not any(op.startswith(("v_mfma", "scratch_")) for op in c["opcodes"])
     assert c["opcodes"].get("v_dot2c_i32_i16_e32", 0) + c["opcodes"].get("v_dot2_i32_i16", 0) >= 60
     assert 0 < c["valu_fast_class"] < c["counts"]["VALU"]
+
+
+def test_sanitizer_twin_is_not_part_of_the_shipped_build(monkeypatch, tmp_path):
+    """The UBSan twin of the library is opt-in test infrastructure (build_ubsan): its absence must neither make the
+    shipped library stale (every load() would retry a failing build on a toolchain without the sanitizer runtime) nor
+    be something build() produces."""
+    from webrtc_aecm_amd import build
+    if build.is_stale():
+        pytest.skip("library not built yet")
+    monkeypatch.setattr(build, "LIB_UBSAN", tmp_path / "libaecm_mi355x_ubsan.so")
+    assert not build.is_stale() and build.ubsan_is_stale()
+    assert build.build() == build.LIB and not (tmp_path / "libaecm_mi355x_ubsan.so").exists()
+    # a toolchain without the runtime: a clear error from the opt-in entry point, nothing else touched
+    monkeypatch.setattr(build, "_ubsan_runtime_dir", lambda hipcc: None)
+    before = build.LIB.stat().st_mtime
+    with pytest.raises(RuntimeError, match="UBSan runtime"):
+        build.build_ubsan()
+    assert build.LIB.stat().st_mtime == before

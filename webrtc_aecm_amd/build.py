@@ -1,5 +1,8 @@
 """Build the HIP shared library in-tree: webrtc_aecm_amd/_lib/libaecm_mi355x.so (gfx950 only), the CLI next to
-it, and the precondition-audit twin libaecm_mi355x_checked.so (same sources, kernels built with -DAECM_CHECKED)."""
+it, and the precondition-audit twin libaecm_mi355x_checked.so (same sources, kernels built with -DAECM_CHECKED).
+
+build_ubsan() is separate and opt-in (test infrastructure): the shipped build neither needs nor waits for a sanitizer
+runtime."""
 from __future__ import annotations
 
 import os
@@ -14,7 +17,7 @@ LIB_DIR = PKG / "_lib"
 LIB = LIB_DIR / "libaecm_mi355x.so"
 LIB_CHECKED = LIB_DIR / "libaecm_mi355x_checked.so"
 # the same kernels under host objects built with UndefinedBehaviorSanitizer (test infrastructure: tests/test_gpu_parity.py
-# runs the C-ABI tests on it; never the default)
+# runs the C-ABI tests on it; never the default, built only by build_ubsan())
 LIB_UBSAN = LIB_DIR / "libaecm_mi355x_ubsan.so"
 UBSAN_FLAGS = ["-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-shared-libsan", "-Wno-option-ignored"]
 CLI = LIB_DIR / "aecm_run"
@@ -43,12 +46,24 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm)")
 
 
+def _deps():
+    return list(CSRC.glob("*")) + list((PKG.parent / "include").rglob("*.h"))
+
+
 def is_stale() -> bool:
-    if not LIB.exists() or not LIB_CHECKED.exists() or not LIB_UBSAN.exists() or not CLI.exists():
+    """The shipped library, its audit twin or the CLI is missing or older than a source.  The sanitizer twin is not part
+    of this: a toolchain without the UBSan runtime must not make every load() retry a failing build."""
+    if not LIB.exists() or not LIB_CHECKED.exists() or not CLI.exists():
         return True
-    t = min(LIB.stat().st_mtime, LIB_CHECKED.stat().st_mtime, LIB_UBSAN.stat().st_mtime)
-    deps = list(CSRC.glob("*")) + list((PKG.parent / "include").rglob("*.h"))
-    return any(d.stat().st_mtime > t for d in deps)
+    t = min(LIB.stat().st_mtime, LIB_CHECKED.stat().st_mtime)
+    return any(d.stat().st_mtime > t for d in _deps())
+
+
+def ubsan_is_stale() -> bool:
+    if not LIB_UBSAN.exists():
+        return True
+    t = LIB_UBSAN.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in _deps())
 
 
 def _compile_flags():
@@ -96,6 +111,81 @@ def build_info():
         return {"commit": None, "dirty": None}
 
 
+def _compile_all(hipcc, jobs, verbose):
+    def compile_one(job):
+        src, obj, extra = job
+        flags = [f for f in _compile_flags() if not (f == "-O3" and "-O1" in extra)]
+        cmd = [hipcc, *flags, *extra, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=str(CSRC))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        list(ex.map(compile_one, jobs))
+
+
+def _link(hipcc, out, objects, link_flags, verbose) -> Path:
+    """Link into a temporary next to `out`; the caller moves it into place (atomically) once everything it needs exists."""
+    tmp = LIB_DIR / f".{out.name}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *link_flags, *objects, "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=str(CSRC))
+    return tmp
+
+
+def _ubsan_runtime_dir(hipcc):
+    """Directory of the shared UBSan runtime of the compiler hipcc drives (asked of that compiler; None when it has none)."""
+    for clang in (Path(hipcc).resolve().parent.parent / "lib" / "llvm" / "bin" / "clang", Path(hipcc).resolve().parent / "clang",
+                  Path(hipcc).resolve().parent / "amdclang"):
+        try:
+            if not clang.exists():
+                continue
+            rt = subprocess.run([str(clang), "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"],
+                                capture_output=True, text=True, timeout=60).stdout.strip()
+            if rt and Path(rt).is_absolute() and Path(rt).exists():
+                return str(Path(rt).parent)
+        except (OSError, subprocess.SubprocessError):
+            continue
+    return None
+
+
+def build_ubsan(force: bool = False, verbose: bool = False) -> Path:
+    """Test infrastructure, opt-in: libaecm_mi355x_ubsan.so = the shipped kernels under host objects compiled with
+    -fsanitize=undefined.  Raises RuntimeError (and touches nothing the product loads) when the toolchain has no shared
+    UBSan runtime or the build fails."""
+    if not force and not ubsan_is_stale():
+        return LIB_UBSAN
+    import fcntl
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    with open(LIB_DIR / ".build_ubsan.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not ubsan_is_stale():
+                return LIB_UBSAN
+            hipcc = _hipcc()
+            rt_dir = _ubsan_runtime_dir(hipcc)
+            if rt_dir is None:
+                raise RuntimeError("no shared UBSan runtime (libclang_rt.ubsan_standalone-x86_64.so) in hipcc's toolchain")
+            obj_dir = LIB_DIR / f".ubsanobj.{os.getpid()}"      # not ".obj.*": build() sweeps those
+            obj_dir.mkdir(exist_ok=True)
+            try:
+                jobs = [(s, obj_dir / (s + ".o"), SOURCE_FLAGS.get(s, [])) for s in KERNEL_SOURCES]
+                jobs += [(s, obj_dir / (s + ".ubsan.o"), UBSAN_FLAGS) for s in HOST_SOURCES]
+                _compile_all(hipcc, jobs, verbose)
+                objects = [str(o) for _, o, _ in jobs]
+                tmp = _link(hipcc, LIB_UBSAN, objects, ["-fsanitize=undefined", "-shared-libsan", f"-Wl,-rpath,{rt_dir}"], verbose)
+                os.replace(tmp, LIB_UBSAN)
+            except (OSError, subprocess.SubprocessError) as e:
+                raise RuntimeError(f"UBSan build failed: {e}") from e
+            finally:
+                for tmp in LIB_DIR.glob(f".{LIB_UBSAN.name}.{os.getpid()}.tmp"):
+                    tmp.unlink()
+                shutil.rmtree(obj_dir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LIB_UBSAN
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP/C++ source of the engine for gfx950 (one hipcc -c per source, in parallel) and link the
     shipped library, its audit twin and the CLI.
@@ -119,39 +209,20 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             hipcc = _hipcc()
             jobs = [(s, obj_dir / (s + ".o"), SOURCE_FLAGS.get(s, [])) for s in SOURCES]
             jobs += [(s, obj_dir / (s + ".checked.o"), SOURCE_FLAGS.get(s, []) + ["-DAECM_CHECKED"]) for s in KERNEL_SOURCES]
-            jobs += [(s, obj_dir / (s + ".ubsan.o"), UBSAN_FLAGS) for s in HOST_SOURCES]
 
-            def compile_one(job):
-                src, obj, extra = job
-                flags = [f for f in _compile_flags() if not (f == "-O3" and "-O1" in extra)]
-                cmd = [hipcc, *flags, *extra, "-c", str(CSRC / src), "-o", str(obj)]
-                if verbose:
-                    print(" ".join(cmd), flush=True)
-                subprocess.check_call(cmd, cwd=str(CSRC))
             try:                                        # the object directory goes away whether or not the build succeeds
-                with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
-                    list(ex.map(compile_one, jobs))
+                _compile_all(hipcc, jobs, verbose)
                 common = [str(obj_dir / (s + ".o")) for s in HOST_SOURCES]
-                common_ubsan = [str(obj_dir / (s + ".ubsan.o")) for s in HOST_SOURCES]
                 kernels = [str(obj_dir / (s + ".o")) for s in KERNEL_SOURCES]
                 kernels_checked = [str(obj_dir / (s + ".checked.o")) for s in KERNEL_SOURCES]
-                rt = subprocess.run([str(Path(hipcc).resolve().parent.parent / "lib" / "llvm" / "bin" / "clang"),
-                                     "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], capture_output=True, text=True).stdout.strip()
-                rt_dir = str(Path(rt).parent) if rt and Path(rt).is_absolute() else "/opt/rocm/lib/llvm/lib/clang/22/lib/linux"
-                for out, kern, host, link in ((LIB, kernels, common, []),
-                                              (LIB_CHECKED, kernels_checked, common, []),
-                                              (LIB_UBSAN, kernels, common_ubsan, ["-fsanitize=undefined", "-shared-libsan", f"-Wl,-rpath,{rt_dir}"])):
-                    tmp = LIB_DIR / f".{out.name}.{os.getpid()}.tmp"
-                    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *link, *kern, *host, "-o", str(tmp)]
-                    if verbose:
-                        print(" ".join(cmd), flush=True)
-                    try:
-                        subprocess.check_call(cmd, cwd=str(CSRC))
-                        os.replace(tmp, out)
-                    finally:
-                        if tmp.exists():
-                            tmp.unlink()
+                # both libraries are linked before either is moved into place: a failing link leaves the old pair
+                tmps = [(_link(hipcc, out, kern + common, [], verbose), out)
+                        for out, kern in ((LIB, kernels), (LIB_CHECKED, kernels_checked))]
+                for tmp, out in tmps:
+                    os.replace(tmp, out)
             finally:
+                for tmp in LIB_DIR.glob(f".*.{os.getpid()}.tmp"):
+                    tmp.unlink()
                 shutil.rmtree(obj_dir, ignore_errors=True)
             # the command-line front end (reference main.cc equivalent + multi-file batch mode)
             tmp_cli = LIB_DIR / f".{CLI.name}.{os.getpid()}.tmp"
@@ -168,4 +239,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
+    import sys
     print(build(force=True, verbose=True))
+    if "--ubsan" in sys.argv:
+        print(build_ubsan(force=True, verbose=True))

@@ -84,8 +84,12 @@ void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, c
     BlockEngine<Gfx950Wave<kFast, kPhasePrio>, kHasClean>::run_stream(st, io, stream, n_blocks);
 }
 
+int RotationStreamLimit(int compute_units) {
+    return (compute_units > 0 ? compute_units : 256) * 4 * AECM_ROTATION_WAVES_PER_EU;
+}
+
 hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
-                               hipStream_t stream, const int32_t *blocks_per_stream) {
+                               int rotation_stream_limit, hipStream_t stream, const int32_t *blocks_per_stream) {
     if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
     const dim3 grid((n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup);
     const dim3 block(64 * kWavesPerWorkgroup);
@@ -93,16 +97,9 @@ hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_stre
     const bool clean = io.near_clean != nullptr;
     // Issue priority by phase of the block when the launch is more waves than the chip holds at once (they then run in
     // rounds and spread over the phases by themselves), the per-block rotation when every wave of the launch is resident
-    // from the start and they would otherwise march in lock step (wave_gfx950.h: kPhasePrio).
-    static int resident_waves[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (resident_waves[dev] == 0) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        resident_waves[dev] = cus * 4 * AECM_ROTATION_WAVES_PER_EU;
-    }
-    const bool phase = n_streams > resident_waves[dev];
+    // from the start and they would otherwise march in lock step (wave_gfx950.h: kPhasePrio).  The limit belongs to the
+    // engine's device (RotationStreamLimit of its CU count, taken once in BatchEngine::Create): nothing cached here.
+    const bool phase = n_streams > rotation_stream_limit;
 #define AECM_LAUNCH(F, C, P) hipLaunchKernelGGL((aecm_process_kernel<F, C, P>), grid, block, lds, stream, st, io, n_streams, n_blocks, blocks_per_stream)
     if (variant == kVariantFast) {
         if (clean) { if (phase) AECM_LAUNCH(true, true, true); else AECM_LAUNCH(true, true, false); }

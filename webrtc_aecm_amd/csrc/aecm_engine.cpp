@@ -22,6 +22,9 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     BatchEngine *e = new BatchEngine();
     e->device_ = device_id;
     e->num_streams_ = num_streams;
+    int cus = 0;
+    if (!AECM_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id))) cus = 0;
+    e->rotation_limit_ = RotationStreamLimit(cus);
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
               AECM_HIP_OK(hipMalloc((void **)&e->st_.vec, S * kVecWordsPerStream * sizeof(uint32_t))) &&
@@ -168,7 +171,7 @@ bool BatchEngine::ProcessBlocksRange(const IoView &io, int num_blocks, int first
     st.vec += (size_t)first * kVecWordsPerStream;
     st.scal += (size_t)first * kNumScal;
     st.hist += (size_t)first * kHistWordsPerStream;
-    if (!AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, stream_, blocks_per_stream_dev))) return false;
+    if (!AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, rotation_limit_, stream_, blocks_per_stream_dev))) return false;
     if (!AECM_HIP_OK(hipEventRecord(ev_stop_[slot], stream_))) return false;
     ++timer_pending_;
     return true;
@@ -255,7 +258,7 @@ bool BatchEngine::ProcessBlocksHostMapped(const IoView &io, int num_blocks) {
     if (io.near_clean) rows(io.near_clean, mapped_host_ + 2 * per, true);
     IoView dev{mapped_dev_, mapped_dev_ + per, io.near_clean ? mapped_dev_ + 2 * per : nullptr, mapped_dev_ + (size_t)n_in * per,
                (int64_t)row, kBlock};
-    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, dev, num_streams_, num_blocks, variant_, stream_))) return false;
+    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, dev, num_streams_, num_blocks, variant_, rotation_limit_, stream_))) return false;
     if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
     rows(io.out, mapped_host_ + (size_t)n_in * per, false);
     return true;
@@ -307,7 +310,7 @@ bool BatchEngine::ProcessBlocksHostPipelined(const IoView &io, int num_blocks) {
         st.scal += first * kNumScal;
         st.hist += first * kHistWordsPerStream;
         IoView dev{dfar + off, dnear + off, io.near_clean ? dclean + off : nullptr, dout + off, (int64_t)row, kBlock};
-        up = up && AECM_HIP_OK(LaunchProcessBlocks(st, dev, (int)count, num_blocks, variant_, stream_)) &&
+        up = up && AECM_HIP_OK(LaunchProcessBlocks(st, dev, (int)count, num_blocks, variant_, rotation_limit_, stream_)) &&
              AECM_HIP_OK(hipEventRecord(done[k], stream_));
         if (!up) failed = true;
         launched.store(k + 1, std::memory_order_release);

@@ -63,6 +63,7 @@ private:
     bool FlushTimers() { return HarvestTimers(true); }
 
     int device_ = 0;
+    int rotation_limit_ = 0;             // RotationStreamLimit of device_'s CU count (launch-size switch of the block kernels)
     int num_streams_ = 0;
     bool initialized_ = false;
     int variant_ = kVariantFast;

@@ -76,7 +76,9 @@ const char *ValidateStateImage(const uint32_t *vec, const int32_t *scal, int fs)
     if (!in(S_LAST_DELAY, -2, kHistory - 1)) return "last_delay";
     if (!in(S_FIXED_DELAY, -32768, kHistory - 1)) return "fixedDelay";
     if (!in(S_STARTUP, 0, 2)) return "startupState";
-    if (!in(S_DFANOISYQ, 0, 15) || !in(S_DFANOISYQ_OLD, 0, 15) || !in(S_DFACLEANQ, 0, 15) || !in(S_DFACLEANQ_OLD, 0, 15)) return "dfaQDomain";
+    // Q domains are norms of a non-negative int16 maximum (WebRtcSpl_NormW16, spl_inl.h:108: at most 14 -- Q 15 would need
+    // a negative one); the nearFilt update's range arguments (aecm_wave.h: near_filt_update) are written for |dQ| <= 14
+    if (!in(S_DFANOISYQ, 0, 14) || !in(S_DFANOISYQ_OLD, 0, 14) || !in(S_DFACLEANQ, 0, 14) || !in(S_DFACLEANQ_OLD, 0, 14)) return "dfaQDomain";
     // flags and small counters
     if (!in(S_CNG, 0, 1)) return "cngMode";
     if (!in(S_CURVAD, 0, 1) || !in(S_FIRSTVAD, 0, 1) || !in(S_FAR_INIT, 0, 1) || !in(S_NEAR_INIT, 0, 1)) return "flag";

@@ -23,8 +23,11 @@ enum KernelVariant : int {
 // Process n_blocks consecutive blocks of streams [0, n_streams) -- one wavefront per stream.
 // blocks_per_stream (device, may be null): stream s processes blocks_per_stream[s] <= n_blocks blocks
 // instead (batches whose streams have different amounts of audio pending).
+// rotation_stream_limit = RotationStreamLimit(CU count of the device the launch runs on): launches of at most that many
+// streams are fully resident from the start and take the kernel variants built for that occupancy.
 hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int variant,
-                               hipStream_t stream, const int32_t *blocks_per_stream = nullptr);
+                               int rotation_stream_limit, hipStream_t stream, const int32_t *blocks_per_stream = nullptr);
+int RotationStreamLimit(int compute_units);
 
 // Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into
 // streams [first, first + count) and clear their far-spectrum history.

@@ -164,6 +164,16 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
     if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
     hipStream_t st = engine_->stream();
+    // The caller's events are parameters: a stale or foreign handle is refused before anything is touched (a query of a
+    // live event answers "done" or "not ready", never anything else), and refused without consequences for the sessions.
+    for (void *ev : {wait_event, done_event}) {
+        if (!ev) continue;
+        const hipError_t q = hipEventQuery(static_cast<hipEvent_t>(ev));
+        if (q != hipSuccess && q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return AECM_BAD_PARAMETER_ERROR;
+        }
+    }
     if (flags_per_session && n != 160) {
         uint8_t any = 0;
         for (int s = 0; s < S; ++s) any |= flags_per_session[s];
@@ -233,7 +243,10 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
     TickIo tio{dfar, dnear, dclean, dout, dstride, n, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, near_pos_};
     TickFlowIo fio{flow_state_, flow_plans_, far_frames_, far_old_, ms_per_session ? ms_dev_[slot] : nullptr,
                    flags_per_session ? flags_dev_[slot] : nullptr, ms, 0, fs_};
-    if (wait_event && !AECM_HIP_OK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(wait_event), 0))) return fail();
+    if (wait_event && !AECM_HIP_OK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(wait_event), 0))) {
+        (void)hipGetLastError();
+        return AECM_BAD_PARAMETER_ERROR;      // nothing of this tick has been enqueued (device pointers: no staging copies): no poison
+    }
     const bool ok = AECM_HIP_OK(LaunchTickFlow(engine_->state_ptrs(), tio, fio, S, st));
     near_pos_ += n;
     if (!ok) return fail();

@@ -1308,6 +1308,7 @@ struct BlockEngine {
         vi far_next = io.far(r, 0);
         vi near_next = io.near(r, 0);
         vi clean_next = kHasClean ? io.clean(r, 0) : vi(0);
+        W::begin_stream();
         auto step = [&](int blk) __attribute__((always_inline)) {
             vi far_cur = far_next, near_cur = near_next, clean_cur = clean_next;
             if (blk + 1 < n_blocks) {             // prefetch the next block's 3 x 128 bytes

@@ -145,13 +145,24 @@ struct Gfx950Wave {
             constexpr int n = (int)(sizeof(kPhasePrios) / sizeof(int)) - 1;             // entries 0 (unused) .. 13
             static_assert(n == 14 && PHASE >= 1 && PHASE <= 13, "one priority per phase 1..13 (entry 0 is unused)");
             constexpr int now = kPhasePrios[PHASE];
-            constexpr int before = PHASE == 1 ? kPhasePrios[n - 1] : kPhasePrios[PHASE - 1];   // phase 13 of the block before (a launch starts at 0: keep entry 13 at 0)
+            constexpr int before = PHASE == 1 ? kPhasePrios[n - 1] : kPhasePrios[PHASE - 1];   // phase 13 of the block before; begin_stream() makes that true of the first block too
             if constexpr (now != before) {
                 if constexpr (now == 0) __builtin_amdgcn_s_setprio(0);
                 else if constexpr (now == 1) __builtin_amdgcn_s_setprio(1);
                 else if constexpr (now == 2) __builtin_amdgcn_s_setprio(2);
                 else __builtin_amdgcn_s_setprio(3);
             }
+        }
+    }
+    // Once per launch, ahead of the block loop: a wave starts at priority 0, and phase_priority<1> only emits an s_setprio
+    // when entry 1 differs from entry 13 (the block before) -- so the first block is put where every later block's phase 1
+    // is, whatever table is being tried (in the 2-3 block tick launches the first block is most of the launch).
+    static __device__ __forceinline__ void begin_stream() {
+        if constexpr (kPhasePriority) {
+            constexpr int first = kPhasePrios[1];
+            if constexpr (first == 1) __builtin_amdgcn_s_setprio(1);
+            else if constexpr (first == 2) __builtin_amdgcn_s_setprio(2);
+            else if constexpr (first == 3) __builtin_amdgcn_s_setprio(3);
         }
     }
     static __device__ __forceinline__ void begin_block(int blk, int n_blocks) {
