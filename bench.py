@@ -242,6 +242,9 @@ def main():
     ap.add_argument("--share-devices", action="store_true",
                     help="map rank r to HIP device r %% device_count (exercises the N-rank path on a box with fewer GPUs; "
                          "implies --dist-backend gloo, RCCL refuses two ranks on one device)")
+    ap.add_argument("--launch-blocks", type=int, default=0,
+                    help="experiment: split every step into launches of this many blocks over the same input (0 = one launch per "
+                         "step, the measured configuration); separates launch-length effects from the data's")
     ap.add_argument("--fixed-delay", type=int, default=-1,
                     help="WebRtcAecm_Control fixed delay (>= 0 disables the estimator's choice; 0 = no far-history reads; "
                          "used to calibrate the FETCH_SIZE counter on a known byte count)")
@@ -291,9 +294,14 @@ def main():
     stride = far.shape[1]
     out = torch.empty_like(near)            # same [S][T*64] layout as the inputs
 
+    C = args.launch_blocks if 0 < args.launch_blocks < T else T
+    chunks = [(b0, min(C, T - b0)) for b0 in range(0, T, C)]
+
     def step():                             # one C-ABI call = one launch = S*T frames; the input repeats every T blocks
-        batch.process_device(far.data_ptr(), near.data_ptr(), out.data_ptr(), stride, 64, T,
-                             clean.data_ptr() if clean is not None else None)
+        for b0, nb in chunks:               # (one chunk unless --launch-blocks)
+            o = b0 * 128                    # bytes into every stream's row
+            batch.process_device(far.data_ptr() + o, near.data_ptr() + o, out.data_ptr() + o, stride, 64, nb,
+                                 clean.data_ptr() + o if clean is not None else None)
 
     torch.cuda.synchronize()
     for _ in range(W):
@@ -312,7 +320,8 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     kernel_ms_total, launches = batch.timers()      # HIP events recorded by the library around every launch, on its stream
-    assert launches == K, (launches, K)
+    assert launches == K * len(chunks), (launches, K, len(chunks))
+    launches = K                            # per step from here on (a step is len(chunks) launches only under --launch-blocks)
 
     cdev = device if args.dist_backend == "nccl" else torch.device("cpu")
     dev_name = "%s (%d CUs, hip device %d)" % (aecm.device_info(local_rank)[0], aecm.device_info(local_rank)[1], local_rank)
@@ -339,7 +348,7 @@ def main():
             "ms_per_step": c["seconds"] / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (Q-format fixed point)", "data": "synthetic",
             "config": {"workload": workload_name(S, T, args.fs, world, args.clean),
-                       "streams_per_gpu": S, "blocks_per_step": T, "fs": args.fs, "kernel_variant": args.variant,
+                       "streams_per_gpu": S, "blocks_per_step": T, "launches_per_step": len(chunks), "fs": args.fs, "kernel_variant": args.variant,
                        "sharding": f"static, {world} x {S} independent streams, no data-path collective",
                        "timed_region_s": c["seconds"], "commit": commit},
             "device": dict(zip(("name", "compute_units", "clock_khz"), aecm.device_info(local_rank))),

@@ -209,6 +209,21 @@ int32_t WebRtcAecmSessions_GetEchoPath(AecmSessions *s, int32_t session, void *e
 /* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */
 int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
 
+/* How a ProcessBlocks launch is scheduled on the device; results do not depend on it.  A launch of more streams than
+ * the chip holds wavefronts is cut into chunks of chunk_blocks blocks that resident wavefronts claim in order from a
+ * queue, so that all streams advance together and the launch does not end in a long drain at low occupancy (default:
+ * 128 blocks, environment AECM_QUEUE_CHUNK).  chunk_blocks = 0: one wavefront keeps one stream for the whole launch,
+ * always.  min_streams < 0 (default): the queue form is used above the chip's resident wavefront count; >= 0: above
+ * that many streams (diagnostics / tests). */
+int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, int32_t min_streams);
+/* Which form a ProcessBlocks launch of num_blocks blocks over the whole batch takes (for measurement tools that must name
+ * the kernel they time): 0 = one wavefront per stream, kernel variants for launches the chip holds at once; 1 = one
+ * wavefront per stream, issue priority by phase; 2 = the chunk queue (*chunk_blocks, if not NULL, receives the chunk). */
+#define AECM_LAUNCH_RESIDENT 0
+#define AECM_LAUNCH_PER_STREAM 1
+#define AECM_LAUNCH_CHUNK_QUEUE 2
+int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t *chunk_blocks);
+
 /* Device self test of the wave primitives on device_id; failures[0..7] must all be 0 afterwards
  * (see webrtc_aecm_amd/csrc/aecm_kernels.h).  exhaustive != 0 checks floor-sqrt on all of [0, 2^31). */
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]);

@@ -301,6 +301,12 @@ struct SimWave {
     static vi load_u16(const uint16_t *p, const vi &idx) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = p[idx.v[i]]; return r; }
     static void store_i16(int16_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) p[idx.v[i]] = (int16_t)val.v[i]; }
     static void store_u16(uint16_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) p[idx.v[i]] = (uint16_t)val.v[i]; }
+    struct ScalarRow {
+        const int32_t *p;
+        int get(int f) const { return p[f]; }
+    };
+    static ScalarRow load_scalar_row(const int32_t *scal) { return ScalarRow{scal}; }
+    static void store_scalar(int32_t *scal, int f, int v) { scal[f] = v; }
 };
 
 }  // namespace aecm

@@ -599,7 +599,7 @@ def test_config2_4096_streams_bit_exact():
         assert np.array_equal(b.digest(s), exp_dig[s])
 
 
-def _replicated_full_size_run(S, T, fs, U, seed0):
+def _replicated_full_size_run(S, T, fs, U, seed0, chunking=None):
     """S streams replicating U distinct seeded (far, near) pairs, one launch of T blocks with everything resident in HBM
     (replication, the launch and the comparison all on the device: the buffers are several GB each).  Every stream's
     output must equal the oracle's answer for the pair it replicates, and sampled streams' state digests too."""
@@ -615,6 +615,8 @@ def _replicated_full_size_run(S, T, fs, U, seed0):
     assert dfar.is_contiguous() and dout.numel() == S * L
     torch.cuda.synchronize()
     b = aecm.AecmBatch(S, fs)
+    if chunking is not None:
+        b.set_launch_chunking(*chunking)
     b.process_device(dfar.data_ptr(), dnear.data_ptr(), dout.data_ptr(), L, 64, T)
     b.synchronize()
     dexp = torch.from_numpy(exp_out).cuda()
@@ -636,6 +638,75 @@ def test_large_batch_properties_65536_streams():
     replicated streams must equal the oracle's answer for the 64 distinct seeds they replicate."""
     n = _replicated_full_size_run(65536, 1100, 16000, 64, 400)
     assert n > 2 ** 32
+
+
+def test_large_batch_one_wave_per_stream_form():
+    """Launches larger than the chip take the chunk-queue kernel by default (the test above); the one-stream-per-wave form
+    of the same launch (WebRtcAecmBatch_SetLaunchChunking(b, 0, ..)) at a size past start-up and past 2^32 elements."""
+    n = _replicated_full_size_run(65536, 1056, 16000, 64, 400, chunking=(0, -1))
+    assert n > 2 ** 32
+
+
+@pytest.mark.parametrize("fs,clean", [(16000, False), (8000, False), (16000, True)])
+def test_chunk_queue_launch_under_contention(fs, clean):
+    """The chunk-queue kernel (aecm_block_kernels.hip) forced onto a batch far smaller than the chip: 24 streams cut into
+    chunks of 4, 32 and 64 blocks, so that the wave that claims a stream's next chunk usually finds its predecessor still
+    running and waits for it -- the hand-over of a stream's state between waves (lane vectors, scalars and far-spectrum
+    history rows through memory at agent scope) is on the critical path of every item.  Outputs and complete state must
+    equal the oracle's; two launches in a row continue each other."""
+    S, T = 24, 192
+    seeds = list(range(7100, 7100 + S))
+    cfgs = [stream_config(s) for s in range(S)]
+    far, near = synth_streams(seeds, 2 * T, fs)
+    cln = synth_clean(near) if clean else None
+    exp = []
+    for s in range(S):
+        o = pyoracle.OracleStream(fs, *cfgs[s])
+        if clean:
+            e = np.concatenate([o.process_block_clean(far[s, k * 64:(k + 1) * 64], near[s, k * 64:(k + 1) * 64], cln[s, k * 64:(k + 1) * 64])
+                                for k in range(2 * T)])
+        else:
+            e = o.process(far[s], near[s])
+        exp.append((e, o.digest()))
+    for chunk in (4, 32, 64):
+        b = aecm.AecmBatch(S, fs)
+        for s, (cng, em) in enumerate(cfgs):
+            b.set_config(cng, em, s, 1)
+        b.set_launch_chunking(chunk, 0)
+        out = np.concatenate([b.process_host(far[:, :T * 64], near[:, :T * 64], cln[:, :T * 64] if clean else None),
+                              b.process_host(far[:, T * 64:], near[:, T * 64:], cln[:, T * 64:] if clean else None)], axis=1)
+        for s in range(S):
+            assert np.array_equal(out[s], exp[s][0]), (chunk, s)
+            assert np.array_equal(b.digest(s), exp[s][1]), (chunk, s, describe_digest_diff(b.digest(s), exp[s][1]))
+        b.close()
+
+
+def test_chunk_queue_launch_larger_than_the_chip():
+    """9 001 streams (more than the chip holds waves, not a multiple of a workgroup's four) x 300 blocks in chunks of 128,
+    128 and 44: the launch takes the queue form by itself.  Every stream must equal the oracle's answer for the pair it
+    replicates; then the same batch continues with a launch in the one-stream-per-wave form and must still agree."""
+    import torch
+    S, T, fs, U = 9001, 300, 16000, 16
+    seeds = list(range(7300, 7300 + U))
+    far, near = synth_streams(seeds, 2 * T, fs)
+    exp_out, exp_dig = oracle_batch(seeds, 2 * T, fs, [(1, 3)] * U, pairs=(far, near))
+    idx = torch.arange(S) % U
+    dfar = torch.from_numpy(far).cuda()[idx].contiguous()
+    dnear = torch.from_numpy(near).cuda()[idx].contiguous()
+    dout = torch.empty_like(dnear)
+    dexp = torch.from_numpy(exp_out).cuda()[idx]
+    torch.cuda.synchronize()
+    L = 2 * T * 64
+    b = aecm.AecmBatch(S, fs)
+    b.process_device(dfar.data_ptr(), dnear.data_ptr(), dout.data_ptr(), L, 64, T)
+    b.set_launch_chunking(0, -1)
+    half = T * 128                                                       # bytes into every row
+    b.process_device(dfar.data_ptr() + half, dnear.data_ptr() + half, dout.data_ptr() + half, L, 64, T)
+    b.synchronize()
+    assert int((dout != dexp).sum().item()) == 0
+    for s in (0, 15, 16, 4500, 9000):
+        assert np.array_equal(b.digest(s), exp_dig[s % U]), s
+    b.close()
 
 
 def test_state_snapshot_import_is_validated():

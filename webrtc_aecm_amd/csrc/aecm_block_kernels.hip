@@ -84,6 +84,95 @@ void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, c
     BlockEngine<Gfx950Wave<kFast, kPhasePrio>, kHasClean>::run_stream(st, io, stream, n_blocks);
 }
 
+// ---- the chunk-queue form: one launch, (chunk, stream) items claimed in order by resident waves -------------------------
+// A launch of S streams x T blocks in the form above gives every wave one stream for all T blocks.  Waves start when a slot
+// frees up, so when the last stream has been handed out the resident waves are anywhere between their first and their last
+// block, and the launch drains for most of a stream's duration at falling occupancy -- a SIMD below ~5 waves no longer
+// fills its issue ports: measured 1.7-2.3 ms of an 83 ms launch at 65 536 streams, the same 2 ms of a 22 ms launch at 16 384
+// (profiles/r04_experiments.md section 1).  Here the launch is cut into chunks of C blocks, item i = (chunk i / S, stream
+// i % S), and a grid that just fills the chip claims items in order from one counter: all streams advance together, and
+// what is left when the counter runs out is at most C blocks per wave -- the drain shrinks by T / C.
+//
+// A stream's chunk c + 1 is picked up by whichever wave comes next, on any CU of any XCD, so between chunks the state
+// travels through memory at agent scope (Gfx950Wave<.., kCoherentState>: sc1 loads and stores, no fences -- a release
+// fence at agent scope is a write-back of the XCD's whole L2).  Order: the claimer of item i - S holds it before item i is
+// claimed (one counter), so a wave that finds done[stream] < chunk waits for a wave that is running -- no deadlock even
+// when the grid is larger than the chip; with S >= the resident waves the wait practically never happens.  The wait is
+// bounded anyway: a wave that gives up raises *err (never cleared by a launch; the engine reports it at the next
+// synchronisation) and leaves.
+constexpr int kQueueCtlWords = 16;          // [0] next item, then done[stream] = chunks of this launch completed
+constexpr uint32_t kQueueMaxPolls = 1u << 20;      // x (s_sleep 16 = 1 024 cycles + one load): about a second
+
+template <bool kHasClean>
+__global__ __launch_bounds__(64 * kWavesPerWorkgroup)
+__attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
+void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, int chunk_blocks, int n_chunks, uint32_t *ctl,
+                               uint32_t *err) {
+    FillLdsTables<64 * kWavesPerWorkgroup>(st.consts);
+    using E = BlockEngine<Gfx950Wave<true, true, false, true>, kHasClean>;
+    const uint32_t n_items = (uint32_t)n_streams * (uint32_t)n_chunks;
+    uint32_t *done = ctl + kQueueCtlWords;
+    // Every lane takes part in the queue's few memory operations with the same address and, for the counter, an addend
+    // that is 1 in lane 0 only: no lane-divergent control flow anywhere in the item loop.
+    const uint32_t one_in_lane0 = (threadIdx.x & 63u) == 0 ? 1u : 0u;
+    for (;;) {
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_fetch_add(ctl, one_in_lane0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (item >= n_items) break;
+        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+        const uint32_t chunk = item / (uint32_t)n_streams;
+        const uint32_t stream = item - chunk * (uint32_t)n_streams;
+        if (chunk != 0) {
+            uint32_t polls = 0;
+            while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < chunk) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++polls > kQueueMaxPolls ||
+                    ((polls & 1023u) == 0 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)) {
+                    __hip_atomic_store(err, 1u + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every wave leaves at its next claim
+                    return;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");                       // the state loads stay behind the flag
+        const int first = (int)chunk * chunk_blocks;
+        const int nb = n_blocks - first < chunk_blocks ? n_blocks - first : chunk_blocks;
+        typename E::StridedIo sio{io, (int64_t)stream * io.stream_stride + (int64_t)first * io.block_stride};
+        E::run_stream_io(st, sio, (int64_t)stream, nb);
+        // every store of the chunk (state, history rows: sc1, written through) has completed before the flag is raised
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(done + stream, chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+size_t QueueControlBytes(int n_streams) { return ((size_t)kQueueCtlWords + (size_t)n_streams) * sizeof(uint32_t); }
+
+// Whether a launch of this shape takes the chunk-queue kernel (chunk_blocks > 0: the engine's setting).
+bool QueueLaunchApplies(int n_streams, int n_blocks, int variant, int chunk_blocks, int min_streams, bool ragged) {
+    if (chunk_blocks <= 0 || variant != kVariantFast || ragged) return false;
+    if (n_streams <= min_streams || n_blocks < 2 * chunk_blocks) return false;
+    const int64_t items = (int64_t)n_streams * ((n_blocks + chunk_blocks - 1) / chunk_blocks);
+    return items < (int64_t(1) << 31);
+}
+
+hipError_t LaunchProcessBlocksQueued(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int chunk_blocks,
+                                     int resident_waves, uint32_t *ctl, uint32_t *err, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(ctl, 0, QueueControlBytes(n_streams), stream);
+    if (e != hipSuccess) return e;
+    const int n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
+    const int resident_groups = resident_waves / kWavesPerWorkgroup;
+    const int needed = (n_streams + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup;
+    const dim3 grid(needed < resident_groups ? needed : resident_groups);
+    const dim3 block(64 * kWavesPerWorkgroup);
+    const size_t lds = sizeof(LdsTables);
+    if (io.near_clean != nullptr)
+        hipLaunchKernelGGL((aecm_process_queue_kernel<true>), grid, block, lds, stream, st, io, n_streams, n_blocks, chunk_blocks, n_chunks, ctl, err);
+    else
+        hipLaunchKernelGGL((aecm_process_queue_kernel<false>), grid, block, lds, stream, st, io, n_streams, n_blocks, chunk_blocks, n_chunks, ctl, err);
+    return hipGetLastError();
+}
+
+int ResidentWaves(int compute_units) { return (compute_units > 0 ? compute_units : 256) * 4 * AECM_WAVES_PER_EU; }
+
 int RotationStreamLimit(int compute_units) {
     return (compute_units > 0 ? compute_units : 256) * 4 * AECM_ROTATION_WAVES_PER_EU;
 }

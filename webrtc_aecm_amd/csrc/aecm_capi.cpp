@@ -253,6 +253,18 @@ int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant) {
     return 0;
 }
 
+int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, int32_t min_streams) {
+    if (!b) return -1;
+    if (chunk_blocks < 0 || chunk_blocks > (1 << 20)) return AECM_BAD_PARAMETER_ERROR;
+    b->engine->set_queue_chunk(chunk_blocks, min_streams);
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t *chunk_blocks) {
+    if (!b) return -1;
+    return b->engine->DescribeLaunch(num_blocks, chunk_blocks);
+}
+
 // ---- streaming batch of sessions ---------------------------------------------------------------------
 
 AecmSessions *WebRtcAecmSessions_Create(int32_t num_streams, int32_t device_id) {

@@ -14,6 +14,10 @@ namespace aecm {
 
 #define AECM_HIP_OK(expr) ((expr) == hipSuccess)
 
+// Launches of more streams than the chip holds waves are cut into chunks of this many blocks and scheduled from a queue
+// (aecm_block_kernels.hip: aecm_process_queue_kernel).  Measured: profiles/r04_experiments.md section 1.
+constexpr int kDefaultQueueChunk = 128;
+
 BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     if (num_streams <= 0) return nullptr;
     int n_dev = 0;
@@ -25,6 +29,9 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     int cus = 0;
     if (!AECM_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id))) cus = 0;
     e->rotation_limit_ = RotationStreamLimit(cus);
+    e->resident_waves_ = ResidentWaves(cus);
+    e->queue_chunk_ = kDefaultQueueChunk;
+    if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::max(0, atoi(env));
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
               AECM_HIP_OK(hipMalloc((void **)&e->st_.vec, S * kVecWordsPerStream * sizeof(uint32_t))) &&
@@ -60,6 +67,8 @@ BatchEngine::~BatchEngine() {
     (void)hipFree(image_vec_dev_);
     (void)hipFree(image_scal_dev_);
     (void)hipFree(consts_dev_);
+    (void)hipFree(queue_ctl_);
+    (void)hipFree(queue_err_);
     (void)hipFree(stage_dev_);
     if (mapped_host_) (void)hipHostFree(mapped_host_);
     (void)hipFree(rec_maps_);
@@ -152,6 +161,46 @@ bool BatchEngine::HarvestTimers(bool wait_all) {
     return true;
 }
 
+// One launch of the block kernels over `count` streams (st, io already offset to the first of them), in the chunk-queue form
+// when the launch is larger than the chip (see QueueLaunchApplies).
+bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev) {
+    if (QueueLaunchApplies(count, num_blocks, variant_, queue_chunk_, queue_min_streams_ >= 0 ? queue_min_streams_ : resident_waves_,
+                           blocks_per_stream_dev != nullptr)) {
+        const size_t need = QueueControlBytes(count);
+        if (need > queue_ctl_bytes_) {                       // grown on first use; stream-ordered work may still read the old one
+            if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+            (void)hipFree(queue_ctl_);
+            queue_ctl_ = nullptr;
+            queue_ctl_bytes_ = 0;
+            if (!AECM_HIP_OK(hipMalloc((void **)&queue_ctl_, need))) return false;
+            queue_ctl_bytes_ = need;
+        }
+        if (!queue_err_ && (!AECM_HIP_OK(hipMalloc((void **)&queue_err_, sizeof(uint32_t))) ||
+                            !AECM_HIP_OK(hipMemsetAsync(queue_err_, 0, sizeof(uint32_t), stream_)))) return false;
+        queue_unchecked_ = true;
+        return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, queue_chunk_, resident_waves_, queue_ctl_, queue_err_, stream_));
+    }
+    return AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, rotation_limit_, stream_, blocks_per_stream_dev));
+}
+
+int BatchEngine::DescribeLaunch(int num_blocks, int *chunk_blocks) const {
+    if (QueueLaunchApplies(num_streams_, num_blocks, variant_, queue_chunk_, queue_min_streams_ >= 0 ? queue_min_streams_ : resident_waves_, false)) {
+        if (chunk_blocks) *chunk_blocks = queue_chunk_;
+        return 2;
+    }
+    if (chunk_blocks) *chunk_blocks = 0;
+    return variant_ == kVariantFast && num_streams_ > rotation_limit_ ? 1 : 0;
+}
+
+// After a synchronisation of stream_: did a wave of a chunk-queue launch give up waiting (it never should)?
+bool BatchEngine::CheckQueueError() {
+    if (!queue_unchecked_) return true;
+    queue_unchecked_ = false;
+    uint32_t err = 0;
+    if (!AECM_HIP_OK(hipMemcpy(&err, queue_err_, sizeof err, hipMemcpyDeviceToHost))) return false;
+    return err == 0;
+}
+
 bool BatchEngine::ProcessBlocks(const IoView &io, int num_blocks, const int32_t *blocks_per_stream_dev) {
     return ProcessBlocksRange(io, num_blocks, 0, num_streams_, blocks_per_stream_dev);
 }
@@ -171,7 +220,7 @@ bool BatchEngine::ProcessBlocksRange(const IoView &io, int num_blocks, int first
     st.vec += (size_t)first * kVecWordsPerStream;
     st.scal += (size_t)first * kNumScal;
     st.hist += (size_t)first * kHistWordsPerStream;
-    if (!AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, rotation_limit_, stream_, blocks_per_stream_dev))) return false;
+    if (!LaunchBlocks(st, io, count, num_blocks, blocks_per_stream_dev)) return false;
     if (!AECM_HIP_OK(hipEventRecord(ev_stop_[slot], stream_))) return false;
     ++timer_pending_;
     return true;
@@ -258,8 +307,8 @@ bool BatchEngine::ProcessBlocksHostMapped(const IoView &io, int num_blocks) {
     if (io.near_clean) rows(io.near_clean, mapped_host_ + 2 * per, true);
     IoView dev{mapped_dev_, mapped_dev_ + per, io.near_clean ? mapped_dev_ + 2 * per : nullptr, mapped_dev_ + (size_t)n_in * per,
                (int64_t)row, kBlock};
-    if (!AECM_HIP_OK(LaunchProcessBlocks(st_, dev, num_streams_, num_blocks, variant_, rotation_limit_, stream_))) return false;
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!LaunchBlocks(st_, dev, num_streams_, num_blocks, nullptr)) return false;
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_)) || !CheckQueueError()) return false;
     rows(io.out, mapped_host_ + (size_t)n_in * per, false);
     return true;
 }
@@ -310,14 +359,14 @@ bool BatchEngine::ProcessBlocksHostPipelined(const IoView &io, int num_blocks) {
         st.scal += first * kNumScal;
         st.hist += first * kHistWordsPerStream;
         IoView dev{dfar + off, dnear + off, io.near_clean ? dclean + off : nullptr, dout + off, (int64_t)row, kBlock};
-        up = up && AECM_HIP_OK(LaunchProcessBlocks(st, dev, (int)count, num_blocks, variant_, rotation_limit_, stream_)) &&
+        up = up && LaunchBlocks(st, dev, (int)count, num_blocks, nullptr) &&
              AECM_HIP_OK(hipEventRecord(done[k], stream_));
         if (!up) failed = true;
         launched.store(k + 1, std::memory_order_release);
     }
     if (failed.load()) launched.store(n_chunks, std::memory_order_release);      // let the helper fall out of its wait
     downloader.join();
-    ok = !failed.load() && AECM_HIP_OK(hipStreamSynchronize(stream_));
+    ok = !failed.load() && AECM_HIP_OK(hipStreamSynchronize(stream_)) && CheckQueueError();
     for (auto e : done)
         if (e) (void)hipEventDestroy(e);
     return ok;
@@ -412,7 +461,7 @@ bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, con
 
 bool BatchEngine::Synchronize() {
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
-    return AECM_HIP_OK(hipStreamSynchronize(stream_));
+    return AECM_HIP_OK(hipStreamSynchronize(stream_)) && CheckQueueError();
 }
 
 bool BatchEngine::LastLaunchMs(float *ms) {

@@ -54,6 +54,10 @@ public:
     bool ExportState(int stream, void *buf);
     int32_t ImportState(int stream, const void *buf);       // 0 / AECM_BAD_PARAMETER_ERROR / AECM_UNSPECIFIED_ERROR
     void set_variant(int v) { variant_ = v; }
+    // blocks = 0: every launch in the one-stream-per-wave form.  min_streams < 0: launches of more streams than the chip
+    // holds waves take the queue form (the default); otherwise launches of more than min_streams streams do (tests).
+    void set_queue_chunk(int blocks, int min_streams) { queue_chunk_ = blocks < 0 ? 0 : blocks; queue_min_streams_ = min_streams; }
+    int DescribeLaunch(int num_blocks, int *chunk_blocks) const;
     int variant() const { return variant_; }
     const StatePtrs &state_ptrs() const { return st_; }      // for kernels launched by the session batch on stream()
 
@@ -64,6 +68,14 @@ private:
 
     int device_ = 0;
     int rotation_limit_ = 0;             // RotationStreamLimit of device_'s CU count (launch-size switch of the block kernels)
+    // The chunk-queue form of large launches (aecm_block_kernels.hip): chunk length in blocks (0 = off; AECM_QUEUE_CHUNK),
+    // the chip's resident waves, the queue's control words (grown on first use) and its error word.
+    int queue_chunk_ = 0, resident_waves_ = 0, queue_min_streams_ = -1;
+    uint32_t *queue_ctl_ = nullptr, *queue_err_ = nullptr;
+    size_t queue_ctl_bytes_ = 0;
+    bool queue_unchecked_ = false;       // a queue launch has been enqueued since the error word was last read
+    bool LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev);
+    bool CheckQueueError();
     int num_streams_ = 0;
     bool initialized_ = false;
     int variant_ = kVariantFast;

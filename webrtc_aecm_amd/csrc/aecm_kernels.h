@@ -29,6 +29,15 @@ hipError_t LaunchProcessBlocks(const StatePtrs &st, const IoView &io, int n_stre
                                int rotation_stream_limit, hipStream_t stream, const int32_t *blocks_per_stream = nullptr);
 int RotationStreamLimit(int compute_units);
 
+// The chunk-queue form of the same launch (aecm_block_kernels.hip): items of chunk_blocks blocks claimed in order by a
+// grid that just fills the chip.  ctl: QueueControlBytes(n_streams) of device memory owned by the engine (cleared by the
+// launch); *err (device, never cleared by a launch) becomes non-zero if a wave gave up waiting for its predecessor.
+size_t QueueControlBytes(int n_streams);
+bool QueueLaunchApplies(int n_streams, int n_blocks, int variant, int chunk_blocks, int min_streams, bool ragged);
+hipError_t LaunchProcessBlocksQueued(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int chunk_blocks,
+                                     int resident_waves, uint32_t *ctl, uint32_t *err, hipStream_t stream);
+int ResidentWaves(int compute_units);
+
 // Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into
 // streams [first, first + count) and clear their far-spectrum history.
 hipError_t LaunchBroadcastImage(const StatePtrs &st, const uint32_t *image_vec, const int32_t *image_scal,

@@ -1046,24 +1046,25 @@ struct BlockEngine {
         r.near_log = lo16(w); r.adapt_log = hi16(w);
         w = V(V_M01);
         r.m01 = w;
+        const auto row = W::load_scalar_row(scal);
         Uniform &u = r.u;
         u.log_pos = 0;
-        u.tot_count = W::uni(scal[S_TOTCOUNT]); u.seed = W::uni(scal[S_SEED]); u.startup = W::uni(scal[S_STARTUP]); u.hist_pos = W::uni(scal[S_HISTPOS]);
-        u.dfa_noisy_q = W::uni(scal[S_DFANOISYQ]); u.dfa_noisy_q_old = W::uni(scal[S_DFANOISYQ_OLD]);
-        u.dfa_clean_q = W::uni(scal[S_DFACLEANQ]); u.dfa_clean_q_old = W::uni(scal[S_DFACLEANQ_OLD]);
-        u.far_log = W::uni(scal[S_FARLOG]); u.fe_min = W::uni(scal[S_FE_MIN]); u.fe_max = W::uni(scal[S_FE_MAX]); u.fe_maxmin = W::uni(scal[S_FE_MAXMIN]);
-        u.fe_vad = W::uni(scal[S_FE_VAD]); u.fe_mse = W::uni(scal[S_FE_MSE]); u.cur_vad = W::uni(scal[S_CURVAD]); u.vad_cnt = W::uni(scal[S_VADCNT]);
-        u.first_vad = W::uni(scal[S_FIRSTVAD]); u.mse_cnt = W::uni(scal[S_MSECNT]); u.mse_adapt_old = W::uni(scal[S_MSE_ADAPT_OLD]);
-        u.mse_stored_old = W::uni(scal[S_MSE_STORED_OLD]); u.mse_thresh = W::uni(scal[S_MSE_THRESH]);
-        u.sup_gain = W::uni(scal[S_SUPGAIN]); u.sup_gain_old = W::uni(scal[S_SUPGAIN_OLD]); u.noise_ctr = W::uni(scal[S_NOISECTR]);
-        u.far_init = W::uni(scal[S_FAR_INIT]); u.near_init = W::uni(scal[S_NEAR_INIT]); u.min_prob = W::uni(scal[S_MIN_PROB]);
-        u.last_prob = W::uni(scal[S_LAST_PROB]); u.last_delay = W::uni(scal[S_LAST_DELAY]);
-        u.mult = W::uni(scal[S_MULT]); u.cng = W::uni(scal[S_CNG]); u.nlp = W::uni(scal[S_NLP]); u.fixed_delay = W::uni(scal[S_FIXED_DELAY]);
-        u.sg_a = W::uni(scal[S_SG_A]); u.sg_d = W::uni(scal[S_SG_D]); u.sg_dab = W::uni(scal[S_SG_DAB]); u.sg_dbd = W::uni(scal[S_SG_DBD]);
+        u.tot_count = row.get(S_TOTCOUNT); u.seed = row.get(S_SEED); u.startup = row.get(S_STARTUP); u.hist_pos = row.get(S_HISTPOS);
+        u.dfa_noisy_q = row.get(S_DFANOISYQ); u.dfa_noisy_q_old = row.get(S_DFANOISYQ_OLD);
+        u.dfa_clean_q = row.get(S_DFACLEANQ); u.dfa_clean_q_old = row.get(S_DFACLEANQ_OLD);
+        u.far_log = row.get(S_FARLOG); u.fe_min = row.get(S_FE_MIN); u.fe_max = row.get(S_FE_MAX); u.fe_maxmin = row.get(S_FE_MAXMIN);
+        u.fe_vad = row.get(S_FE_VAD); u.fe_mse = row.get(S_FE_MSE); u.cur_vad = row.get(S_CURVAD); u.vad_cnt = row.get(S_VADCNT);
+        u.first_vad = row.get(S_FIRSTVAD); u.mse_cnt = row.get(S_MSECNT); u.mse_adapt_old = row.get(S_MSE_ADAPT_OLD);
+        u.mse_stored_old = row.get(S_MSE_STORED_OLD); u.mse_thresh = row.get(S_MSE_THRESH);
+        u.sup_gain = row.get(S_SUPGAIN); u.sup_gain_old = row.get(S_SUPGAIN_OLD); u.noise_ctr = row.get(S_NOISECTR);
+        u.far_init = row.get(S_FAR_INIT); u.near_init = row.get(S_NEAR_INIT); u.min_prob = row.get(S_MIN_PROB);
+        u.last_prob = row.get(S_LAST_PROB); u.last_delay = row.get(S_LAST_DELAY);
+        u.mult = row.get(S_MULT); u.cng = row.get(S_CNG); u.nlp = row.get(S_NLP); u.fixed_delay = row.get(S_FIXED_DELAY);
+        u.sg_a = row.get(S_SG_A); u.sg_d = row.get(S_SG_D); u.sg_dab = row.get(S_SG_DAB); u.sg_dbd = row.get(S_SG_DBD);
         BinState<int> &e = r.b64;
-        e.ch_stored = W::uni(scal[S_B64_CHSTORED]); e.ch_adapt16 = W::uni(scal[S_B64_CHADAPT16]); e.ch_adapt32 = W::uni(scal[S_B64_CHADAPT32]);
-        e.echo_filt = W::uni(scal[S_B64_ECHOFILT]); e.near_filt = W::uni(scal[S_B64_NEARFILT]); e.noise_est = W::uni(scal[S_B64_NOISE]);
-        e.low_ctr = W::uni(scal[S_B64_LOWCTR]); e.high_ctr = W::uni(scal[S_B64_HIGHCTR]);
+        e.ch_stored = row.get(S_B64_CHSTORED); e.ch_adapt16 = row.get(S_B64_CHADAPT16); e.ch_adapt32 = row.get(S_B64_CHADAPT32);
+        e.echo_filt = row.get(S_B64_ECHOFILT); e.near_filt = row.get(S_B64_NEARFILT); e.noise_est = row.get(S_B64_NOISE);
+        e.low_ctr = row.get(S_B64_LOWCTR); e.high_ctr = row.get(S_B64_HIGHCTR);
     }
 
     static AECM_HD void store_state(const Regs &r, uint32_t *vec, int32_t *scal) {
@@ -1088,20 +1089,20 @@ struct BlockEngine {
         V(V_HQ, zext16(r.hq0) | shl(sel(second, r.hq1, sel(logs, W::bpermute(r.stored_log, down36), vi(0))), 16));
         if (W::is_first_lane()) {
             const Uniform &u = r.u;
-            scal[S_TOTCOUNT] = u.tot_count; scal[S_SEED] = u.seed; scal[S_STARTUP] = u.startup; scal[S_HISTPOS] = u.hist_pos;
-            scal[S_DFANOISYQ] = u.dfa_noisy_q; scal[S_DFANOISYQ_OLD] = u.dfa_noisy_q_old;
-            scal[S_DFACLEANQ] = u.dfa_clean_q; scal[S_DFACLEANQ_OLD] = u.dfa_clean_q_old;
-            scal[S_FARLOG] = u.far_log; scal[S_FE_MIN] = u.fe_min; scal[S_FE_MAX] = u.fe_max; scal[S_FE_MAXMIN] = u.fe_maxmin;
-            scal[S_FE_VAD] = u.fe_vad; scal[S_FE_MSE] = u.fe_mse; scal[S_CURVAD] = u.cur_vad; scal[S_VADCNT] = u.vad_cnt;
-            scal[S_FIRSTVAD] = u.first_vad; scal[S_MSECNT] = u.mse_cnt; scal[S_MSE_ADAPT_OLD] = u.mse_adapt_old;
-            scal[S_MSE_STORED_OLD] = u.mse_stored_old; scal[S_MSE_THRESH] = u.mse_thresh;
-            scal[S_SUPGAIN] = u.sup_gain; scal[S_SUPGAIN_OLD] = u.sup_gain_old; scal[S_NOISECTR] = u.noise_ctr;
-            scal[S_FAR_INIT] = u.far_init; scal[S_NEAR_INIT] = u.near_init; scal[S_MIN_PROB] = u.min_prob;
-            scal[S_LAST_PROB] = u.last_prob; scal[S_LAST_DELAY] = u.last_delay;
+            W::store_scalar(scal, S_TOTCOUNT, u.tot_count); W::store_scalar(scal, S_SEED, u.seed); W::store_scalar(scal, S_STARTUP, u.startup); W::store_scalar(scal, S_HISTPOS, u.hist_pos);
+            W::store_scalar(scal, S_DFANOISYQ, u.dfa_noisy_q); W::store_scalar(scal, S_DFANOISYQ_OLD, u.dfa_noisy_q_old);
+            W::store_scalar(scal, S_DFACLEANQ, u.dfa_clean_q); W::store_scalar(scal, S_DFACLEANQ_OLD, u.dfa_clean_q_old);
+            W::store_scalar(scal, S_FARLOG, u.far_log); W::store_scalar(scal, S_FE_MIN, u.fe_min); W::store_scalar(scal, S_FE_MAX, u.fe_max); W::store_scalar(scal, S_FE_MAXMIN, u.fe_maxmin);
+            W::store_scalar(scal, S_FE_VAD, u.fe_vad); W::store_scalar(scal, S_FE_MSE, u.fe_mse); W::store_scalar(scal, S_CURVAD, u.cur_vad); W::store_scalar(scal, S_VADCNT, u.vad_cnt);
+            W::store_scalar(scal, S_FIRSTVAD, u.first_vad); W::store_scalar(scal, S_MSECNT, u.mse_cnt); W::store_scalar(scal, S_MSE_ADAPT_OLD, u.mse_adapt_old);
+            W::store_scalar(scal, S_MSE_STORED_OLD, u.mse_stored_old); W::store_scalar(scal, S_MSE_THRESH, u.mse_thresh);
+            W::store_scalar(scal, S_SUPGAIN, u.sup_gain); W::store_scalar(scal, S_SUPGAIN_OLD, u.sup_gain_old); W::store_scalar(scal, S_NOISECTR, u.noise_ctr);
+            W::store_scalar(scal, S_FAR_INIT, u.far_init); W::store_scalar(scal, S_NEAR_INIT, u.near_init); W::store_scalar(scal, S_MIN_PROB, u.min_prob);
+            W::store_scalar(scal, S_LAST_PROB, u.last_prob); W::store_scalar(scal, S_LAST_DELAY, u.last_delay);
             const BinState<int> &e = r.b64;
-            scal[S_B64_CHSTORED] = e.ch_stored; scal[S_B64_CHADAPT16] = e.ch_adapt16; scal[S_B64_CHADAPT32] = e.ch_adapt32;
-            scal[S_B64_ECHOFILT] = e.echo_filt; scal[S_B64_NEARFILT] = e.near_filt; scal[S_B64_NOISE] = e.noise_est;
-            scal[S_B64_LOWCTR] = e.low_ctr; scal[S_B64_HIGHCTR] = e.high_ctr;
+            W::store_scalar(scal, S_B64_CHSTORED, e.ch_stored); W::store_scalar(scal, S_B64_CHADAPT16, e.ch_adapt16); W::store_scalar(scal, S_B64_CHADAPT32, e.ch_adapt32);
+            W::store_scalar(scal, S_B64_ECHOFILT, e.echo_filt); W::store_scalar(scal, S_B64_NEARFILT, e.near_filt); W::store_scalar(scal, S_B64_NOISE, e.noise_est);
+            W::store_scalar(scal, S_B64_LOWCTR, e.low_ctr); W::store_scalar(scal, S_B64_HIGHCTR, e.high_ctr);
         }
     }
 

@@ -91,9 +91,14 @@ extern "C" __device__ int aecm_llvm_amdgcn_writelane(int value, int lane, int ol
 // scalar registers next to the engine's): the code-size-for-registers trades of aecm_wave.h (joint scaling tests of the inverse
 // transform, the data-dependent short paths) are switched by their own AECM_*_TICK macros there.  At present all of them
 // are on in every kernel family.
-template <bool kFast, bool kPhasePrio = true, bool kTightRegisters = false>
+// kCoherentState: the stream's state (lane vectors, scalars, far-spectrum history) is handed from wave to wave INSIDE one
+// launch (the chunk-queue kernel, aecm_block_kernels.hip): every access to it is a relaxed agent-scope atomic -- on gfx950
+// a plain global_load / global_store with the sc1 bit, which is served at the level all eight XCDs share instead of the
+// CU's L1 or the XCD's L2 -- and the scalars travel as one lane vector instead of through the (non-coherent) scalar cache.
+template <bool kFast, bool kPhasePrio = true, bool kTightRegisters = false, bool kCoherentState = false>
 struct Gfx950Wave {
     static constexpr bool kTight = kTightRegisters;
+    static constexpr bool kCoherent = kCoherentState;
     using vi = int;
     using vb = bool;
     static constexpr bool kPrecomputedConstants = true;    // lane constants and LDS tables come from the host-built blob
@@ -431,12 +436,45 @@ struct Gfx950Wave {
     }
 
     // ---- memory ----
-    static __device__ __forceinline__ int load_u32(const uint32_t *p, int idx) { return (int)p[idx]; }
-    static __device__ __forceinline__ void store_u32(uint32_t *p, int idx, int v) { p[idx] = (uint32_t)v; }
+    // state words and history rows (see kCoherentState); the audio rows (load_i16 / store_i16) are read-only resp. write-only
+    // inside a launch and stay plain
+    static __device__ __forceinline__ int load_u32(const uint32_t *p, int idx) {
+        if constexpr (kCoherent) return (int)__hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return (int)p[idx];
+    }
+    static __device__ __forceinline__ void store_u32(uint32_t *p, int idx, int v) {
+        if constexpr (kCoherent) __hip_atomic_store(p + idx, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p[idx] = (uint32_t)v;
+    }
     static __device__ __forceinline__ int load_i16(const int16_t *p, int idx) { return p[idx]; }
-    static __device__ __forceinline__ int load_u16(const uint16_t *p, int idx) { return p[idx]; }
+    static __device__ __forceinline__ int load_u16(const uint16_t *p, int idx) {
+        if constexpr (kCoherent) return __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return p[idx];
+    }
     static __device__ __forceinline__ void store_i16(int16_t *p, int idx, int v) { p[idx] = (int16_t)v; }
-    static __device__ __forceinline__ void store_u16(uint16_t *p, int idx, int v) { p[idx] = (uint16_t)v; }
+    static __device__ __forceinline__ void store_u16(uint16_t *p, int idx, int v) {
+        if constexpr (kCoherent) __hip_atomic_store(p + idx, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p[idx] = (uint16_t)v;
+    }
+    // The 64 wave-uniform state words of a stream.  Plain: read where they are used (the compiler fetches them with scalar
+    // loads).  Coherent: one lane vector (word f in lane f), each word then read out of its lane.
+    struct ScalarRow {
+        const int32_t *p;
+        int v;
+        __device__ __forceinline__ int get(int f) const {
+            if constexpr (kCoherent) return __builtin_amdgcn_readlane(v, f);
+            else return __builtin_amdgcn_readfirstlane(p[f]);
+        }
+    };
+    static __device__ __forceinline__ ScalarRow load_scalar_row(const int32_t *scal) {
+        if constexpr (kCoherent) return ScalarRow{scal, (int)__hip_atomic_load(scal + lane_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        else return ScalarRow{scal, 0};
+    }
+    // called by the wave's first lane only
+    static __device__ __forceinline__ void store_scalar(int32_t *scal, int f, int v) {
+        if constexpr (kCoherent) __hip_atomic_store(scal + f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else scal[f] = v;
+    }
 };
 
 }  // namespace aecm

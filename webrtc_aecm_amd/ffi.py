@@ -39,7 +39,7 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_Synchronize", "WebRtcAecmBatch_GetLastLaunchMs",
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
-    "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant",
+    "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_DescribeLaunch",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
     "WebRtcAecmBatch_RegisterHostBuffer", "WebRtcAecmBatch_UnregisterHostBuffer",
 ]
@@ -118,6 +118,8 @@ def load():
     lib.WebRtcAecmBatch_ImportState.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmBatch_GetDigest.argtypes = [vp, C.c_int32, vp]
     lib.WebRtcAecmBatch_SetKernelVariant.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmBatch_SetLaunchChunking.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.WebRtcAecmBatch_DescribeLaunch.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     lib.WebRtcAecmSessions_Create.restype = vp
     lib.WebRtcAecmSessions_Create.argtypes = [C.c_int32, C.c_int32]
     lib.WebRtcAecmSessions_Free.argtypes = [vp]
@@ -241,6 +243,20 @@ class AecmBatch:
     def _check(rc, where):
         if rc != 0:
             raise AecmError(rc, "WebRtcAecmBatch_" + where)
+
+    def set_launch_chunking(self, chunk_blocks, min_streams=-1):
+        """Scheduling of large launches (results never depend on it): chunks of chunk_blocks blocks claimed from a queue
+        by resident wavefronts; 0 = one wavefront per stream for the whole launch."""
+        self._check(self.lib.WebRtcAecmBatch_SetLaunchChunking(self.h, chunk_blocks, min_streams), "SetLaunchChunking")
+
+    def describe_launch(self, num_blocks):
+        """(form, chunk_blocks) of a ProcessBlocks launch of num_blocks blocks: form 0 / 1 = one wavefront per stream
+        (small-launch variants / issue priority by phase), 2 = chunk queue."""
+        chunk = C.c_int32(0)
+        form = self.lib.WebRtcAecmBatch_DescribeLaunch(self.h, num_blocks, C.byref(chunk))
+        if form < 0:
+            raise AecmError(form, "WebRtcAecmBatch_DescribeLaunch")
+        return form, chunk.value
 
     def set_config(self, cng_mode, echo_mode, first=0, count=-1):
         self._check(self.lib.WebRtcAecmBatch_set_config(self.h, AecmConfig(cng_mode, echo_mode), first, count), "set_config")
