@@ -34,7 +34,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_FRAME = 384            # 128 far in + 128 near in + 128 out
 HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_SUMMARY = ROOT / "profiles" / "r03_rocprof_summary.json"
+PROFILE_SUMMARY = ROOT / "profiles" / "r04_rocprof_summary.json"
 
 
 def synth_on_device(torch, S, L, seed, device, chunk=8192):
@@ -186,18 +186,18 @@ def workload_name(S, T, fs, world, clean):
     return f"{tag}: {S} streams/GPU x {T} blocks/step, {fs} Hz, cng on, echoMode 1, inputs resident in HBM"
 
 
-def load_profile_record(lib_path, workload_key):
+def load_profile_record(lib_path, workload_key, kernel_substr):
     """Issue-port figures and HBM traffic of the dominant kernel come from separate rocprofv3 PMC passes
-    (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/r02_rocprof_summary.json), which cannot run
+    (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/r04_rocprof_summary.json), which cannot run
     inside this process.  They are only valid for the binary they were measured on: the summary stores the
     instruction-stream fingerprint of the profiled kernel (webrtc_aecm_amd/isa_census.py) and is quoted only
     when the library timed here has the same fingerprint and the same workload; otherwise it is reported as stale."""
     from webrtc_aecm_amd import isa_census
     try:
-        now = isa_census.census(lib_path)
+        now = isa_census.census(lib_path, kernel_substr)
     except Exception as e:
         return None, {"available": False, "reason": f"could not disassemble {lib_path}: {e}"}
-    static = {"kernel_fingerprint": now["fingerprint"], "static_counts": now["counts"],
+    static = {"kernel_symbol": now["kernel"], "kernel_fingerprint": now["fingerprint"], "static_counts": now["counts"],
               "static_valu_fast_class": now["valu_fast_class"], "static_valu_8cycle_class": now["valu_8cycle_class"]}
     if not PROFILE_SUMMARY.exists():
         return None, dict(static, available=False, reason=f"{PROFILE_SUMMARY.name} not recorded yet")
@@ -217,7 +217,7 @@ def load_profile_record(lib_path, workload_key):
                 model="denominators: one wave64 VALU instruction per SIMD per 4 shader cycles (measured for the integer VOP3 / "
                       "multiply / DPP class this kernel is mostly made of) resp. per 2 cycles (the SIMD-32 rate of "
                       "MI355X_MICROARCH.md, reached only by back-to-back simple VOP2 ops)",
-                source=f"profiles/{PROFILE_SUMMARY.name} (rocprofv3 SQ_* PMC passes), profiles/r03_issue_rate.md")
+                source=f"profiles/{PROFILE_SUMMARY.name} (rocprofv3 SQ_* PMC passes), profiles/r02_valu_class_census.md")
     traffic = rec.get("traffic_by_workload", {}).get(workload_key)
     return traffic, note
 
@@ -336,9 +336,15 @@ def main():
         algo_bytes = ALGO_BYTES_PER_FRAME + (128 if args.clean else 0)
         achieved = algo_bytes * S * T / kern_avg_s / 1e9
         workload_key = f"S{S}_T{T}_fs{args.fs}" + ("_clean" if args.clean else "")
-        traffic, issue = load_profile_record(aecm.library_path(), workload_key)
-        if args.variant != "fast" or args.clean:
-            traffic, issue = None, None
+        from webrtc_aecm_amd import isa_census
+        form, chunk = batch.describe_launch(C)                 # which block kernel a launch of this shape takes
+        if args.variant == "fast":
+            kernel_substr, kernel_name = isa_census.BLOCK_KERNELS[(form, bool(args.clean))]
+            traffic, issue = load_profile_record(aecm.library_path(), workload_key, kernel_substr)
+        else:
+            kernel_name, traffic, issue = f"aecm_process_kernel<safe,{'clean' if args.clean else 'noclean'}>", None, None
+        if args.clean or len(chunks) > 1:                      # the profile record is of the default workload's launch
+            traffic = None
         from webrtc_aecm_amd import build as _b
         bi = _b.build_info()                       # written next to the library when it was built (no .git on the GPU box)
         commit = (bi.get("commit") or "unknown") + ("+dirty" if bi.get("dirty") else "")
@@ -359,7 +365,9 @@ def main():
                       "per_rank_kernel_ms_per_step": [p[2] / K for p in c["per_rank"]]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": f"aecm_process_kernel<{args.variant},{'clean' if args.clean else 'noclean'}>",
+                         "kernel": kernel_name,
+                         "launch_form": {0: "one wavefront per stream (launch resident at once)", 1: "one wavefront per stream",
+                                         2: f"chunk queue: items of {chunk} blocks claimed in order by resident wavefronts"}[form],
                          "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_frame": algo_bytes,
                          "algorithmic_bytes_per_launch": algo_bytes * S * T,
                          "note": "instruction-issue-bound integer kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "

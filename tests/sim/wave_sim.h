@@ -189,6 +189,7 @@ struct SimWave {
     static int per_block(int x) { return x; }                              // device: keeps launch-invariant conditions in the loop                                   // device: issue-priority rotation
 
     static vi lane_id() { vi r; for (int i = 0; i < 64; ++i) r.v[i] = i; return r; }
+    static vi stream_lane_id() { return lane_id(); }
     static bool is_first_lane() { return true; }
     static void div_magic_lanes(const vi &d, vi &magic, vi &shift) {
         for (int i = 0; i < 64; ++i) div_magic(d.v[i], &magic.v[i], &shift.v[i]);

@@ -85,6 +85,20 @@ def test_block_kernel_register_budget(tmp_path):
         # phase-priority variants (launches larger than the chip): 7 waves per SIMD = 72 VGPRs; rotation variants (launches
         # of at most 6 waves per SIMD): 80
         assert vgprs <= (72 if phase_prio == "1" else 80) and scratch == 0, (has_clean, phase_prio, vgprs, scratch)
+    # The chunk-queue kernels (launches larger than the chip): the same 7 waves per SIMD, no scratch either (the per-lane
+    # address halves are re-formed per item, wave_gfx950.h: stream_lane_id).
+    for has_clean, max_scratch in (("0", 0), ("1", 0)):
+        m = re.search(r"^_ZN4aecm25aecm_process_queue_kernelILb%sEEE\w*:.*\n" % has_clean, text, re.M)
+        assert m, "chunk-queue kernel not found in the device assembly"
+        body = text[m.end():]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = len(re.findall(r"^\s*scratch_(load|store)", body, re.M))
+        assert vgprs <= 72 and scratch <= max_scratch, (has_clean, vgprs, scratch)
+        # state and history travel at agent scope: sc1 on every access to them, and no release / acquire fence (a write-back
+        # or invalidate of the XCD's whole L2 per item)
+        assert len(re.findall(r"global_(load|store)_\w+ .* sc1", body)) >= 30
+        assert not re.search(r"buffer_(wbl2|inv)", body), "an agent-scope fence crept into the chunk-queue kernel"
     # The tick kernel: the engine's 64 scalar state words must arrive through scalar loads.  A conditional fence, or a
     # store wider than the rings' int16 (vector types alias everything), ahead of load_state silently turns them into
     # vector loads + v_readfirstlane (profiles/r02_experiments.md).  The only 16-byte vector loads it may contain are those
@@ -123,7 +137,9 @@ def test_isa_census_of_the_built_library():
     MFMA and no scratch, and its static mix is the integer VALU + scalar mix DESIGN.md describes."""
     from webrtc_aecm_amd import build, isa_census
     c = isa_census.census(build.build())
-    assert "aecm_process_kernelILb1ELb0ELb1" in c["kernel"] and len(c["fingerprint"]) == 16
+    assert isa_census.HEADLINE_KERNEL in c["kernel"] and len(c["fingerprint"]) == 16
+    for sub, _ in isa_census.BLOCK_KERNELS.values():                   # every kernel bench.py may name exists in the library
+        assert sub in isa_census.census(build.LIB, sub)["kernel"]
     assert c["counts"]["VALU"] > 800 and c["counts"]["SALU"] > 300
     assert not any(op.startswith(("v_mfma", "scratch_")) for op in c["opcodes"])
     assert c["opcodes"].get("v_dot2c_i32_i16_e32", 0) + c["opcodes"].get("v_dot2_i32_i16", 0) >= 60

@@ -22,11 +22,11 @@ sys.path.insert(0, "$R")
 import webrtc_aecm_amd as aecm
 from webrtc_aecm_amd import isa_census
 lib = aecm.load()
-c = isa_census.census(aecm.library_path())
+c = isa_census.census(aecm.library_path(), "${CENSUS_KERNEL:-}" or isa_census.HEADLINE_KERNEL)
 from webrtc_aecm_amd import build as _b
 bi = _b.build_info()
 commit = (bi.get("commit") or "unknown") + ("+dirty" if bi.get("dirty") else "")
-print(json.dumps({"state_size_bytes": lib.WebRtcAecmBatch_state_size_bytes(), "kernel_fingerprint": c["fingerprint"],
+print(json.dumps({"state_size_bytes": lib.WebRtcAecmBatch_state_size_bytes(), "kernel_symbol": c["kernel"], "kernel_fingerprint": c["fingerprint"],
                   "static_counts": c["counts"], "static_valu_fast_class": c["valu_fast_class"], "commit": commit or None}))
 PY
 if has stats; then   # per-kernel time (same command as the bench line)

@@ -48,7 +48,7 @@ with open(ROOT / "profiles" / f"{tag}_kernel_stats.csv", "w", newline="") as f:
     w = csv.writer(f)
     for r in rows[:6]:
         w.writerow([r[0][:110]] + r[1:])
-kern_row = next(r for r in rows[1:] if "aecm_process_kernel" in r[0])
+kern_row = next(r for r in rows[1:] if "aecm_process" in r[0])
 kern_ns = float(kern_row[3])
 pmc = {}
 for p in ("prof_fetch", "prof_write", "prof_sq1", "prof_sq2", "prof_sq3", "prof_grbm"):
@@ -86,7 +86,7 @@ workload_key = f"S{S}_T{T}_fs{FS}"
 summary = {
     "command": "tools/profile_gpu.sh: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 10 "
                "--warmup 2; PMC counters in separate --pmc passes (FETCH_SIZE, WRITE_SIZE, 3 x SQ, GRBM), --kernel-trace only",
-    "measured_at_commit": meta["commit"], "kernel_fingerprint": meta["kernel_fingerprint"],
+    "measured_at_commit": meta["commit"], "kernel_symbol": meta.get("kernel_symbol"), "kernel_fingerprint": meta["kernel_fingerprint"],
     "static_counts": meta["static_counts"], "static_valu_fast_class": meta["static_valu_fast_class"],
     "workload": {"streams": S, "blocks_per_launch": T, "frames_per_launch": frames, "fs": FS},
     "kernel": kern_row[0][:80],

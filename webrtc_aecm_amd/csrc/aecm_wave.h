@@ -185,7 +185,7 @@ struct BlockEngine {
     static constexpr uint32_t lcg_inc(int j) { uint32_t c = 0; for (int i = 0; i < j; ++i) c = c * 69069u + 1u; return c; }
 
     static AECM_HD void init_lane_constants(Regs &r, const uint32_t *consts) {
-        r.lane = W::lane_id();
+        r.lane = W::stream_lane_id();
         r.brev = bitrev6(r.lane);
         r.k_p = W::opaque_const(32770);
         r.lcg_mul64 = (int)lcg_pow(64);

@@ -185,6 +185,14 @@ struct Gfx950Wave {
         }
     }
     static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+    // The lane id the per-stream addresses of run_stream_io are built from.  In the chunk-queue kernel, which runs many
+    // streams per wave, a copy the compiler cannot see through: the per-lane halves of those 64-bit addresses are then
+    // formed per item instead of being hoisted out of the item loop into registers that do not exist (scratch spills).
+    static __device__ __forceinline__ int stream_lane_id() {
+        int t = lane_id();
+        if constexpr (kCoherent) asm volatile("" : "+v"(t));
+        return t;
+    }
     static __device__ __forceinline__ bool is_first_lane() { return lane_id() == 0; }
     static __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
     static __device__ __forceinline__ void div_magic_lanes(int d, int &magic, int &shift) { div_magic(d, &magic, &shift); }

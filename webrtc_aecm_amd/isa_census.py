@@ -121,7 +121,20 @@ def census_of_text(text: str):
     return out
 
 
-def census(lib_path, kernel_substr: str = "aecm_process_kernelILb1ELb0ELb1"):
+# The block kernel a launch takes, by WebRtcAecmBatch_DescribeLaunch's form (fast variant; with / without a clean input):
+# mangled-name fragment and the name bench.py prints.
+BLOCK_KERNELS = {
+    (0, False): ("aecm_process_kernelILb1ELb0ELb0", "aecm_process_kernel<fast,noclean,rotation>"),
+    (0, True): ("aecm_process_kernelILb1ELb1ELb0", "aecm_process_kernel<fast,clean,rotation>"),
+    (1, False): ("aecm_process_kernelILb1ELb0ELb1", "aecm_process_kernel<fast,noclean>"),
+    (1, True): ("aecm_process_kernelILb1ELb1ELb1", "aecm_process_kernel<fast,clean>"),
+    (2, False): ("aecm_process_queue_kernelILb0E", "aecm_process_queue_kernel<noclean>"),
+    (2, True): ("aecm_process_queue_kernelILb1E", "aecm_process_queue_kernel<clean>"),
+}
+HEADLINE_KERNEL = BLOCK_KERNELS[(2, False)][0]       # bench.py's default workload (65 536 streams: larger than the chip)
+
+
+def census(lib_path, kernel_substr: str = HEADLINE_KERNEL):
     """Census of the first kernel whose mangled name contains kernel_substr (default: the headline block kernel)."""
     all_k = census_of_text(disassemble(lib_path))
     for name, c in all_k.items():
@@ -133,6 +146,6 @@ def census(lib_path, kernel_substr: str = "aecm_process_kernelILb1ELb0ELb1"):
 if __name__ == "__main__":
     from . import build as _build
     lib = sys.argv[1] if len(sys.argv) > 1 else _build.LIB
-    c = census(lib, sys.argv[2] if len(sys.argv) > 2 else "aecm_process_kernelILb1ELb0ELb1")
+    c = census(lib, sys.argv[2] if len(sys.argv) > 2 else HEADLINE_KERNEL)
     c["opcodes"] = dict(list(c["opcodes"].items())[:40])
     print(json.dumps(c, indent=1))
