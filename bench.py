@@ -354,7 +354,8 @@ def main():
             "ms_per_step": c["seconds"] / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (Q-format fixed point)", "data": "synthetic",
             "config": {"workload": workload_name(S, T, args.fs, world, args.clean),
-                       "streams_per_gpu": S, "blocks_per_step": T, "launches_per_step": len(chunks), "fs": args.fs, "kernel_variant": args.variant,
+                       "streams_per_gpu": S, "blocks_per_step": T, "launches_per_step": len(chunks), "launch_form": form,
+                       "launch_chunk_blocks": chunk, "fs": args.fs, "kernel_variant": args.variant,
                        "sharding": f"static, {world} x {S} independent streams, no data-path collective",
                        "timed_region_s": c["seconds"], "commit": commit},
             "device": dict(zip(("name", "compute_units", "clock_khz"), aecm.device_info(local_rank))),

@@ -54,7 +54,14 @@ pmc = {}
 for p in ("prof_fetch", "prof_write", "prof_sq1", "prof_sq2", "prof_sq3", "prof_grbm"):
     pmc.update(agg(SRC / p / "bench_counter_collection.csv"))
 cal = agg(SRC / "prof_fetch_cal" / "bench_counter_collection.csv")
-known_read = frames * 256 + S * state_bytes               # inputs + one state load, no history reads (fixed delay 0)
+# chunk-queue launches (bench line: config.launch_chunk_blocks) load and store a stream's state once per chunk
+import re as _re
+chunk = bl["config"].get("launch_chunk_blocks")
+if chunk is None:
+    m = _re.search(r"items of (\d+) blocks", bl["roofline"].get("launch_form", ""))
+    chunk = int(m.group(1)) if m else 0
+state_trips = -(-T // chunk) if chunk else 1
+known_read = frames * 256 + S * state_bytes * state_trips  # inputs + the state loads, no history reads (fixed delay 0)
 fetch_factor = known_read / (cal["FETCH_SIZE"] * 1024)
 gui = pmc["GRBM_GUI_ACTIVE"] / 8                          # summed over the 8 XCDs
 fetch = pmc["FETCH_SIZE"] * 1024 * fetch_factor
@@ -88,7 +95,8 @@ summary = {
                "--warmup 2; PMC counters in separate --pmc passes (FETCH_SIZE, WRITE_SIZE, 3 x SQ, GRBM), --kernel-trace only",
     "measured_at_commit": meta["commit"], "kernel_symbol": meta.get("kernel_symbol"), "kernel_fingerprint": meta["kernel_fingerprint"],
     "static_counts": meta["static_counts"], "static_valu_fast_class": meta["static_valu_fast_class"],
-    "workload": {"streams": S, "blocks_per_launch": T, "frames_per_launch": frames, "fs": FS},
+    "workload": {"streams": S, "blocks_per_launch": T, "frames_per_launch": frames, "fs": FS, "launch_chunk_blocks": chunk,
+                 "state_round_trips_per_launch": state_trips},
     "kernel": kern_row[0][:80],
     "kernel_avg_ms_rocprof": kern_ns / 1e6, "kernel_calls": int(kern_row[1]),
     "kernel_avg_ms_hip_events_same_run": bl["roofline"]["kernel_avg_ms"],
@@ -96,7 +104,7 @@ summary = {
     "pmc_avg_per_launch": pmc,
     "fetch_size_calibration": {"known_read_bytes": known_read, "raw_fetch_bytes": cal["FETCH_SIZE"] * 1024,
                                "factor": fetch_factor,
-                               "how": f"bench.py --fixed-delay 0: no far-history reads, reads = 256 B/frame + {state_bytes} B/stream"},
+                               "how": f"bench.py --fixed-delay 0: no far-history reads, reads = 256 B/frame + {state_bytes} B/stream x {state_trips} state load(s) per launch"},
     "derived": derived,
     "traffic_by_workload": {workload_key: fetch + write},
 }
