@@ -89,6 +89,7 @@ SIM_UN(popc, popc(x))
 SIM_UN(pk_abs_sat_i16, pk_abs_sat_i16(x))
 SIM_UN(pk_neg_i16, pk_neg_i16(x))
 SIM_UN(opaque_v, opaque_v(x))
+SIM_UN(pk_nonzero_u16, pk_nonzero_u16(x))
 SIM_UN(max_halves_i16, max_halves_i16(x))
 #undef SIM_UN
 

@@ -473,6 +473,10 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
                 if (mad16_lo((int)0x80008000, -32768, 1) != 0x40000001 || mad16_hi((int)0x7fff0000, -32768, -32770) != (int)0xbffffffe) bump(4);
                 const int ml = imax(sext16(x), sext16(y)), mh = imax(sar(x, 16), sar(y, 16));
                 if (pk_max_i16(x, y) != ((ml & 0xffff) | (int)((unsigned)mh << 16))) bump(4);
+                // per half "non-zero" (v_pk_min_u16 with an inline constant, as assembly); random words and words with an empty half
+                const int xz[4] = {x, x & 0xffff, (int)((unsigned)x & 0xffff0000u), 0};
+                for (int k = 0; k < 4; ++k)
+                    if (pk_nonzero_u16(xz[k]) != ((((unsigned)xz[k] & 0xffffu) != 0 ? 1 : 0) | (((unsigned)xz[k] >> 16) != 0 ? 0x10000 : 0))) bump(4);
             }
             // 5: ballot bit order
             const bool p = (v >> 3) & 1;

@@ -235,6 +235,17 @@ AECM_PK_BINOP(pk_ashr_i16, al >> (bl & 15), ah >> (bh & 15))
 AECM_PK_BINOP(pk_min_u16, ul < vl ? ul : vl, uh < vh ? uh : vh)
 #undef AECM_PK_BINOP
 #endif
+// per half: 1 where the half is non-zero, else 0.  v_pk_min_u16 with the inline constant 1, as assembly: written as a
+// minimum (or a comparison) the compiler turns it into per-half compares, selects and a re-pack -- five instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+AECM_HD int pk_nonzero_u16(int x) {
+    int r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(x));
+    return r;
+}
+#else
+AECM_HD int pk_nonzero_u16(int x) { return (((unsigned)x & 0xffffu) != 0 ? 1 : 0) | (((unsigned)x >> 16) != 0 ? 0x10000 : 0); }
+#endif
 // x, as a value the optimiser cannot see through (it otherwise rewrites packed arithmetic it recognises -- a multiply by a
 // 0 / 1 factor -- into per-half compares, selects and a re-pack: six instructions for one)
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -561,7 +561,10 @@ struct BlockEngine {
         }
         r.mean = mean_step(v, 6, r.mean);
         const uint64_t bits = W::ballot(v > r.mean);
-        near_word = (int)(uint32_t)((bits >> (kBandFirst + 32)) | (bits << (32 - kBandFirst)));   // bins 12..31 from lanes 44..63, bins 32..43 from lanes 0..11
+        // bins 12..31 from lanes 44..63, bins 32..43 from lanes 0..11.  Two scalar shifts and an or, each half pinned to the
+        // scalar unit: written as one 64-bit expression the compiler picks v_alignbit_b32 and moves both halves of the
+        // (wave-uniform) ballot into vector registers for it
+        near_word = W::per_block(W::per_block((int)((uint32_t)(bits >> 32) >> kBandFirst)) | W::per_block((int)((uint32_t)bits << (32 - kBandFirst))));
         return (int)(uint32_t)(bits >> kBandFirst);
     }
 
@@ -582,7 +585,7 @@ struct BlockEngine {
         const vi diff = pk_sub_i16(bc, r.m01);                                                    // |.| <= 2^14
         const vi round = pk_ashr_i16(diff, vi(0x000f000f)) & pk_sub_i16(pk_shl_b16(vi(0x00010001), factor), vi(0x00010001));
         const vi step = pk_ashr_i16(pk_add_i16(diff, round), factor);                             // truncating toward zero
-        r.m01 = pk_mad_u16(step, opaque_v(pk_min_u16(fb, vi(0x00010001))), r.m01);                          // only where the far word has a bit set (:558)
+        r.m01 = pk_mad_u16(step, pk_nonzero_u16(fb), r.m01);                                                // only where the far word has a bit set (:558)
         // first minimum / maximum over the 100 means (:568-576): (mean << 7 | slot) is a total order
         const vi m0 = zext16(r.m01), m1 = lsr(r.m01, 16);
         vi key0 = shl(m0, 7) | r.lane;

@@ -400,7 +400,10 @@ struct Gfx950Wave {
     static __device__ __forceinline__ int bpermute(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
     static __device__ __forceinline__ int shift_up1(int v, int fill) {
         if constexpr (kFast) {
-            return AECM_DPP(fill, v, kDppWaveShr1, 0xf, 0xf, false);   // lane 0 has no source: keeps `old` = fill
+            // in place (lane 0, which has no source, keeps its own value) and then lane 0 written from the scalar side: the
+            // result can live in the register of v -- with `fill` as the old value it needs a register of its own, a move of
+            // the fill into it and, for a history carried round the block loop, a copy back
+            return writelane(AECM_DPP(v, v, kDppWaveShr1, 0xf, 0xf, false), fill, 0);
         } else {
             int t = __shfl_up(v, 1);
             return lane_id() == 0 ? fill : t;
