@@ -172,8 +172,8 @@ void BuildKernelConstants(std::vector<uint32_t> *blob) {
         lc[LC_DIV_MAGIC * kLanes + t] = (uint32_t)magic;
         lc[LC_DIV_SHIFT * kLanes + t] = (uint32_t)shift;
         const int brev = BitRev6(t);
-        lc[LC_HANN_LO * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[t];
-        lc[LC_HANN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - t];
+        lc[LC_HANN_LO * kLanes + t] = (uint32_t)((int32_t)kAecmSqrtHanningQ14[t] << 2);          // << 2: aecm_wave.h, window()
+        lc[LC_HANN_HI * kLanes + t] = (uint32_t)((int32_t)kAecmSqrtHanningQ14[64 - t] << 2);
         lc[LC_HANN_SYN_LO * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[brev];
         lc[LC_HANN_SYN_HI * kLanes + t] = (uint32_t)(int32_t)kAecmSqrtHanningQ14[64 - brev];
         lc[LC_BIN0_REAL * kLanes + t] = t == 0 ? 0x0000ffffu : 0xffffffffu;

@@ -83,7 +83,7 @@ constexpr size_t kHistWordsPerStream = size_t(kHistory) * kLanes;   // uint16 un
 enum LaneConstRow : int {
     LC_LCG_MUL = 0, LC_LCG_ADD,          // LCG jump-ahead A^t, C_t (reference spl.cc:129-147)
     LC_DIV_MAGIC, LC_DIV_SHIFT,          // reciprocal of (bin index + 1) (aecm_core.cc:904)
-    LC_HANN_LO, LC_HANN_HI,              // analysis window hann[t], hann[64-t]
+    LC_HANN_LO, LC_HANN_HI,              // analysis window hann[t] << 2, hann[64-t] << 2
     LC_HANN_SYN_LO, LC_HANN_SYN_HI,      // synthesis window in IFFT output lane order
     LC_BIN0_REAL,                        // 0x0000ffff in lane 0, all ones elsewhere: and-mask that clears bin 0's imaginary half (aecm_core_c.cc:296)
     LC_NOT_BIN0,                         // 0 in lane 0, all ones elsewhere: bin 0 gets no comfort noise (aecm_core_c.cc:146-147)

@@ -198,8 +198,8 @@ struct BlockEngine {
             return;
         }
         // definition (the host builds the blob from the same formulas; tests compare the two)
-        r.lc[LC_HANN_LO] = sext16(W::hann(r.lane));                 // analysis window, first half : hann[t]
-        r.lc[LC_HANN_HI] = sext16(W::hann(vi(64) - r.lane));        //                  second half: hann[64-t]
+        r.lc[LC_HANN_LO] = shl(sext16(W::hann(r.lane)), 2);         // analysis window << 2 (see window()), first half : hann[t]
+        r.lc[LC_HANN_HI] = shl(sext16(W::hann(vi(64) - r.lane)), 2);     //                                second half: hann[64-t]
         r.lc[LC_HANN_SYN_LO] = sext16(W::hann(r.brev));             // synthesis window in IFFT output lane order
         r.lc[LC_HANN_SYN_HI] = sext16(W::hann(vi(64) - r.brev));
         vi a = vi(1), c = vi(0);
@@ -271,6 +271,19 @@ struct BlockEngine {
         vi acc = add(mul24(vi(32767), lo16(b)), shl_add(lo16(a), 15, 32769));
         b = lsr(sub(shl_add(a, 16, 65537), acc), 16);
         a = lsr(acc, 16);
+    }
+
+    // The same stage fed straight from the analysis window (window()): a, b arrive as the products x * (hann << 2), whose
+    // UPPER halves are the windowed samples w_a, w_b (the reference's (x * hann) >> 14 truncated to int16, aecm_core_c.cc:
+    // 174-182).  v_mad_i32_i16 multiplies an upper half in place, so neither sample is ever extracted: with
+    //     nacc = w_a * (-32768) + (w_b * (-32767) - 32769) = -acc          (acc as in fft_stage0_real, modulo 2^32)
+    // the outputs are  a' = upper half of -nacc  and  b' = upper half of (w_a << 16) + 65537 + nacc,  where w_a << 16 is the
+    // product with its lower half masked off: two multiply-adds, a mask, a three-operand add, a negation and two shifts for
+    // the window's two narrowing shifts, their sign extensions and the whole of stage 0.
+    static AECM_HD void fft_stage0_windowed(vi &a, vi &b) {
+        const vi nacc = mad16_hi(a, vi(-32768), mad16_hi_uc(b, vi(-32767), -32769));
+        b = lsr(add(add(a & (int)0xffff0000, nacc), 65537), 16);
+        a = lsr(neg(nacc), 16);
     }
 
     // Forward stages 1..6 as 4 multiply-adds + 4 dot products + 2 byte permutes.  With K = -32768,
@@ -450,8 +463,10 @@ struct BlockEngine {
     // and 4 (bound 5621); a group whose joint test fails falls back to the per-stage tests, stages 5 and 6 always test
     // for themselves.  On speech-like data the joint tests pass for ~95 % / ~92 % of the blocks: 4.3 tests per block on
     // average instead of 7.  Bit-exact by construction: a skipped test is one whose outcome is proven.
-    template <bool kInverse, bool kRealInput, int N>
+    // kFirstStage = 1: stage 0 has been done by the caller (fft_stage0_windowed).
+    template <bool kInverse, bool kRealInput, int N, int kFirstStage = 0>
     static AECM_HD int fft128(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
+        static_assert(kFirstStage == 0 || (kFirstStage == 1 && !kInverse && kRealInput), "only the windowed forward transform starts at stage 1");
         int scale = 0;
         if constexpr (kInverse && N == 1 && kIfftGroupedTests > 0) {
             static_assert(no_scale_bound<1>() == 13573 && no_scale_bound<2>() == 5621 && no_scale_bound<3>() == 2327, "growth bound");
@@ -480,7 +495,7 @@ struct BlockEngine {
             }
             return scale;
         }
-        scale += fft_stage<kInverse, kRealInput, N, 0>(aa, bb, k_p);
+        if constexpr (kFirstStage == 0) scale += fft_stage<kInverse, kRealInput, N, 0>(aa, bb, k_p);
         scale += fft_stage<kInverse, kRealInput, N, 1>(aa, bb, k_p);
         scale += fft_stage<kInverse, kRealInput, N, 2>(aa, bb, k_p);
         scale += fft_stage<kInverse, kRealInput, N, 3>(aa, bb, k_p);
@@ -504,7 +519,7 @@ struct BlockEngine {
     // max_abs: max |x| over the 128 samples of the analysis window (the caller reduces the transforms
     // of one block together, see process_block).
     static AECM_HD vi abs_max(vi old_s, vi new_s) { return imax(iabs(old_s), iabs(new_s)); }
-    // The analysis window of one signal in FFT operand form; returns the dynamic Q.
+    // The analysis window of one signal, as the products stage 0 starts from; returns the dynamic Q.
     static AECM_HD int window(const Regs &r, vi old_s, vi new_s, int max_abs, vi &a, vi &b) {
         // dynamic Q: norm of max |x|, |-32768| clamped to 32767 (:288-289)
         int mx = imin(max_abs, 32767);
@@ -512,10 +527,10 @@ struct BlockEngine {
         // window (:174-182): scale, truncate to int16, multiply by sqrt-Hanning Q14, truncate
         // q = norm16(max |x|) with the maximum clamped to 32767, so x << q fits int16 for every sample of the window
         // (the reference's (int16_t) cast is the identity; for x = -32768 the clamp makes q = 0)
-        vi wo = sext16(sar(mul24(as_i16(shl(old_s, q)), lane_const<LC_HANN_LO>(r)), 14));
-        vi wn = sext16(sar(mul24(as_i16(shl(new_s, q)), lane_const<LC_HANN_HI>(r)), 14));
-        a = zext16(wo);                                     // packed (re, 0): imaginary input is zero (real_fft.c:59-65)
-        b = zext16(wn);
+        // The window rows hold hann << 2 (<= 2^16), so the windowed sample (x * hann) >> 14 -- which fits int16: |x << q| <
+        // 2^15, hann <= 2^14 -- is the UPPER half of the 32-bit product; stage 0 consumes it there (fft_stage0_windowed)
+        a = mul24(as_i16(shl(old_s, q)), lane_const<LC_HANN_LO>(r));
+        b = mul24(as_i16(shl(new_s, q)), lane_const<LC_HANN_HI>(r));
         return q;
     }
     // Spectrum of one signal from the forward transform's outputs.
@@ -979,7 +994,7 @@ struct BlockEngine {
         n16 = n16 & gate;                                                                     // bin 0 gets no comfort noise (:146-147): one mask instead of two selects
         I idx = as_i16(sar(mul24(I(359), rnd), 15));                                            // :150
         u_re = as_i16(sar(mul24(n16, W::cos360(idx)), 13));     /* |cos|, |sin| <= 2^13 */                                     // :153-156
-        u_im = as_i16(sar(mul24(neg(n16), W::sin360(idx)), 13));
+        u_im = as_i16(sar(mul24(opaque_v(neg(n16)), W::sin360(idx)), 13));   // opaque: a plain negation, not one redone in 24 bits
     }
 
     // ComfortNoise of the block (:52-164, called at :702-705) added to the suppressed spectrum (e_re, e_im | e_re64, e_im64).
@@ -1136,7 +1151,8 @@ struct BlockEngine {
                 max_abs[2] = W::reduce_max(abs_max(r.c_old, clean_new));
                 q[2] = window(r, r.c_old, clean_new, max_abs[2], fa[kSignals - 1], fb[kSignals - 1]);
             }
-            fft128<false, true, kSignals>(fa, fb, r.k_p);
+            for (int n = 0; n < kSignals; ++n) fft_stage0_windowed(fa[n], fb[n]);
+            fft128<false, true, kSignals, 1>(fa, fb, r.k_p);
             spectrum(r, fa[0], fb[0], q[0], xf);
             AECM_PHASE_MARK(1, xf.mag, xf.re);
             W::template phase_priority<2>();
@@ -1256,6 +1272,9 @@ struct BlockEngine {
             hnl64 = hnl64 < kNlpCompLow ? 0 : hnl64;
             if (num_pos < 3) { hnl = vi(0); hnl64 = 0; }
         }
+        // (the gain as a value the optimiser cannot see through: knowing that the 24-bit multiplies below only look at its
+        // low 24 bits, it otherwise carries the gain shifted left by 8 through the NLP's selects and shifts it back per use)
+        hnl = opaque_v(hnl);
         e_re = as_i16(sar(mul24(clean.re, hnl) + 8192, 14));      // |re| <= 2^15, 0 <= hnl <= 2^14                         // :680-685
         e_im = as_i16(sar(mul24(clean.im, hnl) + 8192, 14));
         e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
