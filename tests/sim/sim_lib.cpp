@@ -88,7 +88,13 @@ int sim_fft128(int16_t *re, int16_t *im, int variant) {
     const VecI kp = SimWave::opaque_const(32770);
     if (variant == 0) scale = E::fft128<false, true>(a, b, kp);
     else if (variant == 1) scale = E::fft128<false, false>(a, b, kp);
-    else scale = E::fft128<true, false>(a, b, kp);
+    else {
+        scale = E::fft128<true, false>(a, b, kp);
+        for (int t = 0; t < kLanes; ++t) {          // the inverse transform hands its real parts on in the upper halves
+            a.v[t] >>= 16;
+            b.v[t] >>= 16;
+        }
+    }
     for (int t = 0; t < kLanes; ++t) {
         int r = 0;
         for (int k = 0; k < 6; ++k) r |= ((t >> k) & 1) << (5 - k);

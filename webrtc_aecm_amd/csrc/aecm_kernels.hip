@@ -556,7 +556,11 @@ __global__ __launch_bounds__(256) void aecm_fft128_kernel(int16_t *data, int32_t
     const int kp = Gfx950Wave<kFast>::opaque_const(32770);
     if (variant == 0) scale = E::template fft128<false, true>(a, b, kp);
     else if (variant == 1) scale = E::template fft128<false, false>(a, b, kp);
-    else scale = E::template fft128<true, false>(a, b, kp);
+    else {
+        scale = E::template fft128<true, false>(a, b, kp);
+        a >>= 16;                                   // the inverse transform hands its real parts on in the upper halves
+        b >>= 16;
+    }
     int r = 0;
     for (int i = 0; i < 6; ++i) r |= ((lane >> i) & 1) << (5 - i);
     re[r] = (int16_t)a;

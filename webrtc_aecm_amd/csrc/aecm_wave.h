@@ -366,6 +366,15 @@ struct BlockEngine {
         return best;
     }
 
+    // A last stage's real-only output (S == 6: the inverse transform's a and b, the forward transform's b).  The value is the
+    // upper half of a 32-bit accumulator.  Forward: moved down (bin 64's real part is read as a 16-bit value).  Inverse:
+    // handed on as it is -- the synthesis window multiplies the upper half in place (v_mad_i32_i16 with op_sel), so the
+    // shift down and the sign extension after it never happen; whoever wants the int16 takes hi16() of it.
+    template <bool kInverse>
+    static AECM_HD vi last_real(vi acc) {
+        if constexpr (kInverse) return acc;
+        else return lsr(acc, 16);
+    }
     // kProvenNoScale (inverse only): the caller has shown that this stage's max |x| is <= 13573.
     template <bool kInverse, int S, int N, bool kProvenNoScale = false>
     static AECM_HD int fft_stage_generic(vi (&aa)[N], vi (&bb)[N], const vi &k_p) {
@@ -398,8 +407,8 @@ struct BlockEngine {
                     vi acc_im = vi(0), z_im = vi(0);
                     if (kNeedImA) acc_im = dot2_i16(b, w_im, shl_add(hi16(a), 15, 32769));
                     if (kNeedImB) z_im = sub((a & (int)0xffff0000) + 65537, acc_im);
-                    a = kNeedImA ? pack_hi16(acc_re, acc_im) : lsr(acc_re, 16);
-                    b = kNeedImB ? pack_hi16(z_re, z_im) : lsr(z_re, 16);
+                    a = kNeedImA ? pack_hi16(acc_re, acc_im) : last_real<kInverse>(acc_re);
+                    b = kNeedImB ? pack_hi16(z_re, z_im) : last_real<kInverse>(z_re);
                 } else {
                     // shift == 2, sh = 16 (rare): Y = (x_a << 14) +- (T >> 1) + 2^15
                     vi t_re = sar(dot2_i16(b, w_re, vi(1)), 1);
@@ -410,8 +419,8 @@ struct BlockEngine {
                         a = pack_hi16(add(base_re, t_re), add(base_im, t_im));
                         b = pack_hi16(sub(base_re, t_re), sub(base_im, t_im));
                     } else {
-                        a = lsr(add(base_re, t_re), 16);
-                        b = lsr(sub(base_re, t_re), 16);
+                        a = last_real<kInverse>(add(base_re, t_re));
+                        b = last_real<kInverse>(sub(base_re, t_re));
                     }
                 }
             } else {
@@ -431,8 +440,8 @@ struct BlockEngine {
                     a = pack_hi16(v_re, v_im);
                     b = pack_hi16(z_re, z_im);
                 } else {
-                    a = lsr(v_re, 16);
-                    b = lsr(z_re, 16);
+                    a = last_real<kInverse>(v_re);
+                    b = last_real<kInverse>(z_re);
                 }
             }
         }
@@ -1298,10 +1307,10 @@ struct BlockEngine {
         AECM_PHASE_MARK(11, a, b);
         W::template phase_priority<12>();
         const int sh = out_cfft - u.dfa_clean_q;
-        // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b); real parts only
-        vi first = as_i16(sar(mul24(lo16(a), lane_const<LC_HANN_SYN_LO>(r)) + 8192, 14));               // :219-221
+        // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b): real parts only, in the UPPER halves (fft_stage_generic: last_real)
+        vi first = as_i16(sar(mad16_hi_uc(a, lane_const<LC_HANN_SYN_LO>(r), 8192), 14));                // :219-221
         vi out = sat16(add(shift_i31(first, vi(sh)), r.out_ovl));                     // :222-227; |sh| <= 14
-        vi second = sar(mul24(lo16(b), lane_const<LC_HANN_SYN_HI>(r)), 14);                             // :229-234
+        vi second = sar(mad16_hi_uc(b, lane_const<LC_HANN_SYN_HI>(r), 0), 14);                          // :229-234
         r.out_ovl = sat16(shift_i31(second, vi(sh)));
         AECM_PHASE_MARK(12, out, r.out_ovl);
         W::template phase_priority<13>();
