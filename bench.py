@@ -368,7 +368,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_name,
                          "launch_form": {0: "one wavefront per stream (launch resident at once)", 1: "one wavefront per stream",
-                                         2: f"chunk queue: items of {chunk} blocks claimed in order by resident wavefronts"}[form],
+                                         2: f"chunk queue: items of {chunk} blocks claimed in order by resident wavefronts",
+                                         3: "pipelined: six wavefronts per four streams, the transforms one block ahead in wavefronts of their own"}[form],
                          "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_frame": algo_bytes,
                          "algorithmic_bytes_per_launch": algo_bytes * S * T,
                          "note": "instruction-issue-bound integer kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "

@@ -216,12 +216,19 @@ int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
  * always.  min_streams < 0 (default): the queue form is used above the chip's resident wavefront count; >= 0: above
  * that many streams (diagnostics / tests). */
 int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, int32_t min_streams);
+/* Launches the chip holds at once (<= 4 streams x 4 workgroups per compute unit = 4 096 streams on an MI355X; fast
+ * variant, no clean near-end input) run pipelined: six wavefronts serve four streams, the state-independent transforms
+ * of a block in wavefronts of their own, one block ahead of the rest.  min_streams: the smallest batch that takes this
+ * form (default 2; <= 0: never).  Results do not depend on it.  Environment: AECM_PIPELINED (0 = never, n = from n). */
+int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
 /* Which form a ProcessBlocks launch of num_blocks blocks over the whole batch takes (for measurement tools that must name
  * the kernel they time): 0 = one wavefront per stream, kernel variants for launches the chip holds at once; 1 = one
- * wavefront per stream, issue priority by phase; 2 = the chunk queue (*chunk_blocks, if not NULL, receives the chunk). */
+ * wavefront per stream, issue priority by phase; 2 = the chunk queue (*chunk_blocks, if not NULL, receives the chunk);
+ * 3 = pipelined (six wavefronts per four streams). */
 #define AECM_LAUNCH_RESIDENT 0
 #define AECM_LAUNCH_PER_STREAM 1
 #define AECM_LAUNCH_CHUNK_QUEUE 2
+#define AECM_LAUNCH_PIPELINED 3
 int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t *chunk_blocks);
 
 /* Device self test of the wave primitives on device_id; failures[0..7] must all be 0 afterwards

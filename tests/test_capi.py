@@ -99,6 +99,15 @@ def test_block_kernel_register_budget(tmp_path):
         # or invalidate of the XCD's whole L2 per item)
         assert len(re.findall(r"global_(load|store)_\w+ .* sc1", body)) >= 30
         assert not re.search(r"buffer_(wbl2|inv)", body), "an agent-scope fence crept into the chunk-queue kernel"
+    # The pipelined kernel (launches the chip holds at once; 24 of its waves per CU): the same budget, no scratch; its two
+    # roles meet at workgroup barriers only (no polling loops: no s_sleep).
+    m = re.search(r"^_ZN4aecm29aecm_process_pipelined_kernelE\w*:.*\n", text, re.M)
+    assert m, "pipelined kernel not found in the device assembly"
+    body = text[m.end():]
+    body = body[:body.index(".end_amdhsa_kernel")]
+    vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+    assert vgprs <= 72 and not re.search(r"^\s*scratch_(load|store)", body, re.M), vgprs
+    assert len(re.findall(r"^\s*s_barrier", body, re.M)) >= 4 and not re.search(r"^\s*s_sleep", body, re.M)
     # The tick kernel: the engine's 64 scalar state words must arrive through scalar loads.  A conditional fence, or a
     # store wider than the rings' int16 (vector types alias everything), ahead of load_state silently turns them into
     # vector loads + v_readfirstlane (profiles/r02_experiments.md).  The only 16-byte vector loads it may contain are those

@@ -47,15 +47,18 @@ def test_device_fft128_on_arbitrary_complex_data(variant):
                 assert gscale[k] == scale.value, (fft_variant, k)
 
 
-@pytest.mark.parametrize("variant", [aecm.KERNEL_SAFE, aecm.KERNEL_FAST])
+@pytest.mark.parametrize("variant,pipelined", [(aecm.KERNEL_SAFE, False), (aecm.KERNEL_FAST, False), (aecm.KERNEL_FAST, True)])
 @pytest.mark.parametrize("fs", [16000, 8000])
-def test_block_parity_vs_oracle(fs, variant):
-    """64 streams x 2048 blocks (all three start-up states), mixed configs, outputs and full state."""
+def test_block_parity_vs_oracle(fs, variant, pipelined):
+    """64 streams x 2048 blocks (all three start-up states), mixed configs, outputs and full state; the fast variant in
+    both forms a launch of this size can take: one wavefront per stream, and pipelined (six wavefronts per four streams)."""
     S, T = 64, 2048
     seeds = list(range(1000, 1000 + S))
     cfgs = [stream_config(s) for s in range(S)]
     far, near = synth_streams(seeds, T, fs)
     b = aecm.AecmBatch(S, fs, variant=variant)
+    b.set_launch_pipelining(2 if pipelined else 0)
+    assert b.describe_launch(T)[0] == (3 if pipelined else 0)
     for s, (cng, em) in enumerate(cfgs):
         b.set_config(cng, em, s, 1)
     out = b.process_host(far, near)
@@ -678,6 +681,39 @@ def test_chunk_queue_launch_under_contention(fs, clean):
         for s in range(S):
             assert np.array_equal(out[s], exp[s][0]), (chunk, s)
             assert np.array_equal(b.digest(s), exp[s][1]), (chunk, s, describe_digest_diff(b.digest(s), exp[s][1]))
+        b.close()
+
+
+@pytest.mark.parametrize("fs", [16000, 8000])
+def test_pipelined_launch_sizes_and_lengths(fs):
+    """The pipelined form of launches the chip holds at once (aecm_block_kernels.hip: aecm_process_pipelined_kernel): batch
+    sizes that leave workgroups partly empty (1..9, 333 streams: a back wave or a front wave's second stream without a
+    stream), launches of 1, 2 and 3 blocks (the front waves' prologue and the last, empty trip), and launches that
+    continue each other across forms (pipelined, one wavefront per stream, pipelined): outputs and complete state."""
+    T_parts = (1, 2, 3, 130, 64)
+    T = sum(T_parts)
+    for S in (1, 2, 3, 4, 5, 7, 9, 333):
+        seeds = list(range(7500, 7500 + min(S, 24)))
+        far, near = synth_streams(seeds, T, fs)
+        exp = []
+        for k in range(len(seeds)):
+            o = pyoracle.OracleStream(fs, *stream_config(k))
+            exp.append((o.process(far[k], near[k]), o.digest()))
+        idx = np.arange(S) % len(seeds)
+        far_s, near_s = far[idx], near[idx]
+        b = aecm.AecmBatch(S, fs)
+        for s in range(S):
+            b.set_config(*stream_config(int(idx[s])), s, 1)
+        outs, pos = [], 0
+        for i, t in enumerate(T_parts):
+            b.set_launch_pipelining(0 if i == 3 else 1)
+            assert b.describe_launch(t)[0] == (0 if i == 3 else 3)
+            outs.append(b.process_host(far_s[:, pos * 64:(pos + t) * 64], near_s[:, pos * 64:(pos + t) * 64]))
+            pos += t
+        out = np.concatenate(outs, axis=1)
+        for s in range(S):
+            assert np.array_equal(out[s], exp[idx[s]][0]), (S, s)
+            assert np.array_equal(b.digest(s), exp[idx[s]][1]), (S, s, describe_digest_diff(b.digest(s), exp[idx[s]][1]))
         b.close()
 
 

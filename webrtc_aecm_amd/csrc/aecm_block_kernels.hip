@@ -144,6 +144,154 @@ void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blo
     }
 }
 
+// ---- the pipelined form: launches the chip holds at once ------------------------------------------------------------
+// With one wavefront per stream a launch of S <= 4 096 streams puts at most 4 waves on a SIMD, every one of them alternating
+// between a stretch of dense vector work (the transforms) and a long scalar-heavy stretch (delay estimator, energies,
+// channel bookkeeping, gains): 4 096 streams run at 75 % of the rate the issue ports sustain with 7 waves.  But a block's
+// first third -- windows, forward transforms and magnitudes (BlockEngine::front_block, 36 % of its vector instructions) --
+// depends on the input samples alone, not on the adaptive state.  Here a workgroup of SIX waves serves FOUR streams:
+// waves 0..3 run back_block for one stream each, waves 4 and 5 run front_block for two streams each, one block ahead, and
+// hand the spectra over through LDS (two buffers per stream, one barrier per block: while the back waves read the spectra
+// of block b the front waves write those of block b + 1).  Per stream the sequential part of a block shrinks to the back
+// part, and a SIMD holds 6 waves instead of 4 -- two of them nearly pure vector work that overlaps the others' scalar
+// stretches by construction.  4 workgroups per CU (24 waves, 4 x 27 KB of LDS) = 4 096 streams on 256 CUs, all resident.
+#ifndef AECM_PIPE_FRONT_PRIO
+#define AECM_PIPE_FRONT_PRIO 0        // the front waves' issue priority (the back waves': by phase, 1..3)
+#endif
+constexpr int kPipeStreams = 4, kPipeFrontWaves = 2, kPipeWaves = kPipeStreams + kPipeFrontWaves;
+constexpr int kPipeStreamsPerFront = kPipeStreams / kPipeFrontWaves;
+struct PipeSlot {           // the spectra of one block of one stream on their way from the front to the back wave
+    int near_x[kLanes];     // near-end spectrum, bins 0..63: re | im << 16 (im conjugated as the block path uses it)
+    int mags[kLanes];       // far-end magnitude | near-end magnitude << 16 (both <= 46 340)
+    int scalars[kLanes];    // lanes 0..4: far mag[64], far Q, near re[64], near mag[64], near Q
+};
+struct PipeShared {
+    PipeSlot slots[2][kPipeStreams];      // [block parity][stream of the workgroup]
+};
+
+// Synchronisation: ONE workgroup barrier per block.  While the back waves work on block b out of slots[b & 1], the front
+// waves write block b + 1 into slots[(b + 1) & 1]; the barrier at the end of the step makes both true for the next one.
+// Every wave of the workgroup executes 1 + n_blocks barriers whatever its role and whether or not its streams exist.
+// (Measured against rings with per-stream counters and no barrier -- pairs of waves that only wait for each other:
+// slower, 4 096 streams 783 vs 818 M frames/s.  A wave parked at a barrier costs nothing; a wave polling a counter costs
+// issue slots, and at the priority its last phase left it with it starves the wave it is waiting for.)
+__global__ __launch_bounds__(64 * kPipeWaves)
+__attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
+void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks) {
+    FillLdsTables<64 * kPipeWaves>(st.consts);
+    PipeShared &sh = *reinterpret_cast<PipeShared *>(&g_lds[1]);        // behind the tables
+    using W = Gfx950Wave<true, true>;
+    using E = BlockEngine<W, false>;
+    using EF = BlockEngine<Gfx950Wave<true, false>, false>;               // the front waves keep one priority (no per-phase s_setprio)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t first = (int64_t)blockIdx.x * kPipeStreams;
+    if (wave < kPipeStreams) {
+        // ---- back wave: one stream, everything of a block after the transforms ----
+        typename E::Regs r;
+        E::init_lane_constants(r, st.consts);
+        const int64_t stream = first + wave;
+        const bool live = stream < n_streams;
+        uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
+        int32_t *scal = st.scal + stream * (int64_t)kNumScal;
+        uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
+        typename E::StridedIo sio{io, stream * io.stream_stride};
+        if (live) E::load_state(r, vec, scal);
+        W::begin_stream();
+        __syncthreads();                                                  // the spectra of block 0 are in slots[0]
+        for (int blk = 0; blk < n_blocks; ++blk) {
+            if (live) {
+                const PipeSlot &slot = sh.slots[blk & 1][wave];
+                const int lane = W::lane_id();
+                const int x = slot.near_x[lane], m = slot.mags[lane], sc = slot.scalars[lane];
+                typename E::Spectrum xf, df;
+                xf.mag = zext16(m);
+                xf.mag64 = __builtin_amdgcn_readlane(sc, 0);
+                xf.q = __builtin_amdgcn_readlane(sc, 1);
+                xf.re = xf.im = 0;
+                xf.re64 = 0;
+                df.re = sext16(x);
+                df.im = sar(x, 16);
+                df.mag = lsr(m, 16);
+                df.re64 = __builtin_amdgcn_readlane(sc, 2);
+                df.mag64 = __builtin_amdgcn_readlane(sc, 3);
+                df.q = __builtin_amdgcn_readlane(sc, 4);
+                E::update_startup(r.u);
+                r.table_index = W::table_index_for_this_block();
+                const int out = E::back_block(r, hist, xf, df, df);
+                sio.out(r, blk, out);
+            }
+            __syncthreads();                                              // slots[blk & 1] are free again, block blk + 1 is in the others
+        }
+        if (live) E::template store_state<false>(r, vec, scal);
+    } else {
+        // ---- front wave: two streams, the transforms of the block after the one their back waves are at ----
+        typename EF::Regs r;
+        EF::init_lane_constants(r, st.consts);
+        __builtin_amdgcn_s_setprio(AECM_PIPE_FRONT_PRIO);
+        const int k0 = (wave - kPipeStreams) * kPipeStreamsPerFront;
+        int x_old[kPipeStreamsPerFront], d_old[kPipeStreamsPerFront], far_next[kPipeStreamsPerFront], near_next[kPipeStreamsPerFront];
+        bool live[kPipeStreamsPerFront];
+        for (int k = 0; k < kPipeStreamsPerFront; ++k) {
+            const int64_t stream = first + k0 + k;
+            live[k] = stream < n_streams;
+            x_old[k] = d_old[k] = far_next[k] = near_next[k] = 0;
+            if (live[k]) {
+                EF::load_time_state(st.vec + stream * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
+                typename EF::StridedIo sio{io, stream * io.stream_stride};
+                far_next[k] = sio.far(r, 0);
+                near_next[k] = sio.near(r, 0);
+            }
+        }
+        for (int blk = 0; blk <= n_blocks; ++blk) {                      // trip blk writes block blk (the last trip: nothing)
+            if (blk < n_blocks) {
+#pragma unroll
+                for (int k = 0; k < kPipeStreamsPerFront; ++k) {
+                    if (!live[k]) continue;
+                    const int far_cur = far_next[k], near_cur = near_next[k];
+                    if (blk + 1 < n_blocks) {
+                        typename EF::StridedIo sio{io, (first + k0 + k) * io.stream_stride};
+                        far_next[k] = sio.far(r, blk + 1);
+                        near_next[k] = sio.near(r, blk + 1);
+                    }
+                    r.table_index = Gfx950Wave<true, false>::table_index_for_this_block();
+                    typename EF::Spectrum xf, df, cf;
+                    EF::front_block(r, x_old[k], far_cur, d_old[k], near_cur, 0, 0, xf, df, cf);
+                    x_old[k] = far_cur;
+                    d_old[k] = near_cur;
+                    PipeSlot &slot = sh.slots[blk & 1][k0 + k];
+                    const int lane = W::lane_id();
+                    slot.near_x[lane] = (df.re & 0xffff) | (int)((unsigned)df.im << 16);
+                    slot.mags[lane] = xf.mag | (int)((unsigned)df.mag << 16);
+                    int sc = 0;
+                    sc = W::writelane(sc, xf.mag64, 0);
+                    sc = W::writelane(sc, xf.q, 1);
+                    sc = W::writelane(sc, df.re64, 2);
+                    sc = W::writelane(sc, df.mag64, 3);
+                    sc = W::writelane(sc, df.q, 4);
+                    slot.scalars[lane] = sc;
+                }
+            }
+            __syncthreads();
+        }
+        for (int k = 0; k < kPipeStreamsPerFront; ++k)
+            if (live[k]) EF::store_time_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
+    }
+}
+
+// Streams a pipelined launch keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
+int PipelinedStreamLimit(int compute_units) {
+    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / kPipeWaves, by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + sizeof(PipeShared)));
+    return (compute_units > 0 ? compute_units : 256) * (by_waves < by_lds ? by_waves : by_lds) * kPipeStreams;
+}
+
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, hipStream_t stream) {
+    if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
+    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * kPipeWaves);
+    const size_t lds = sizeof(LdsTables) + sizeof(PipeShared);
+    hipLaunchKernelGGL(aecm_process_pipelined_kernel, grid, block, lds, stream, st, io, n_streams, n_blocks);
+    return hipGetLastError();
+}
+
 size_t QueueControlBytes(int n_streams) { return ((size_t)kQueueCtlWords + (size_t)n_streams) * sizeof(uint32_t); }
 
 // Whether a launch of this shape takes the chunk-queue kernel (chunk_blocks > 0: the engine's setting).

@@ -260,6 +260,12 @@ int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, in
     return 0;
 }
 
+int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams) {
+    if (!b) return -1;
+    b->engine->set_pipelined_min_streams(min_streams);
+    return 0;
+}
+
 int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t *chunk_blocks) {
     if (!b) return -1;
     return b->engine->DescribeLaunch(num_blocks, chunk_blocks);

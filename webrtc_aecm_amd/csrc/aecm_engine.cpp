@@ -32,6 +32,8 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     e->resident_waves_ = ResidentWaves(cus);
     e->queue_chunk_ = kDefaultQueueChunk;
     if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::max(0, atoi(env));
+    e->pipe_max_streams_ = PipelinedStreamLimit(cus);
+    if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
               AECM_HIP_OK(hipMalloc((void **)&e->st_.vec, S * kVecWordsPerStream * sizeof(uint32_t))) &&
@@ -161,6 +163,12 @@ bool BatchEngine::HarvestTimers(bool wait_all) {
     return true;
 }
 
+// The word a wave of a chunk-queue or pipelined launch raises when it gives up waiting for another wave (never cleared by a launch).
+bool BatchEngine::EnsureLaunchErrorWord() {
+    if (queue_err_) return true;
+    return AECM_HIP_OK(hipMalloc((void **)&queue_err_, sizeof(uint32_t))) && AECM_HIP_OK(hipMemsetAsync(queue_err_, 0, sizeof(uint32_t), stream_));
+}
+
 // One launch of the block kernels over `count` streams (st, io already offset to the first of them), in the chunk-queue form
 // when the launch is larger than the chip (see QueueLaunchApplies).
 bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev) {
@@ -175,12 +183,19 @@ bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count,
             if (!AECM_HIP_OK(hipMalloc((void **)&queue_ctl_, need))) return false;
             queue_ctl_bytes_ = need;
         }
-        if (!queue_err_ && (!AECM_HIP_OK(hipMalloc((void **)&queue_err_, sizeof(uint32_t))) ||
-                            !AECM_HIP_OK(hipMemsetAsync(queue_err_, 0, sizeof(uint32_t), stream_)))) return false;
+        if (!EnsureLaunchErrorWord()) return false;
         queue_unchecked_ = true;
         return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, queue_chunk_, resident_waves_, queue_ctl_, queue_err_, stream_));
     }
+    if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
+        return AECM_HIP_OK(LaunchProcessBlocksPipelined(st, io, count, num_blocks, stream_));
     return AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, rotation_limit_, stream_, blocks_per_stream_dev));
+}
+
+// Launches the chip holds at once take the pipelined kernel (aecm_block_kernels.hip): fast variant, no clean input, every
+// stream the same number of blocks.
+bool BatchEngine::PipelinedLaunchApplies(int count, bool clean, bool ragged) const {
+    return variant_ == kVariantFast && !clean && !ragged && count >= pipe_min_streams_ && count <= pipe_max_streams_;
 }
 
 int BatchEngine::DescribeLaunch(int num_blocks, int *chunk_blocks) const {
@@ -189,6 +204,7 @@ int BatchEngine::DescribeLaunch(int num_blocks, int *chunk_blocks) const {
         return 2;
     }
     if (chunk_blocks) *chunk_blocks = 0;
+    if (PipelinedLaunchApplies(num_streams_, false, false)) return 3;
     return variant_ == kVariantFast && num_streams_ > rotation_limit_ ? 1 : 0;
 }
 

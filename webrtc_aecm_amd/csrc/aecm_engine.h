@@ -11,6 +11,8 @@
 
 namespace aecm {
 
+constexpr int kDefaultPipelinedMinStreams = 2;    // a single stream (the drop-in ABI's 10 ms calls) keeps its one-wave launch
+
 class BatchEngine {
 public:
     // Returns nullptr if the device cannot be used or memory cannot be allocated.
@@ -58,6 +60,7 @@ public:
     // holds waves take the queue form (the default); otherwise launches of more than min_streams streams do (tests).
     void set_queue_chunk(int blocks, int min_streams) { queue_chunk_ = blocks < 0 ? 0 : blocks; queue_min_streams_ = min_streams; }
     int DescribeLaunch(int num_blocks, int *chunk_blocks) const;
+    void set_pipelined_min_streams(int n) { pipe_min_streams_ = n > 0 ? n : 0x7fffffff; }    // n <= 0: never
     int variant() const { return variant_; }
     const StatePtrs &state_ptrs() const { return st_; }      // for kernels launched by the session batch on stream()
 
@@ -74,8 +77,13 @@ private:
     uint32_t *queue_ctl_ = nullptr, *queue_err_ = nullptr;
     size_t queue_ctl_bytes_ = 0;
     bool queue_unchecked_ = false;       // a queue launch has been enqueued since the error word was last read
+    // The pipelined form of launches the chip holds at once: from pipe_min_streams_ (AECM_PIPELINED; SetLaunchPipelining)
+    // up to PipelinedStreamLimit of the device.
+    int pipe_min_streams_ = kDefaultPipelinedMinStreams, pipe_max_streams_ = 0;
+    bool PipelinedLaunchApplies(int count, bool clean, bool ragged) const;
     bool LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev);
     bool CheckQueueError();
+    bool EnsureLaunchErrorWord();
     int num_streams_ = 0;
     bool initialized_ = false;
     int variant_ = kVariantFast;

@@ -38,6 +38,12 @@ hipError_t LaunchProcessBlocksQueued(const StatePtrs &st, const IoView &io, int 
                                      int resident_waves, uint32_t *ctl, uint32_t *err, hipStream_t stream);
 int ResidentWaves(int compute_units);
 
+// The pipelined form of a launch the chip holds at once (aecm_block_kernels.hip): six waves per four streams, the
+// state-independent transforms of a block in waves of their own, one block ahead.  Fast variant, no clean input, every
+// stream the same number of blocks.
+int PipelinedStreamLimit(int compute_units);
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, hipStream_t stream);
+
 // Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into
 // streams [first, first + count) and clear their far-spectrum history.
 hipError_t LaunchBroadcastImage(const StatePtrs &st, const uint32_t *image_vec, const int32_t *image_scal,

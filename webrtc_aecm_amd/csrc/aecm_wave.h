@@ -1094,6 +1094,18 @@ struct BlockEngine {
         e.low_ctr = row.get(S_B64_LOWCTR); e.high_ctr = row.get(S_B64_HIGHCTR);
     }
 
+    // The previous block's far / near input samples: the only state front_block reads.
+    static AECM_HD void load_time_state(const uint32_t *vec, vi lane, vi &x_old, vi &d_old) {
+        const vi w = W::load_u32(vec + V_XD_OLD * kLanes, lane);
+        x_old = lo16(w);
+        d_old = hi16(w);
+    }
+    static AECM_HD void store_time_state(uint32_t *vec, vi lane, vi x_old, vi d_old) {
+        W::store_u32(vec + V_XD_OLD * kLanes, lane, pack(x_old, d_old));
+    }
+
+    // kTimeState = false: without V_XD_OLD (a wave that only ran back_block does not have it: store_time_state)
+    template <bool kTimeState = true>
     static AECM_HD void store_state(const Regs &r, uint32_t *vec, int32_t *scal) {
         auto V = [&](int f, vi w) { W::store_u32(vec + f * kLanes, r.lane, w); };
         const vb second = r.lane < kSecondPass;                  // live lanes of the second-pass words
@@ -1101,7 +1113,7 @@ struct BlockEngine {
         // lane t (36..55) takes log entry k = t - 36, which lives in ring lane (log_pos + k) mod 20
         const vi ring = (r.lane - kSecondPass) + r.u.log_pos;
         const vi down36 = sel(ring >= kLogEntries, ring - kLogEntries, ring) & 63;
-        V(V_XD_OLD, pack(r.x_old, r.d_old));
+        if constexpr (kTimeState) V(V_XD_OLD, pack(r.x_old, r.d_old));
         V(V_OUTBUF, pack(r.out_ovl, r.c_old));
         V(V_CH16, pack(r.b.ch_stored, r.b.ch_adapt16));
         V(V_CH32, r.b.ch_adapt32);
@@ -1138,27 +1150,29 @@ struct BlockEngine {
     // sample t of the new 64-sample block (sign-extended).  Returns the output block in IFFT lane
     // order: lane t holds out[bitrev6(t)].
     // ------------------------------------------------------------------------------------------
-    static AECM_HD vi process_block(Regs &r, uint16_t *hist, vi far_new, vi near_new, vi clean_new) {
-        Uniform &u = r.u;
+    // A block comes in two parts.  front_block: TimeToFrequencyDomain of the far-end, near-end and (optional) clean near-end
+    // windows (:439, :442, :452) -- a function of the input samples alone (the previous and the new 64 of each signal), not
+    // of the adaptive state.  back_block: everything else, which is sequential per stream.  process_block is one after the
+    // other in one wave; the kernel for launches smaller than the chip (aecm_block_kernels.hip: aecm_process_pipelined_kernel)
+    // runs the two parts in different waves of a workgroup, one block apart.
+    static AECM_HD void update_startup(Uniform &u) {
         if (AECM_STEADY_NEVER(u.startup < 2)) u.startup = (gtu(u.tot_count, kConvLen - 1) ? 1 : 0) + (gtu(u.tot_count, kConvLen2 - 1) ? 1 : 0);  // :420-424
-
-        if (W::kLaneConstsInTable) r.table_index = W::table_index_for_this_block();
-
-        Spectrum xf, df, cf;
+    }
+    // r: only the lane constants are used (lane, brev, table_index).  The three transforms advance in lockstep.
+    static AECM_HD void front_block(const Regs &r, vi x_old, vi far_new, vi d_old, vi near_new, vi c_old, vi clean_new,
+                                    Spectrum &xf, Spectrum &df, Spectrum &cf) {
         AECM_PHASE_MARK(0, far_new, near_new);
         W::template phase_priority<1>();
-        // TimeToFrequencyDomain of the far-end, near-end and (optional) clean near-end windows
-        // (:439, :442, :452), transformed in lockstep.
         {
             constexpr int kSignals = kHasClean ? 3 : 2;
             int max_abs[3], q[3] = {0, 0, 0};
-            W::reduce_max2(abs_max(r.x_old, far_new), abs_max(r.d_old, near_new), max_abs[0], max_abs[1]);
+            W::reduce_max2(abs_max(x_old, far_new), abs_max(d_old, near_new), max_abs[0], max_abs[1]);
             vi fa[kSignals], fb[kSignals];
-            q[0] = window(r, r.x_old, far_new, max_abs[0], fa[0], fb[0]);
-            q[1] = window(r, r.d_old, near_new, max_abs[1], fa[1], fb[1]);
+            q[0] = window(r, x_old, far_new, max_abs[0], fa[0], fb[0]);
+            q[1] = window(r, d_old, near_new, max_abs[1], fa[1], fb[1]);
             if (kHasClean) {
-                max_abs[2] = W::reduce_max(abs_max(r.c_old, clean_new));
-                q[2] = window(r, r.c_old, clean_new, max_abs[2], fa[kSignals - 1], fb[kSignals - 1]);
+                max_abs[2] = W::reduce_max(abs_max(c_old, clean_new));
+                q[2] = window(r, c_old, clean_new, max_abs[2], fa[kSignals - 1], fb[kSignals - 1]);
             }
             for (int n = 0; n < kSignals; ++n) fft_stage0_windowed(fa[n], fb[n]);
             fft128<false, true, kSignals, 1>(fa, fb, r.k_p);
@@ -1169,6 +1183,23 @@ struct BlockEngine {
             if (kHasClean) spectrum(r, fa[kSignals - 1], fb[kSignals - 1], q[2], cf);
         }
         AECM_PHASE_MARK(2, df.mag, df.re);
+    }
+
+    static AECM_HD vi process_block(Regs &r, uint16_t *hist, vi far_new, vi near_new, vi clean_new) {
+        update_startup(r.u);
+        if (W::kLaneConstsInTable) r.table_index = W::table_index_for_this_block();
+        Spectrum xf, df, cf;
+        front_block(r, r.x_old, far_new, r.d_old, near_new, r.c_old, clean_new, xf, df, cf);
+        const vi out = back_block(r, hist, xf, df, cf);
+        r.x_old = far_new;                                                            // :239-245
+        r.d_old = near_new;
+        if (kHasClean) r.c_old = clean_new;
+        return out;
+    }
+
+    // Of xf only mag / mag64 / q are read; cf only with a clean input.
+    static AECM_HD vi back_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, const Spectrum &cf) {
+        Uniform &u = r.u;
         W::template phase_priority<3>();
         u.dfa_noisy_q_old = u.dfa_noisy_q;
         u.dfa_noisy_q = df.q;
@@ -1314,9 +1345,6 @@ struct BlockEngine {
         r.out_ovl = sat16(shift_i31(second, vi(sh)));
         AECM_PHASE_MARK(12, out, r.out_ovl);
         W::template phase_priority<13>();
-        r.x_old = far_new;                                                            // :239-245
-        r.d_old = near_new;
-        if (kHasClean) r.c_old = clean_new;
         return out;
     }
 

@@ -39,7 +39,7 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_Synchronize", "WebRtcAecmBatch_GetLastLaunchMs",
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
-    "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_DescribeLaunch",
+    "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_SetLaunchPipelining", "WebRtcAecmBatch_DescribeLaunch",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
     "WebRtcAecmBatch_RegisterHostBuffer", "WebRtcAecmBatch_UnregisterHostBuffer",
 ]
@@ -120,6 +120,7 @@ def load():
     lib.WebRtcAecmBatch_SetKernelVariant.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmBatch_SetLaunchChunking.argtypes = [vp, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DescribeLaunch.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.WebRtcAecmBatch_SetLaunchPipelining.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmSessions_Create.restype = vp
     lib.WebRtcAecmSessions_Create.argtypes = [C.c_int32, C.c_int32]
     lib.WebRtcAecmSessions_Free.argtypes = [vp]
@@ -249,9 +250,14 @@ class AecmBatch:
         by resident wavefronts; 0 = one wavefront per stream for the whole launch."""
         self._check(self.lib.WebRtcAecmBatch_SetLaunchChunking(self.h, chunk_blocks, min_streams), "SetLaunchChunking")
 
+    def set_launch_pipelining(self, min_streams):
+        """Smallest batch whose launches run pipelined (six wavefronts per four streams; results never depend on it);
+        <= 0: never."""
+        self._check(self.lib.WebRtcAecmBatch_SetLaunchPipelining(self.h, min_streams), "SetLaunchPipelining")
+
     def describe_launch(self, num_blocks):
         """(form, chunk_blocks) of a ProcessBlocks launch of num_blocks blocks: form 0 / 1 = one wavefront per stream
-        (small-launch variants / issue priority by phase), 2 = chunk queue."""
+        (small-launch variants / issue priority by phase), 2 = chunk queue, 3 = pipelined (six wavefronts per four streams)."""
         chunk = C.c_int32(0)
         form = self.lib.WebRtcAecmBatch_DescribeLaunch(self.h, num_blocks, C.byref(chunk))
         if form < 0:

@@ -130,6 +130,7 @@ BLOCK_KERNELS = {
     (1, True): ("aecm_process_kernelILb1ELb1ELb1", "aecm_process_kernel<fast,clean>"),
     (2, False): ("aecm_process_queue_kernelILb0E", "aecm_process_queue_kernel<noclean>"),
     (2, True): ("aecm_process_queue_kernelILb1E", "aecm_process_queue_kernel<clean>"),
+    (3, False): ("aecm_process_pipelined_kernel", "aecm_process_pipelined_kernel"),
 }
 HEADLINE_KERNEL = BLOCK_KERNELS[(2, False)][0]       # bench.py's default workload (65 536 streams: larger than the chip)
 
