@@ -19,6 +19,7 @@ HERE = Path(__file__).resolve().parent
 ORACLE_SO = HERE / "_build" / "libaecm_oracle.so"
 REF_SO = HERE / "_ref" / "libaecm_ref.so"
 REFMAIN = HERE / "_ref" / "aecm_run_refmain"     # the reference's main.cc, unmodified, linked against the MI355X library
+REFWAV = HERE / "_ref" / "ref_wavdec"            # the WAV reader the reference CLI uses (dr_wav.h) behind oracle/ref_wavdec.cc
 BLOCK = 64
 BINS = 65
 DIGEST_WORDS = 24
@@ -42,6 +43,8 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", str(HERE), "oracle"], stdout=subprocess.DEVNULL)
     if Path("/root/reference/aecm").is_dir() and (force or not REF_SO.exists()):
         subprocess.check_call(["make", "-C", str(HERE), "ref"], stdout=subprocess.DEVNULL)
+    if Path("/root/reference/dr_wav.h").is_file() and (force or not REFWAV.exists() or REFWAV.stat().st_mtime < (HERE / "ref_wavdec.cc").stat().st_mtime):
+        subprocess.run(["make", "-C", str(HERE), "refwav"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)   # best effort, like refmain
     product = HERE.parent / "webrtc_aecm_amd" / "_lib" / "libaecm_mi355x.so"
     if Path("/root/reference/main.cc").is_file() and product.exists() and (
             force or not REFMAIN.exists() or REFMAIN.stat().st_mtime < product.stat().st_mtime):

@@ -120,3 +120,53 @@ def drive_session(sess, far, near, frame, ms_seq, far_present=None, clean=None):
             assert rc == 0, (i, rc)
         codes[i], out[sl] = sess.process(near[sl], None if clean is None else clean[sl], int(ms_seq[i]))
     return out, codes
+
+
+# ---- WAV files in the sample formats the reference CLI reads (dr_wav) ----------------------------------------------------
+WAV_FORMATS = ("u8", "s16", "s24", "s32", "s16_ext", "s24_ext", "f32", "f64", "f32_ext", "alaw", "mulaw")
+
+
+def write_wav_format(path, rate, x, fmt):
+    """x: int16 samples.  Writes them in `fmt` (from WAV_FORMATS): values are spread over each format's range in a way that
+    exercises its rounding (float formats get non-representable fractions, 24/32-bit formats non-zero low bytes,
+    the companded formats every code)."""
+    import struct
+    x = np.asarray(x, dtype=np.int64)
+    rs = np.random.RandomState(len(x) * 31 + len(fmt))
+    ext = fmt.endswith("_ext")
+    base = fmt[:-4] if ext else fmt
+    if base == "u8":
+        tag, bits, data = 1, 8, (((x >> 8) + 128) & 0xff).astype(np.uint8).tobytes()
+    elif base == "s16":
+        tag, bits, data = 1, 16, x.astype("<i2").tobytes()
+    elif base == "s24":
+        v = (x << 8) + rs.randint(0, 256, size=x.size)
+        b = np.empty((x.size, 3), np.uint8)
+        b[:, 0], b[:, 1], b[:, 2] = v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff
+        tag, bits, data = 1, 24, b.tobytes()
+    elif base == "s32":
+        tag, bits, data = 1, 32, ((x << 16) + rs.randint(0, 65536, size=x.size)).astype("<i4").tobytes()
+    elif base in ("f32", "f64"):
+        v = x / 32768.0 + rs.uniform(-0.4, 0.4, size=x.size) / 32768.0          # off the int16 grid: the rounding rule matters
+        v[:8] = [-1.0, 1.0, -1.5, 1.5, 0.0, -0.0, 0.99999, -0.99999][: min(8, x.size)]
+        tag, bits, data = 3, (32 if base == "f32" else 64), v.astype("<f4" if base == "f32" else "<f8").tobytes()
+    elif base in ("alaw", "mulaw"):
+        codes = ((x >> 8) & 0xff).astype(np.uint8)
+        codes[:256] = np.arange(min(256, x.size), dtype=np.uint8)                 # every code once
+        tag, bits, data = (6 if base == "alaw" else 7), 8, codes.tobytes()
+    else:
+        raise ValueError(fmt)
+    align = bits // 8
+    if ext:
+        guid_tail = bytes.fromhex("000000001000800000aa00389b71")
+        fmt_chunk = struct.pack("<HHIIHHHHI", 0xFFFE, 1, rate, rate * align, align, bits, 22, bits, 4) + struct.pack("<H", tag) + guid_tail
+    else:
+        fmt_chunk = struct.pack("<HHIIHH", tag, 1, rate, rate * align, align, bits)
+        if tag != 1:
+            fmt_chunk += struct.pack("<H", 0)                                       # cbSize of the non-PCM header
+    chunks = b"fmt " + struct.pack("<I", len(fmt_chunk)) + fmt_chunk
+    if tag != 1 and not ext:
+        chunks += b"fact" + struct.pack("<II", 4, len(data) // align)
+    chunks += b"LIST" + struct.pack("<I", 5) + b"INFOx" + b"\0"                     # an odd-sized chunk to skip (padded)
+    chunks += b"data" + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+    Path(path).write_bytes(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)

@@ -159,3 +159,29 @@ def test_reference_main_cc_unmodified_on_the_gpu(tmp_path):
         out = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
     n = g["out"].size
     assert np.array_equal(out[:n], g["out"])
+
+
+def test_cli_equals_the_reference_caller_on_other_sample_formats(tmp_path):
+    """WAV pairs in 32-bit float, 24-bit PCM and mu-law: the reference's unmodified main.cc (reading through dr_wav, linked
+    to libaecm_mi355x.so) and aecm_run (its own reader) must write the same <near>_out.wav, byte for byte."""
+    import shutil
+    from helpers import write_wav_format
+    from oracle import pyoracle
+    from webrtc_aecm_amd import build
+    from webrtc_aecm_amd.synth import synth_pair
+    if not pyoracle.REFMAIN.exists():
+        pytest.skip("prebuilt oracle/_ref/aecm_run_refmain not present")
+    build.build()
+    far, near = synth_pair(77, 600, 16000, "mixed")
+    for fmt_far, fmt_near in (("f32", "f32"), ("s24", "mulaw"), ("f64_", "u8")):
+        fmt_far = fmt_far.rstrip("_")
+        outs = []
+        for who, exe in (("ref", pyoracle.REFMAIN), ("ours", build.CLI)):
+            d = tmp_path / f"{who}_{fmt_far}_{fmt_near}"
+            d.mkdir()
+            write_wav_format(d / "far.wav", 16000, far, fmt_far)
+            write_wav_format(d / "near.wav", 16000, near, fmt_near)
+            r = subprocess.run([str(exe), str(d / "far.wav"), str(d / "near.wav")], capture_output=True, text=True, input="\n", timeout=300)
+            assert r.returncode == 0, (who, fmt_far, fmt_near, r.stdout + r.stderr)
+            outs.append((d / "near_out.wav").read_bytes())
+        assert len(outs[0]) > 44 + 2 * 160 * 100 and outs[0] == outs[1], (fmt_far, fmt_near)

@@ -7,7 +7,10 @@
 //   aecm_run --batch list.txt            many pairs at once (one "far.wav near.wav" per line): all
 //                                        recordings of one sample rate are processed as one device batch
 //                                        (WebRtcAecmBatch_ProcessRecordingsHost), one wavefront per file
-// Minimal RIFF/WAVE PCM-16 reader/writer (the reference uses dr_wav.h for I/O only).
+//   aecm_run --decode in.wav out.wav     read in.wav the way the pair modes do and write it back as 16-bit PCM
+//                                        (which sample formats are read, and how they become int16: ReadWav)
+// RIFF/WAVE reader for the sample formats the reference CLI accepts, 16-bit PCM writer (the reference uses dr_wav.h for
+// I/O only).
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +34,66 @@ struct Wav {
     std::vector<int16_t> samples;
 };
 
+// Sample formats the reference CLI accepts through dr_wav's drwav_open_file_and_read_pcm_frames_s16 (main.cc:39-54;
+// dr_wav.h v0.12 is vendored in the reference for I/O only) and how each becomes int16 -- restated from its published
+// conversion rules, because a different rounding of a float or 24-bit input would be a different input to the canceller:
+//   PCM  8 bit  unsigned: (x << 8) - 32768                         (dr_wav.h: drwav_u8_to_s16)
+//   PCM 16 bit            as it is
+//   PCM 24 / 32 bit       the upper 16 bits (arithmetic shift)      (drwav_s24_to_s16, drwav_s32_to_s16)
+//   PCM 40..64 bit        the upper 16 bits                         (drwav__pcm_to_s16, generic path)
+//   IEEE float 32 / 64    c = clamp(x, -1, 1) + 1;  (int)(c * 32767.5) - 32768, evaluated in the sample's own precision
+//   A-law, mu-law         ITU-T G.711 expansion (the tables of dr_wav.h are that expansion; generated here)
+// RIFF containers, plain and WAVE_FORMAT_EXTENSIBLE headers.  Not read: ADPCM variants, Sony Wave64, RF64.
+enum : uint16_t { kFmtPcm = 1, kFmtAdpcm = 2, kFmtFloat = 3, kFmtAlaw = 6, kFmtMulaw = 7, kFmtExtensible = 0xFFFE };
+
+int16_t AlawToS16(uint8_t byte) {
+    const unsigned a = byte ^ 0x55u, exponent = (a >> 4) & 7u, mantissa = a & 15u;
+    const int magnitude = exponent == 0 ? (int)(mantissa << 4) + 8 : (int)(((mantissa << 4) + 0x108u) << (exponent - 1));
+    return (int16_t)((a & 0x80u) ? magnitude : -magnitude);
+}
+
+int16_t MulawToS16(uint8_t byte) {
+    const unsigned u = (uint8_t)~byte, exponent = (u >> 4) & 7u, mantissa = u & 15u;
+    const int magnitude = (int)((((mantissa << 3) + 0x84u) << exponent) - 0x84u);
+    return (int16_t)((u & 0x80u) ? -magnitude : magnitude);
+}
+
+// One sample of `bytes` bytes (little endian) of format `format` -> int16.  False: a format / width dr_wav does not convert.
+bool DecodeSample(uint16_t format, unsigned bytes, const uint8_t *p, int16_t *out) {
+    switch (format) {
+        case kFmtPcm: {
+            if (bytes == 1) { *out = (int16_t)(((int)p[0] << 8) - 32768); return true; }
+            if (bytes < 2 || bytes > 8) return false;
+            *out = (int16_t)(uint16_t)(p[bytes - 2] | (unsigned)p[bytes - 1] << 8);       // the upper 16 bits of the sample
+            return true;
+        }
+        case kFmtFloat: {
+            if (bytes == 4) {
+                float x;
+                memcpy(&x, p, 4);
+                volatile float c = (x < -1.0f) ? -1.0f : ((x > 1.0f) ? 1.0f : x);   // volatile: every step rounded to float, no fusing
+                c = c + 1.0f;
+                c = c * 32767.5f;
+                *out = (int16_t)((int)c - 32768);
+                return true;
+            }
+            if (bytes == 8) {
+                double x;
+                memcpy(&x, p, 8);
+                volatile double c = (x < -1.0) ? -1.0 : ((x > 1.0) ? 1.0 : x);
+                c = c + 1.0;
+                c = c * 32767.5;
+                *out = (int16_t)((int)c - 32768);
+                return true;
+            }
+            return false;
+        }
+        case kFmtAlaw: if (bytes != 1) return false; *out = AlawToS16(p[0]); return true;
+        case kFmtMulaw: if (bytes != 1) return false; *out = MulawToS16(p[0]); return true;
+        default: return false;
+    }
+}
+
 bool ReadWav(const std::string &path, Wav *w) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -40,7 +103,7 @@ bool ReadWav(const std::string &path, Wav *w) {
     bool ok = fread(tag, 1, 4, f) == 4 && memcmp(tag, "RIFF", 4) == 0 && rd32(&riff_size) && fread(tag, 1, 4, f) == 4 &&
               memcmp(tag, "WAVE", 4) == 0;
     bool have_fmt = false, have_data = false;
-    uint16_t format = 0, bits = 0;
+    uint16_t format = 0, bits = 0, block_align = 0;
     while (ok && !have_data) {
         uint32_t size = 0;
         if (fread(tag, 1, 4, f) != 4 || !rd32(&size)) break;
@@ -50,8 +113,9 @@ bool ReadWav(const std::string &path, Wav *w) {
             format = (uint16_t)(b[0] | b[1] << 8);
             w->channels = (uint16_t)(b[2] | b[3] << 8);
             w->rate = (uint32_t)b[4] | (uint32_t)b[5] << 8 | (uint32_t)b[6] << 16 | (uint32_t)b[7] << 24;
+            block_align = (uint16_t)(b[12] | b[13] << 8);
             bits = (uint16_t)(b[14] | b[15] << 8);
-            if (format == 0xFFFE && size >= 26) {              // WAVE_FORMAT_EXTENSIBLE: sub-format GUID starts with the tag
+            if (format == kFmtExtensible && size >= 26) {      // WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the tag
                 uint8_t ext[10];
                 ok = ok && fread(ext, 1, 10, f) == 10;
                 format = (uint16_t)(ext[8] | ext[9] << 8);
@@ -61,10 +125,22 @@ bool ReadWav(const std::string &path, Wav *w) {
             }
             have_fmt = true;
         } else if (memcmp(tag, "data", 4) == 0) {
-            if (!have_fmt || format != 1 || bits != 16) { ok = false; break; }
-            w->samples.resize(size / 2);
-            const size_t got = fread(w->samples.data(), 2, w->samples.size(), f);
-            w->samples.resize(got);
+            // bytes per sample from the block alignment (as dr_wav does: drwav_get_bytes_per_pcm_frame), else from the bit depth
+            if (!have_fmt || w->channels == 0) { ok = false; break; }
+            unsigned bytes = (block_align && block_align % w->channels == 0) ? block_align / w->channels : 0;
+            if (bytes == 0 && bits % 8 == 0) bytes = bits / 8;
+            int16_t probe;
+            const uint8_t zero[8] = {0};
+            if (bytes == 0 || bytes > 8 || !DecodeSample(format, bytes, zero, &probe)) { ok = false; break; }
+            if (format == kFmtPcm && bytes == 2) {              // the usual case: straight into place
+                w->samples.resize(size / 2);
+                w->samples.resize(fread(w->samples.data(), 2, w->samples.size(), f));
+            } else {
+                std::vector<uint8_t> raw(size);
+                raw.resize(fread(raw.data(), 1, raw.size(), f));
+                w->samples.resize(raw.size() / bytes);
+                for (size_t i = 0; i < w->samples.size(); ++i) DecodeSample(format, bytes, raw.data() + i * bytes, &w->samples[i]);
+            }
             have_data = true;
         } else {
             fseek(f, (long)(size + (size & 1)), SEEK_CUR);
@@ -213,8 +289,14 @@ int RunBatch(const char *list_path, const std::vector<int> &devices) {
 
 int main(int argc, char **argv) {
     printf("WebRTC Acoustic Echo Canceller for Mobile -- MI355X engine\n");
-    printf("usage : aecm_run far_file.wav near_file.wav | aecm_run --batch pairs.txt [--devices 0,1,...]\n");
+    printf("usage : aecm_run far_file.wav near_file.wav | aecm_run --batch pairs.txt [--devices 0,1,...] | aecm_run --decode in.wav out.wav\n");
     if (argc < 3) return -1;
+    if (strcmp(argv[1], "--decode") == 0) {                  // the reader on its own (no engine, no GPU)
+        Wav w;
+        if (argc < 4 || !ReadWav(argv[2], &w)) { printf("failed to read wav files.\n"); return 1; }
+        if (w.channels != 1) { printf("mono files only.\n"); return 1; }
+        return WriteWav(argv[3], w.rate, w.samples) ? 0 : 1;
+    }
     if (strcmp(argv[1], "--batch") == 0) {
         // --devices: HIP device ids to shard the recordings over (one host thread + one batch each); default $AECM_DEVICE or 0
         std::vector<int> devices;
