@@ -90,7 +90,7 @@ bool BatchEngine::Init(int fs) {
                                     hipMemcpyHostToDevice, stream_)))
         return false;
     if (!AECM_HIP_OK(LaunchBroadcastImage(st_, image_vec_dev_, image_scal_dev_, 0, num_streams_, stream_))) return false;
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;   // img goes out of scope
+    if (!Drain()) return false;   // img goes out of scope
     initialized_ = true;
     fs_ = fs;
     mixed_rates_ = false;
@@ -208,6 +208,9 @@ int BatchEngine::DescribeLaunch(int num_blocks, int *chunk_blocks) const {
     return variant_ == kVariantFast && num_streams_ > rotation_limit_ ? 1 : 0;
 }
 
+// Wait for everything enqueued on stream_; false if a HIP call failed or a wave of a chunk-queue launch gave up waiting.
+bool BatchEngine::Drain() { return AECM_HIP_OK(hipStreamSynchronize(stream_)) && CheckQueueError(); }
+
 // After a synchronisation of stream_: did a wave of a chunk-queue launch give up waiting (it never should)?
 bool BatchEngine::CheckQueueError() {
     if (!queue_unchecked_) return true;
@@ -283,11 +286,11 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
     if (!ProcessBlocks(dev, num_blocks)) return false;
     if (dense) {
         if (!AECM_HIP_OK(hipMemcpyAsync(io.out, dev.out, per * sizeof(int16_t), hipMemcpyDeviceToHost, stream_))) return false;
-        return AECM_HIP_OK(hipStreamSynchronize(stream_));
+        return Drain();
     }
     tmp.resize(per);
     if (!AECM_HIP_OK(hipMemcpyAsync(tmp.data(), dev.out, per * sizeof(int16_t), hipMemcpyDeviceToHost, stream_))) return false;
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!Drain()) return false;
     for (int s = 0; s < num_streams_; ++s)
         for (int b = 0; b < num_blocks; ++b)
             memcpy(io.out + s * io.stream_stride + b * io.block_stride, &tmp[((size_t)s * num_blocks + b) * kBlock],
@@ -324,7 +327,7 @@ bool BatchEngine::ProcessBlocksHostMapped(const IoView &io, int num_blocks) {
     IoView dev{mapped_dev_, mapped_dev_ + per, io.near_clean ? mapped_dev_ + 2 * per : nullptr, mapped_dev_ + (size_t)n_in * per,
                (int64_t)row, kBlock};
     if (!LaunchBlocks(st_, dev, num_streams_, num_blocks, nullptr)) return false;
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_)) || !CheckQueueError()) return false;
+    if (!Drain()) return false;
     rows(io.out, mapped_host_ + (size_t)n_in * per, false);
     return true;
 }
@@ -382,7 +385,7 @@ bool BatchEngine::ProcessBlocksHostPipelined(const IoView &io, int num_blocks) {
     }
     if (failed.load()) launched.store(n_chunks, std::memory_order_release);      // let the helper fall out of its wait
     downloader.join();
-    ok = !failed.load() && AECM_HIP_OK(hipStreamSynchronize(stream_)) && CheckQueueError();
+    ok = !failed.load() && Drain();
     for (auto e : done)
         if (e) (void)hipEventDestroy(e);
     return ok;
@@ -471,13 +474,13 @@ bool BatchEngine::ProcessRecordings(const int16_t *far, const int16_t *near, con
             ok = AECM_HIP_OK(hipMemcpy2DAsync(out + s0 * stream_stride, stream_stride * 2, dout, n_in * 2, n_in * 2, C,
                                               hipMemcpyDeviceToHost, stream_));
     }
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) ok = false;      // sch (the maps' host copy) goes out of scope
+    if (!Drain()) ok = false;      // sch (the maps' host copy) goes out of scope
     return ok;
 }
 
 bool BatchEngine::Synchronize() {
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
-    return AECM_HIP_OK(hipStreamSynchronize(stream_)) && CheckQueueError();
+    return Drain();
 }
 
 bool BatchEngine::LastLaunchMs(float *ms) {
@@ -517,7 +520,7 @@ bool BatchEngine::SetEchoPath(int stream, const int16_t path[kBins]) {
         for (int i = 0; i < 7; ++i) values[i] = scal[fields[i]];
         ok = PatchScalars(fields, values, 7, stream, 1);
     }
-    const bool drained = AECM_HIP_OK(hipStreamSynchronize(stream_));
+    const bool drained = Drain();
     return ok && drained;
 }
 
@@ -526,7 +529,7 @@ bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
     if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
     std::vector<uint32_t> ch(kLanes);
     std::vector<int32_t> scal(kNumScal);
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!Drain()) return false;
     if (!AECM_HIP_OK(hipMemcpy(ch.data(), st_.vec + (size_t)stream * kVecWordsPerStream + V_CH16 * kLanes,
                                kLanes * sizeof(uint32_t), hipMemcpyDeviceToHost)))
         return false;
@@ -550,7 +553,7 @@ static_assert(sizeof(SnapshotHeader) == BatchEngine::kStateHeaderBytes, "snapsho
 
 bool BatchEngine::ExportState(int stream, void *buf) {
     if (stream < 0 || stream >= num_streams_) return false;
-    if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_)) || !Drain()) return false;
     uint8_t *p = static_cast<uint8_t *>(buf);
     uint8_t *body = p + kStateHeaderBytes;
     if (!(AECM_HIP_OK(hipMemcpy(body, st_.vec + (size_t)stream * kVecWordsPerStream, kVecWordsPerStream * 4, hipMemcpyDeviceToHost)) &&
@@ -584,7 +587,7 @@ int32_t BatchEngine::ImportState(int stream, const void *buf) {
     memcpy(vec.data(), body, kVecWordsPerStream * 4);
     const bool sane = ValidateStateImage(vec.data(), scal, (int)h.fs) == nullptr;
     if (!sane) return kErrBadParameter;
-    if (!AECM_HIP_OK(hipSetDevice(device_)) || !AECM_HIP_OK(hipStreamSynchronize(stream_))) return kErrUnspecified;
+    if (!AECM_HIP_OK(hipSetDevice(device_)) || !Drain()) return kErrUnspecified;
     if (!(AECM_HIP_OK(hipMemcpy(st_.vec + (size_t)stream * kVecWordsPerStream, body, kVecWordsPerStream * 4, hipMemcpyHostToDevice)) &&
           AECM_HIP_OK(hipMemcpy(st_.scal + (size_t)stream * kNumScal, body + kVecWordsPerStream * 4, kNumScal * 4, hipMemcpyHostToDevice)) &&
           AECM_HIP_OK(hipMemcpy(st_.hist + (size_t)stream * kHistWordsPerStream, body + kVecWordsPerStream * 4 + kNumScal * 4,
@@ -600,7 +603,7 @@ bool BatchEngine::Digest(int stream, uint32_t digest[kDigestWords]) {
     std::vector<uint32_t> vec(kVecWordsPerStream);
     std::vector<int32_t> scal(kNumScal);
     std::vector<uint16_t> hist(kHistWordsPerStream);
-    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+    if (!Drain()) return false;
     if (!AECM_HIP_OK(hipMemcpy(vec.data(), st_.vec + (size_t)stream * kVecWordsPerStream, vec.size() * sizeof(uint32_t),
                                hipMemcpyDeviceToHost)))
         return false;

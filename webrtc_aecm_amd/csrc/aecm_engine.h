@@ -83,6 +83,7 @@ private:
     bool PipelinedLaunchApplies(int count, bool clean, bool ragged) const;
     bool LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev);
     bool CheckQueueError();
+    bool Drain();
     bool EnsureLaunchErrorWord();
     int num_streams_ = 0;
     bool initialized_ = false;
