@@ -337,7 +337,7 @@ def main():
         achieved = algo_bytes * S * T / kern_avg_s / 1e9
         workload_key = f"S{S}_T{T}_fs{args.fs}" + ("_clean" if args.clean else "")
         from webrtc_aecm_amd import isa_census
-        form, chunk = batch.describe_launch(C)                 # which block kernel a launch of this shape takes
+        form, chunk = batch.describe_launch(C, bool(args.clean))              # which block kernel a launch of this shape takes
         if args.variant == "fast":
             kernel_substr, kernel_name = isa_census.BLOCK_KERNELS[(form, bool(args.clean))]
             traffic, issue = load_profile_record(aecm.library_path(), workload_key, kernel_substr)

@@ -221,7 +221,8 @@ int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, in
  * of a block in wavefronts of their own, one block ahead of the rest.  min_streams: the smallest batch that takes this
  * form (default 2; <= 0: never).  Results do not depend on it.  Environment: AECM_PIPELINED (0 = never, n = from n). */
 int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
-/* Which form a ProcessBlocks launch of num_blocks blocks over the whole batch takes (for measurement tools that must name
+/* Which form a ProcessBlocks launch of num_blocks blocks over the whole batch takes, with (has_clean_input != 0) or
+ * without a clean near-end input (for measurement tools that must name
  * the kernel they time): 0 = one wavefront per stream, kernel variants for launches the chip holds at once; 1 = one
  * wavefront per stream, issue priority by phase; 2 = the chunk queue (*chunk_blocks, if not NULL, receives the chunk);
  * 3 = pipelined (six wavefronts per four streams). */
@@ -229,7 +230,7 @@ int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
 #define AECM_LAUNCH_PER_STREAM 1
 #define AECM_LAUNCH_CHUNK_QUEUE 2
 #define AECM_LAUNCH_PIPELINED 3
-int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t *chunk_blocks);
+int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t has_clean_input, int32_t *chunk_blocks);
 
 /* Device self test of the wave primitives on device_id; failures[0..7] must all be 0 afterwards
  * (see webrtc_aecm_amd/csrc/aecm_kernels.h).  exhaustive != 0 checks floor-sqrt on all of [0, 2^31). */

@@ -85,7 +85,7 @@ def main():
             "frames_processed_per_side": S * T * a.passes, "samples_compared": S * T * 64, "digests_compared": S,
             "ok": not bad_streams, "mismatching_streams": bad_streams[:32], "mismatching_samples": bad_samples,
             "mismatching_digests": bad_digests, "cpu_cores": cores, "cpu_seconds_wall": round(time.perf_counter() - t0, 1),
-            "launch_form": dict(zip(("form", "chunk_blocks"), batch.describe_launch(T))),      # 2 = chunk queue (include/aecm_batch.h)
+            "launch_form": dict(zip(("form", "chunk_blocks"), batch.describe_launch(T, bool(a.clean)))),      # 2 = chunk queue (include/aecm_batch.h)
             "library": str(aecm.library_path()), "build": _build.build_info()}
     print(json.dumps(line))
     return 0 if not bad_streams else 1

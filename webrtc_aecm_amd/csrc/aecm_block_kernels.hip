@@ -1,4 +1,8 @@
-// The block kernels of the MI355X AECM engine: aecm_process_kernel, one wavefront per stream.
+// The block kernels of the MI355X AECM engine.  One block DSP (BlockEngine, aecm_wave.h) under three launch forms:
+//   aecm_process_kernel            one wavefront per stream for the whole launch (described next)
+//   aecm_process_queue_kernel      launches larger than the chip: (chunk, stream) items claimed in order by a resident grid
+//   aecm_process_pipelined_kernel  launches the chip holds at once: six waves per four streams, transforms one block ahead
+// (aecm_engine.cpp: LaunchBlocks picks by the size of the launch; the forms give identical results.)
 //
 // The whole persistent state of a stream (~40 lane vectors + ~50 scalars) is loaded into registers once, n_blocks blocks
 // are processed back to back (WebRtcAecm_ProcessBlock-equivalents, aecm_wave.h), and the state is written back once.  Per

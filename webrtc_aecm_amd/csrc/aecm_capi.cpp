@@ -266,9 +266,9 @@ int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams) {
     return 0;
 }
 
-int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t *chunk_blocks) {
+int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t has_clean_input, int32_t *chunk_blocks) {
     if (!b) return -1;
-    return b->engine->DescribeLaunch(num_blocks, chunk_blocks);
+    return b->engine->DescribeLaunch(num_blocks, has_clean_input != 0, chunk_blocks);
 }
 
 // ---- streaming batch of sessions ---------------------------------------------------------------------

@@ -198,13 +198,13 @@ bool BatchEngine::PipelinedLaunchApplies(int count, bool clean, bool ragged) con
     return variant_ == kVariantFast && !clean && !ragged && count >= pipe_min_streams_ && count <= pipe_max_streams_;
 }
 
-int BatchEngine::DescribeLaunch(int num_blocks, int *chunk_blocks) const {
+int BatchEngine::DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const {
     if (QueueLaunchApplies(num_streams_, num_blocks, variant_, queue_chunk_, queue_min_streams_ >= 0 ? queue_min_streams_ : resident_waves_, false)) {
         if (chunk_blocks) *chunk_blocks = queue_chunk_;
         return 2;
     }
     if (chunk_blocks) *chunk_blocks = 0;
-    if (PipelinedLaunchApplies(num_streams_, false, false)) return 3;
+    if (PipelinedLaunchApplies(num_streams_, has_clean, false)) return 3;
     return variant_ == kVariantFast && num_streams_ > rotation_limit_ ? 1 : 0;
 }
 

@@ -59,7 +59,7 @@ public:
     // blocks = 0: every launch in the one-stream-per-wave form.  min_streams < 0: launches of more streams than the chip
     // holds waves take the queue form (the default); otherwise launches of more than min_streams streams do (tests).
     void set_queue_chunk(int blocks, int min_streams) { queue_chunk_ = blocks < 0 ? 0 : blocks; queue_min_streams_ = min_streams; }
-    int DescribeLaunch(int num_blocks, int *chunk_blocks) const;
+    int DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const;
     void set_pipelined_min_streams(int n) { pipe_min_streams_ = n > 0 ? n : 0x7fffffff; }    // n <= 0: never
     int variant() const { return variant_; }
     const StatePtrs &state_ptrs() const { return st_; }      // for kernels launched by the session batch on stream()

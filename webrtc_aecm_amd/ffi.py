@@ -119,7 +119,7 @@ def load():
     lib.WebRtcAecmBatch_GetDigest.argtypes = [vp, C.c_int32, vp]
     lib.WebRtcAecmBatch_SetKernelVariant.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmBatch_SetLaunchChunking.argtypes = [vp, C.c_int32, C.c_int32]
-    lib.WebRtcAecmBatch_DescribeLaunch.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.WebRtcAecmBatch_DescribeLaunch.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.WebRtcAecmBatch_SetLaunchPipelining.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmSessions_Create.restype = vp
     lib.WebRtcAecmSessions_Create.argtypes = [C.c_int32, C.c_int32]
@@ -255,11 +255,11 @@ class AecmBatch:
         <= 0: never."""
         self._check(self.lib.WebRtcAecmBatch_SetLaunchPipelining(self.h, min_streams), "SetLaunchPipelining")
 
-    def describe_launch(self, num_blocks):
+    def describe_launch(self, num_blocks, clean=False):
         """(form, chunk_blocks) of a ProcessBlocks launch of num_blocks blocks: form 0 / 1 = one wavefront per stream
         (small-launch variants / issue priority by phase), 2 = chunk queue, 3 = pipelined (six wavefronts per four streams)."""
         chunk = C.c_int32(0)
-        form = self.lib.WebRtcAecmBatch_DescribeLaunch(self.h, num_blocks, C.byref(chunk))
+        form = self.lib.WebRtcAecmBatch_DescribeLaunch(self.h, num_blocks, 1 if clean else 0, C.byref(chunk))
         if form < 0:
             raise AecmError(form, "WebRtcAecmBatch_DescribeLaunch")
         return form, chunk.value
