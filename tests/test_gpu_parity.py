@@ -1347,7 +1347,8 @@ def test_c_abi_under_ubsan():
         pytest.skip(f"no sanitizer twin of the library: {e}")
     env = dict(os.environ, AECM_LIB_PATH=str(build.LIB_UBSAN), UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     sel = ("session_abi or snapshot or echo_path or control or tick_major or ragged or chunked or clean_input or recordings_equal or "
-           "streaming_session_batch or unaligned or per_session_sound or churn or mixed_call or tick_argument or in_place or cli_single")
+           "streaming_session_batch or unaligned or per_session_sound or churn or mixed_call or tick_argument or in_place or cli_single or "
+           "chunk_queue or pipelined_launch")
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-p", "no:cacheprovider", "-k", sel],
                        env=env, capture_output=True, text=True, timeout=1500)
     log = r.stdout + r.stderr
