@@ -717,6 +717,32 @@ def test_pipelined_launch_sizes_and_lengths(fs):
         b.close()
 
 
+def test_launch_form_by_size():
+    """Which kernel a launch takes (WebRtcAecmBatch_DescribeLaunch; INTEGRATION.md has the table): one stream -> one wavefront
+    per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant); up to the chip's resident
+    waves -> one wavefront per stream; above -> chunk queue, if the launch is at least two chunks long."""
+    cus = aecm.device_info(0)[1]
+    pipe_max, resident, rotation = cus * 16, cus * 28, cus * 24
+    for S, T, clean, want in ((1, 300, False, 0), (2, 300, False, 3), (pipe_max, 3, False, 3), (pipe_max, 300, True, 0),
+                              (pipe_max + 1, 300, False, 0), (rotation + 1, 300, False, 1), (resident, 300, False, 1),
+                              (resident + 1, 255, False, 1), (resident + 1, 256, False, 2), (resident + 1, 256, True, 2)):
+        b = aecm.AecmBatch(S, 16000)
+        form, chunk = b.describe_launch(T, clean)
+        assert form == want and chunk == (128 if want == 2 else 0), (S, T, clean, form, chunk)
+        if S == pipe_max:
+            b.set_variant(aecm.KERNEL_SAFE)
+            assert b.describe_launch(T, clean)[0] == 0
+            b.set_variant(aecm.KERNEL_FAST)
+            b.set_launch_pipelining(0)
+            assert b.describe_launch(T, clean)[0] == 0
+        if S == resident + 1 and T == 256:
+            b.set_launch_chunking(0)
+            assert b.describe_launch(T, clean) == (1, 0)
+            b.set_launch_chunking(64, 10)
+            assert b.describe_launch(T, clean) == (2, 64)
+        b.close()
+
+
 def test_chunk_queue_launch_larger_than_the_chip():
     """9 001 streams (more than the chip holds waves, not a multiple of a workgroup's four) x 300 blocks in chunks of 128,
     128 and 44: the launch takes the queue form by itself.  Every stream must equal the oracle's answer for the pair it
