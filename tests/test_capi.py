@@ -52,7 +52,7 @@ def test_no_cpu_fallback_without_gpu(gpu_available):
 def test_product_does_not_use_the_oracle():
     """The shipped path must never import, include, link or load anything under oracle/."""
     banned = ("aecm_oracle.h", "aecm_oracle_tables.h", "pyoracle", "libaecm_oracle", "libaecm_ref", "import oracle",
-              "from oracle", "ref_shim")
+              "from oracle", "ref_shim", "ref_wavdec")
     files = [p for p in (ROOT / "webrtc_aecm_amd").rglob("*") if p.is_file() and p.suffix in {".py", ".h", ".cpp", ".hip"}]
     files += list((ROOT / "include").glob("*.h"))
     assert files

@@ -90,7 +90,11 @@ bool BatchEngine::Init(int fs) {
                                     hipMemcpyHostToDevice, stream_)))
         return false;
     if (!AECM_HIP_OK(LaunchBroadcastImage(st_, image_vec_dev_, image_scal_dev_, 0, num_streams_, stream_))) return false;
-    if (!Drain()) return false;   // img goes out of scope
+    // a launch that failed (a wave of a chunk-queue launch gave up waiting: CheckQueueError) left the streams it had not
+    // finished in an unknown state; re-initialising all of them is what clears the record
+    if (queue_err_ && !AECM_HIP_OK(hipMemsetAsync(queue_err_, 0, sizeof(uint32_t), stream_))) return false;
+    queue_unchecked_ = false;
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;   // img goes out of scope
     initialized_ = true;
     fs_ = fs;
     mixed_rates_ = false;
