@@ -717,6 +717,36 @@ def test_pipelined_launch_sizes_and_lengths(fs):
         b.close()
 
 
+def test_chunk_queue_half_a_million_hand_overs():
+    """The state hand-over between waves (memory at agent scope, any CU of any XCD picks up a stream's next chunk) as often
+    as a test can afford: 8 200 streams x 512 blocks in chunks of 8 -- 64 hand-overs per stream, 525 000 in the launch, the
+    chip full throughout -- against the same batch run with one wavefront per stream (itself pinned to the oracle and the
+    reference elsewhere): every output sample and every stream's complete state digest."""
+    import torch
+    S, T, fs, U = 8200, 512, 16000, 40
+    seeds = list(range(7700, 7700 + U))
+    far, near = synth_streams(seeds, T, fs)
+    idx = torch.arange(S) % U
+    dfar = torch.from_numpy(far).cuda()[idx].contiguous()
+    dnear = torch.from_numpy(near).cuda()[idx].contiguous()
+    outs, digs = [], []
+    for chunking in ((8, -1), (0, -1)):
+        b = aecm.AecmBatch(S, fs, echo_mode=2)
+        b.set_launch_chunking(*chunking)
+        assert b.describe_launch(T)[0] == (2 if chunking[0] else 1)
+        dout = torch.empty_like(dnear)
+        b.process_device(dfar.data_ptr(), dnear.data_ptr(), dout.data_ptr(), T * 64, 64, T)
+        b.synchronize()
+        outs.append(dout)
+        digs.append(np.stack([b.digest(s) for s in range(0, S, 7)]))
+        b.close()
+    assert int((outs[0] != outs[1]).sum().item()) == 0
+    assert np.array_equal(digs[0], digs[1])
+    # and the one-wave run is the oracle's
+    o = pyoracle.OracleStream(fs, 1, 2)
+    assert np.array_equal(outs[1][5].cpu().numpy(), o.process(far[5], near[5]))
+
+
 def test_launch_form_by_size():
     """Which kernel a launch takes (WebRtcAecmBatch_DescribeLaunch; INTEGRATION.md has the table): one stream -> one wavefront
     per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant); up to the chip's resident
