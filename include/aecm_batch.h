@@ -210,11 +210,11 @@ int32_t WebRtcAecmSessions_GetEchoPath(AecmSessions *s, int32_t session, void *e
 int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
 
 /* How a ProcessBlocks launch is scheduled on the device; results do not depend on it.  A launch of more streams than
- * the chip holds wavefronts is cut into chunks of chunk_blocks blocks that resident wavefronts claim in order from a
- * queue, so that all streams advance together and the launch does not end in a long drain at low occupancy (default:
- * 128 blocks, environment AECM_QUEUE_CHUNK).  chunk_blocks = 0: one wavefront keeps one stream for the whole launch,
- * always.  min_streams < 0 (default): the queue form is used above the chip's resident wavefront count; >= 0: above
- * that many streams (diagnostics / tests). */
+ * the pipelined form takes (4 096 on an MI355X) is cut into chunks of chunk_blocks blocks that resident wavefronts
+ * claim in order from a queue, so that all streams advance together and the launch does not end at low occupancy
+ * (default: 128 blocks, environment AECM_QUEUE_CHUNK; a quarter of it, at least 8, while every stream's wavefront is
+ * resident at once).  chunk_blocks = 0: one wavefront keeps one stream for the whole launch, always.  min_streams < 0
+ * (default): the threshold above; >= 0: the queue form above that many streams (diagnostics / tests). */
 int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, int32_t min_streams);
 /* Launches the chip holds at once (<= 4 streams x 4 workgroups per compute unit = 4 096 streams on an MI355X; fast
  * variant, no clean near-end input) run pipelined: six wavefronts serve four streams, the state-independent transforms

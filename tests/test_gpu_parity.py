@@ -717,6 +717,34 @@ def test_pipelined_launch_sizes_and_lengths(fs):
         b.close()
 
 
+def test_chunk_queue_launch_the_chip_holds_at_once():
+    """5 003 streams (between the pipelined form's 4 096 and the chip's 7 168 resident waves): every wave is resident from the
+    start and the launch still takes the chunk queue (items of 32 blocks), because the waves dispatched first pull ahead and
+    then take more of the work.  Every stream against the oracle's answer for the pair it replicates, with a clean input too."""
+    import torch
+    S, T, fs, U = 5003, 200, 16000, 16
+    seeds = list(range(7900, 7900 + U))
+    far, near = synth_streams(seeds, T, fs)
+    idx = torch.arange(S) % U
+    for clean in (False, True):
+        cln = synth_clean(near) if clean else None
+        exp = []
+        for k in range(U):
+            o = pyoracle.OracleStream(fs, 1, 3)
+            exp.append(np.concatenate([o.process_block_clean(far[k, j * 64:(j + 1) * 64], near[k, j * 64:(j + 1) * 64], cln[k, j * 64:(j + 1) * 64])
+                                       for j in range(T)]) if clean else o.process(far[k], near[k]))
+        dfar = torch.from_numpy(far).cuda()[idx].contiguous()
+        dnear = torch.from_numpy(near).cuda()[idx].contiguous()
+        dclean = torch.from_numpy(cln).cuda()[idx].contiguous() if clean else None
+        dout = torch.empty_like(dnear)
+        b = aecm.AecmBatch(S, fs)
+        assert b.describe_launch(T, clean) == (2, 32)
+        b.process_device(dfar.data_ptr(), dnear.data_ptr(), dout.data_ptr(), T * 64, 64, T, dclean.data_ptr() if clean else None)
+        b.synchronize()
+        assert int((dout != torch.from_numpy(np.stack(exp)).cuda()[idx]).sum().item()) == 0, clean
+        b.close()
+
+
 def test_chunk_queue_half_a_million_hand_overs():
     """The state hand-over between waves (memory at agent scope, any CU of any XCD picks up a stream's next chunk) as often
     as a test can afford: 8 200 streams x 512 blocks in chunks of 8 -- 64 hand-overs per stream, 525 000 in the launch, the
@@ -749,16 +777,18 @@ def test_chunk_queue_half_a_million_hand_overs():
 
 def test_launch_form_by_size():
     """Which kernel a launch takes (WebRtcAecmBatch_DescribeLaunch; INTEGRATION.md has the table): one stream -> one wavefront
-    per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant); up to the chip's resident
-    waves -> one wavefront per stream; above -> chunk queue, if the launch is at least two chunks long."""
+    per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant); more -> chunk queue if
+    the launch is at least two chunks long (chunks of 32 blocks up to the chip's resident waves, of 128 above), else one
+    wavefront per stream."""
     cus = aecm.device_info(0)[1]
     pipe_max, resident, rotation = cus * 16, cus * 28, cus * 24
-    for S, T, clean, want in ((1, 300, False, 0), (2, 300, False, 3), (pipe_max, 3, False, 3), (pipe_max, 300, True, 0),
-                              (pipe_max + 1, 300, False, 0), (rotation + 1, 300, False, 1), (resident, 300, False, 1),
-                              (resident + 1, 255, False, 1), (resident + 1, 256, False, 2), (resident + 1, 256, True, 2)):
+    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 0), (pipe_max, 3, False, 3, 0), (pipe_max, 300, True, 0, 0),
+                                          (pipe_max + 1, 300, False, 2, 32), (pipe_max + 1, 63, False, 0, 0), (rotation + 1, 63, False, 1, 0),
+                                          (resident, 64, True, 2, 32), (resident + 1, 255, False, 1, 0), (resident + 1, 256, False, 2, 128),
+                                          (resident + 1, 256, True, 2, 128)):
         b = aecm.AecmBatch(S, 16000)
         form, chunk = b.describe_launch(T, clean)
-        assert form == want and chunk == (128 if want == 2 else 0), (S, T, clean, form, chunk)
+        assert (form, chunk) == (want, want_chunk), (S, T, clean, form, chunk)
         if S == pipe_max:
             b.set_variant(aecm.KERNEL_SAFE)
             assert b.describe_launch(T, clean)[0] == 0

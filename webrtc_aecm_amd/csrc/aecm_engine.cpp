@@ -32,6 +32,7 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     e->resident_waves_ = ResidentWaves(cus);
     e->queue_chunk_ = kDefaultQueueChunk;
     if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::max(0, atoi(env));
+    if (const char *env = getenv("AECM_QUEUE_MIN_STREAMS")) e->queue_min_streams_ = atoi(env);      // experiments: the queue form above this many streams
     e->pipe_max_streams_ = PipelinedStreamLimit(cus);
     if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
     const size_t S = (size_t)num_streams;
@@ -176,8 +177,8 @@ bool BatchEngine::EnsureLaunchErrorWord() {
 // One launch of the block kernels over `count` streams (st, io already offset to the first of them), in the chunk-queue form
 // when the launch is larger than the chip (see QueueLaunchApplies).
 bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev) {
-    if (QueueLaunchApplies(count, num_blocks, variant_, queue_chunk_, queue_min_streams_ >= 0 ? queue_min_streams_ : resident_waves_,
-                           blocks_per_stream_dev != nullptr)) {
+    const int chunk = QueueChunkFor(count);
+    if (QueueLaunchApplies(count, num_blocks, variant_, chunk, QueueMinStreams(), blocks_per_stream_dev != nullptr)) {
         const size_t need = QueueControlBytes(count);
         if (need > queue_ctl_bytes_) {                       // grown on first use; stream-ordered work may still read the old one
             if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
@@ -189,7 +190,7 @@ bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count,
         }
         if (!EnsureLaunchErrorWord()) return false;
         queue_unchecked_ = true;
-        return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, queue_chunk_, resident_waves_, queue_ctl_, queue_err_, stream_));
+        return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, chunk, resident_waves_, queue_ctl_, queue_err_, stream_));
     }
     if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
         return AECM_HIP_OK(LaunchProcessBlocksPipelined(st, io, count, num_blocks, stream_));
@@ -202,9 +203,20 @@ bool BatchEngine::PipelinedLaunchApplies(int count, bool clean, bool ragged) con
     return variant_ == kVariantFast && !clean && !ragged && count >= pipe_min_streams_ && count <= pipe_max_streams_;
 }
 
+// The chunk queue takes every launch of more streams than the pipelined form does (or than min_streams, when set): above the
+// chip's resident waves because the launch would otherwise end in a long drain, and between 4 096 streams and that too --
+// every wave is resident there, but the SIMD's arbiter favours its oldest wave, the waves dispatched first pull ahead, and
+// with items claimed in order those waves simply take more of the work (4 608 streams 728 -> 830 M frames/s, 6 144
+// 844 -> 930 M, 7 168 917 -> 961 M; profiles/r04_experiments.md section 4).  Shorter chunks there: 32 instead of 128 blocks.
+int BatchEngine::QueueMinStreams() const { return queue_min_streams_ >= 0 ? queue_min_streams_ : pipe_max_streams_; }
+int BatchEngine::QueueChunkFor(int count) const {
+    if (queue_chunk_ <= 0 || count > resident_waves_) return queue_chunk_;
+    return std::max(8, queue_chunk_ / 4);
+}
+
 int BatchEngine::DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const {
-    if (QueueLaunchApplies(num_streams_, num_blocks, variant_, queue_chunk_, queue_min_streams_ >= 0 ? queue_min_streams_ : resident_waves_, false)) {
-        if (chunk_blocks) *chunk_blocks = queue_chunk_;
+    if (QueueLaunchApplies(num_streams_, num_blocks, variant_, QueueChunkFor(num_streams_), QueueMinStreams(), false)) {
+        if (chunk_blocks) *chunk_blocks = QueueChunkFor(num_streams_);
         return 2;
     }
     if (chunk_blocks) *chunk_blocks = 0;

@@ -82,6 +82,8 @@ private:
     int pipe_min_streams_ = kDefaultPipelinedMinStreams, pipe_max_streams_ = 0;
     bool PipelinedLaunchApplies(int count, bool clean, bool ragged) const;
     bool LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev);
+    int QueueMinStreams() const;
+    int QueueChunkFor(int count) const;
     bool CheckQueueError();
     bool Drain();
     bool EnsureLaunchErrorWord();
