@@ -37,30 +37,41 @@ HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH
 PROFILE_SUMMARY = ROOT / "profiles" / "r04_rocprof_summary.json"
 
 
-def synth_on_device(torch, S, L, seed, device, chunk=8192):
+PROFILES = {
+    # name: (far-end envelope levels, near-end talk levels, what it is)
+    "recipe": ([15., 60., 500., 3000., 9000., 20000.], [0., 0., 0., 2000., 8000.],
+               "the default: far end with pauses (0.4 s segments from 15 to 20 000), echo + near-end talk bursts 2 segments in 5"),
+    "always_active": ([500., 3000., 9000., 20000.], [2000., 8000.],
+                      "far end never below 500 and near-end talk in every segment: double talk in every block, the VAD never drops"),
+    "full_scale": ([60000.], [60000.], "far end and near-end talk clipped to +-32767 nearly everywhere: every inverse-transform stage rescales"),
+    "silent": ([0.], [0.], "digital silence on both ends"),
+}
+
+
+def synth_on_device(torch, S, L, seed, device, chunk=8192, profile="recipe"):
     """Synthetic far/near int16 [S, L] in HBM: white noise x piecewise-constant envelope (0.4 s
-    segments from {15..20000}), near = sparse 4-tap echo of far + near-end talk bursts (the recipe
+    segments from the profile's levels), near = sparse 4-tap echo of far + near-end talk bursts (the recipe
     of webrtc_aecm_amd/synth.py, float math on the GPU; bench data need not be reproducible bit
-    for bit across machines, parity is checked elsewhere)."""
+    for bit across machines, parity is checked elsewhere).  profile: PROFILES (the content sweep)."""
     far = torch.empty((S, L), dtype=torch.int16, device=device)
     near = torch.empty((S, L), dtype=torch.int16, device=device)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    levels = torch.tensor([15., 60., 500., 3000., 9000., 20000.], device=device)
-    talk_levels = torch.tensor([0., 0., 0., 2000., 8000.], device=device)
+    levels = torch.tensor(PROFILES[profile][0], device=device)
+    talk_levels = torch.tensor(PROFILES[profile][1], device=device)
     seg = 6400
     nseg = L // seg + 2
     taps = ((100, 0.5), (180, -0.3), (333, 0.2), (600, 0.1))
     for s0 in range(0, S, chunk):
         n = min(chunk, S - s0)
-        env = levels[torch.randint(0, 6, (n, nseg), generator=g, device=device)].repeat_interleave(seg, dim=1)[:, :L]
+        env = levels[torch.randint(0, len(levels), (n, nseg), generator=g, device=device)].repeat_interleave(seg, dim=1)[:, :L]
         x = torch.randn((n, L), generator=g, device=device) * env * 0.58
         x[:, 1:-1] = (x[:, :-2] + 2 * x[:, 1:-1] + x[:, 2:]) * 0.25
         x = x.clamp_(-32768, 32767).round_()
         echo = torch.zeros_like(x)
         for d, gain in taps:
             echo[:, d:] += gain * x[:, :-d]
-        tenv = talk_levels[torch.randint(0, 5, (n, nseg), generator=g, device=device)].repeat_interleave(seg, dim=1)[:, :L]
+        tenv = talk_levels[torch.randint(0, len(talk_levels), (n, nseg), generator=g, device=device)].repeat_interleave(seg, dim=1)[:, :L]
         y = echo + torch.randn((n, L), generator=g, device=device) * tenv * 0.3
         far[s0:s0 + n] = x.to(torch.int16)
         near[s0:s0 + n] = y.clamp_(-32768, 32767).round_().to(torch.int16)
@@ -130,7 +141,7 @@ def cpu_baseline(fs, pairs, budget_s=12.0):
     }
 
 
-def verify_timed_workload(batch, far, near, clean, out, S, T, passes, fs, fixed_delay):
+def verify_timed_workload(batch, far, near, clean, out, S, T, passes, fs, fixed_delay, timed_passes=0, world=1):
     """Parity of the timed workload itself (outside the timed region): streams 0..15, S/2 and S-1 of this rank's own
     batch are pushed through the CPU checker -- the unmodified reference (oracle/_ref, WebRtcAecm_ProcessBlock,
     aecm_core_c.cc:368-711) when its prebuilt library travelled with the tree, our restatement otherwise -- for every
@@ -146,24 +157,45 @@ def verify_timed_workload(batch, far, near, clean, out, S, T, passes, fs, fixed_
     def one(k):
         f, d, c, got = host[k]
         chk = pyoracle.RefCoreStream(fs, 1, 1) if use_ref else pyoracle.OracleStream(fs, 1, 1)
+        # which paths the blocks of the TIMED passes took: counted by the restatement (oracle/aecm_oracle.h: ORC_STAT_*), which runs
+        # next to the reference when that is the checker (the reference has no such counters and is not modified)
+        cnt = chk if not use_ref else (pyoracle.OracleStream(fs, 1, 1) if c is None else None)
         if fixed_delay >= 0:
             chk.control(fixed_delay, 1)
+            if cnt is not None and cnt is not chk:
+                cnt.control(fixed_delay, 1)
         exp = None
-        for _ in range(passes):
+        before = None
+        for p in range(passes):
+            if p == passes - timed_passes and cnt is not None:
+                before = cnt.stats()
             if c is None:
                 exp = chk.process(f, d)
+                if cnt is not None and cnt is not chk:
+                    cnt.process(f, d)
             else:
                 exp = np.concatenate([chk.process_block_clean(f[b * 64:(b + 1) * 64], d[b * 64:(b + 1) * 64], c[b * 64:(b + 1) * 64])
                                       for b in range(T)])
         bad_out = int(np.count_nonzero(exp != got))
         dig_ok = bool(np.array_equal(chk.digest(), gpu_digest[k]))
-        return bad_out, dig_ok
+        stats = None
+        if cnt is not None and before is not None:
+            after = cnt.stats()
+            stats = {n: after[n] - before[n] for n in after}
+        return bad_out, dig_ok, stats
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=max(1, min(len(picks), usable_cores()))) as ex:
+    # every rank checks its own shard at the same time: a rank takes its share of the host's cores, not all of them
+    workers = max(1, min(len(picks), usable_cores() // max(1, world)))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
         res = list(ex.map(one, range(len(picks))))
-    bad = [picks[k] for k, (b, dg) in enumerate(res) if b or not dg]
-    return {"streams": picks, "blocks": passes * T, "blocks_compared_sample_by_sample": T,
-            "checker": "reference" if use_ref else "port", "ok": not bad, "mismatching_streams": bad,
+    bad = [picks[k] for k, (b, dg, _) in enumerate(res) if b or not dg]
+    tot = {}
+    for _, _, st in res:
+        for n, v in (st or {}).items():
+            tot[n] = tot.get(n, 0) + v
+    shares = {n + "_share": round(v / tot["blocks"], 4) for n, v in tot.items() if n != "blocks"} if tot.get("blocks") else None
+    return {"streams": picks, "blocks": passes * T, "blocks_compared_sample_by_sample": T, "content_shares": shares,
+            "checker": "reference" if use_ref else "port", "checker_threads": workers, "ok": not bad, "mismatching_streams": bad,
             "state_digest_compared": True, "seconds": time.perf_counter() - t0,
             "what": f"{len(picks)} streams of the timed batch x all {passes} passes ({passes * T} blocks each) re-run on the CPU "
                     f"checker; last pass's output rows and the final state digest compared bit for bit"}
@@ -183,7 +215,7 @@ def workload_name(S, T, fs, world, clean):
         tag = "BASELINE.json configs[3] (8 kHz mode, 32768 streams)"
     else:
         tag = "custom size"
-    return f"{tag}: {S} streams/GPU x {T} blocks/step, {fs} Hz, cng on, echoMode 1, inputs resident in HBM"
+    return f"{tag}: {S} streams/GPU x {T} blocks/step, {fs} Hz, cng on, echoMode 1, inputs resident in HBM"   # (+ the content profile, main())
 
 
 def load_profile_record(lib_path, workload_key, kernel_substr):
@@ -245,6 +277,9 @@ def main():
     ap.add_argument("--launch-blocks", type=int, default=0,
                     help="experiment: split every step into launches of this many blocks over the same input (0 = one launch per "
                          "step, the measured configuration); separates launch-length effects from the data's")
+    ap.add_argument("--profile", choices=sorted(PROFILES), default="recipe",
+                    help="content of the synthetic signals (the frame rate depends on which data-dependent paths the blocks take): "
+                         + "; ".join(f"{k} = {v[2]}" for k, v in PROFILES.items()))
     ap.add_argument("--fixed-delay", type=int, default=-1,
                     help="WebRtcAecm_Control fixed delay (>= 0 disables the estimator's choice; 0 = no far-history reads; "
                          "used to calibrate the FETCH_SIZE counter on a known byte count)")
@@ -285,7 +320,7 @@ def main():
     S, T, K, W = args.streams, args.blocks, args.steps, args.warmup
     if args.total_streams:
         _, S = adist.shard_range(args.total_streams, rank, world)
-    far, near = synth_on_device(torch, S, T * 64, 1234 + rank, device)
+    far, near = synth_on_device(torch, S, T * 64, 1234 + rank, device, profile=args.profile)
     clean = (near.to(torch.int32) * 3 // 4).to(torch.int16) if args.clean else None
     batch = aecm.AecmBatch(S, args.fs, cng_mode=1, echo_mode=1, device=local_rank,
                            variant=aecm.KERNEL_FAST if args.variant == "fast" else aecm.KERNEL_SAFE)
@@ -328,7 +363,7 @@ def main():
     c = adist.gather_counters(S * T * K, wall, kernel_ms_total, cdev, dev_name)
     parity = None
     if not args.no_parity:                  # every rank checks streams of its own shard; rank 0 reports, all must agree
-        parity = verify_timed_workload(batch, far, near, clean, out, S, T, W + K, args.fs, args.fixed_delay)
+        parity = verify_timed_workload(batch, far, near, clean, out, S, T, W + K, args.fs, args.fixed_delay, timed_passes=K, world=world)
         parity["ranks_ok"] = adist.all_ok(parity["ok"], cdev)
     if rank == 0:
         value = c["frames"] / c["seconds"]
@@ -353,7 +388,8 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": c["seconds"] / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (Q-format fixed point)", "data": "synthetic",
-            "config": {"workload": workload_name(S, T, args.fs, world, args.clean),
+            "config": {"workload": workload_name(S, T, args.fs, world, args.clean) + ("" if args.profile == "recipe" else f", content profile {args.profile}"),
+                       "content_profile": args.profile,
                        "streams_per_gpu": S, "blocks_per_step": T, "launches_per_step": len(chunks), "launch_form": form,
                        "launch_chunk_blocks": chunk, "fs": args.fs, "kernel_variant": args.variant,
                        "sharding": f"static, {world} x {S} independent streams, no data-path collective",
@@ -376,6 +412,14 @@ def main():
                                  "see issue_bound for the binding resource",
                          "issue_bound": issue},
         }
+        shares = parity.pop("content_shares", None) if parity is not None else None
+        # what the frame rate was measured ON: the signal profile and, from the checker's streams over the timed passes, how many
+        # blocks took the data-dependent paths that cost or save work (profiles/r05_content_sweep.txt has all profiles side by side)
+        res["content"] = {"profile": args.profile, "what": PROFILES[args.profile][2],
+                          "nlms_share": shares and shares.get("nlms_share"), "passthrough_share": shares and shares.get("gain_zero_share"),
+                          "q_steady_share": shares and shares.get("q_steady_share"), "ifft_unscaled_share": shares and shares.get("ifft_unscaled_share"),
+                          "delayed_share": shares and shares.get("delayed_share"),
+                          "measured_on": None if shares is None else f"{len(parity['streams'])} streams of the timed batch x the {K} timed passes"}
         if parity is not None:
             res["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:

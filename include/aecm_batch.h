@@ -108,6 +108,18 @@ size_t WebRtcAecmBatch_state_size_bytes(void);
 int32_t WebRtcAecmBatch_ExportState(AecmBatch *b, int32_t stream, void *state, size_t size_bytes);
 int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *state, size_t size_bytes);
 
+/* The same for streams [first, first + count) at once: `states` = count snapshots of WebRtcAecmBatch_state_size_bytes()
+ * each, back to back (size_bytes = count x that).  One gather (scatter) launch on the device and one copy per 8 192 streams
+ * instead of three blocking copies per stream.  The *Device forms take anything the device can address: device memory
+ * (e.g. the staging buffer of a peer-to-peer migration), or the alias of a caller-owned host buffer registered with
+ * WebRtcAecmBatch_RegisterHostBuffer -- the kernels then write (read) the snapshots in place over the link.
+ * ImportStates is all or nothing: every snapshot is validated exactly like ImportState validates one (on the device for
+ * the *Device form) before any stream is touched; AECM_BAD_PARAMETER_ERROR if one of them may not be run on. */
+int32_t WebRtcAecmBatch_ExportStates(AecmBatch *b, int32_t first, int32_t count, void *states_host, size_t size_bytes);
+int32_t WebRtcAecmBatch_ImportStates(AecmBatch *b, int32_t first, int32_t count, const void *states_host, size_t size_bytes);
+int32_t WebRtcAecmBatch_ExportStatesDevice(AecmBatch *b, int32_t first, int32_t count, void *states_dev, size_t size_bytes);
+int32_t WebRtcAecmBatch_ImportStatesDevice(AecmBatch *b, int32_t first, int32_t count, const void *states_dev, size_t size_bytes);
+
 /* 24-word digest of one stream's complete state (canonical order: oracle/aecm_oracle.c). */
 int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]);
 
@@ -206,15 +218,28 @@ int32_t WebRtcAecmSessions_set_config_session(AecmSessions *s, int32_t session, 
 int32_t WebRtcAecmSessions_InitEchoPath(AecmSessions *s, int32_t session, const void *echo_path, size_t size_bytes);
 int32_t WebRtcAecmSessions_GetEchoPath(AecmSessions *s, int32_t session, void *echo_path, size_t size_bytes);
 
+/* Snapshot of ONE live session (checkpoint; migration of a call into another AecmSessions object, on another GPU):
+ * everything the reference keeps per instance -- AecMobile's wrapper members and its far-end jitter buffer
+ * (echo_control_mobile.cc:42-79), the core's frame buffers and the core state (aecm_core.h:41-141) -- in a form that does
+ * not depend on the object it was taken from.  A session imported into any slot of any object of the same sampling rate
+ * continues bit-exactly where the exported one stopped, whatever the two objects' ages; the exporting object is not
+ * changed.  ImportSession refuses (AECM_BAD_PARAMETER_ERROR, nothing changed) a snapshot of another layout or rate, one
+ * whose wrapper state could not have been reached (buffer fills, pending samples, flags), and a core state ImportState
+ * would refuse.  Both calls wait for the ticks enqueued so far. */
+size_t WebRtcAecmSessions_session_size_bytes(void);
+int32_t WebRtcAecmSessions_ExportSession(AecmSessions *s, int32_t session, void *snapshot, size_t size_bytes);
+int32_t WebRtcAecmSessions_ImportSession(AecmSessions *s, int32_t session, const void *snapshot, size_t size_bytes);
+
 /* AECM_KERNEL_FAST (default) or AECM_KERNEL_SAFE cross-lane primitives. */
 int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
 
 /* How a ProcessBlocks launch is scheduled on the device; results do not depend on it.  A launch of more streams than
  * the pipelined form takes (4 096 on an MI355X) is cut into chunks of chunk_blocks blocks that resident wavefronts
  * claim in order from a queue, so that all streams advance together and the launch does not end at low occupancy
- * (default: 128 blocks, environment AECM_QUEUE_CHUNK; a quarter of it, at least 8, while every stream's wavefront is
- * resident at once).  chunk_blocks = 0: one wavefront keeps one stream for the whole launch, always.  min_streams < 0
- * (default): the threshold above; >= 0: the queue form above that many streams (diagnostics / tests). */
+ * (default: 128 blocks, environment AECM_QUEUE_CHUNK; the default / environment value is quartered, to at least 8, while
+ * every stream's wavefront is resident at once -- a chunk_blocks set through this call is taken as it is).
+ * chunk_blocks = 0: one wavefront keeps one stream for the whole launch, always.  min_streams < 0 (default): the
+ * threshold above; >= 0: the queue form above that many streams (diagnostics / tests). */
 int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, int32_t min_streams);
 /* Launches the chip holds at once (<= 4 streams x 4 workgroups per compute unit = 4 096 streams on an MI355X; fast
  * variant, no clean near-end input) run pipelined: six wavefronts serve four streams, the state-independent transforms

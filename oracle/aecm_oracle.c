@@ -98,6 +98,9 @@ struct AecmOracle {
     int16_t dfa_clean_q, dfa_clean_q_old, dfa_noisy_q, dfa_noisy_q_old;
     uint32_t tot_count;
     uint32_t seed;
+
+    /* Not state: how often a block took the data-dependent paths the HIP kernel has short forms for (aecm_oracle_get_stats). */
+    uint64_t stats[ORC_STATS];
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -720,6 +723,12 @@ int aecm_oracle_process_block(AecmOracle *o, const int16_t far_blk[ORC_BLOCK],
     o->tot_count++;                                                          /* :506 */
     update_channel(o, far_spec, zeros_xbuf, dfa_noisy, mu, echo_est);        /* :511 */
     const int16_t sup_gain = calc_suppression_gain(o);                       /* :514 */
+    o->stats[ORC_STAT_BLOCKS]++;
+    o->stats[ORC_STAT_NLMS] += mu != 0;                                      /* aecm_core.cc:830 */
+    o->stats[ORC_STAT_GAIN_ZERO] += sup_gain == 0;
+    o->stats[ORC_STAT_Q_STEADY] += o->dfa_clean_q <= o->dfa_clean_q_old;
+    o->stats[ORC_STAT_DELAYED] += delay != 0;
+    o->stats[ORC_STAT_VAD] += o->current_vad != 0;
 
     for (int i = 0; i < ORC_BINS; ++i) {                                     /* :517-615 */
         uint32_t gained;
@@ -824,6 +833,7 @@ int aecm_oracle_process_block(AecmOracle *o, const int16_t far_blk[ORC_BLOCK],
     }
     int out_cfft = 0;
     aecm_oracle_fft128(re, im, 1, &out_cfft);
+    o->stats[ORC_STAT_IFFT_UNSCALED] += out_cfft == 0;                       /* complex_fft.c:382-396: no stage rescaled */
     const int sh = out_cfft - o->dfa_clean_q;
     for (int i = 0; i < ORC_BLOCK; ++i) {                                    /* :218-235 */
         int16_t y = (int16_t)((re[i] * kOrcSqrtHanningQ14[i] + 8192) >> 14);
@@ -853,6 +863,8 @@ int aecm_oracle_process_stream(AecmOracle *o, const int16_t *far_s, const int16_
 /* ------------------------------------------------------------------------------------------ */
 /* Lifetime / configuration                                                                     */
 /* ------------------------------------------------------------------------------------------ */
+
+void aecm_oracle_get_stats(const AecmOracle *o, uint64_t stats[ORC_STATS]) { memcpy(stats, o->stats, sizeof o->stats); }
 
 AecmOracle *aecm_oracle_create(void) { return (AecmOracle *)calloc(1, sizeof(AecmOracle)); }
 void aecm_oracle_free(AecmOracle *o) { free(o); }

@@ -28,6 +28,17 @@ enum {
     ORC_LOGBUF = 64,     /* MAX_BUF_LEN (aecm_defines.h:33) */
     ORC_DIGEST_WORDS = 24
 };
+/* Branch statistics of the blocks processed since aecm_oracle_init (bench.py's content sweep): how many blocks ... */
+enum {
+    ORC_STAT_BLOCKS = 0,
+    ORC_STAT_NLMS,            /* ... ran the NLMS channel update (mu != 0, aecm_core.cc:830) */
+    ORC_STAT_GAIN_ZERO,       /* ... had supGain == 0 after CalcSuppressionGain (every Wiener gain is then ONE_Q14) */
+    ORC_STAT_Q_STEADY,        /* ... did not raise the near-end Q domain (dfaCleanQDomain <= dfaCleanQDomainOld, aecm_core_c.cc:552-579) */
+    ORC_STAT_IFFT_UNSCALED,   /* ... went through the inverse transform without a rescaling stage (complex_fft.c:382-396) */
+    ORC_STAT_DELAYED,         /* ... used an aligned far spectrum older than the current one (delay != 0, aecm_core.cc:157-172) */
+    ORC_STAT_VAD,             /* ... had currentVADValue set (aecm_core.cc:733-740) */
+    ORC_STATS = 8
+};
 
 typedef struct AecmOracle AecmOracle;
 
@@ -64,6 +75,8 @@ int aecm_oracle_process_stream(AecmOracle *o, const int16_t *far_s, const int16_
 /* State digest for parity triage (same word order as the HIP library's
  * WebRtcAecmBatch_GetDigest; see include/aecm_batch.h). */
 void aecm_oracle_digest(const AecmOracle *o, uint32_t digest[ORC_DIGEST_WORDS]);
+
+void aecm_oracle_get_stats(const AecmOracle *o, uint64_t stats[ORC_STATS]);
 
 /* Exposed for unit tests of the primitives. */
 int32_t aecm_oracle_sqrt_floor(int32_t value);                          /* spl.cc:84-105 */

@@ -81,6 +81,7 @@ def oracle_lib():
         lib.aecm_oracle_process_block.argtypes = [C.c_void_p, _i16p, _i16p, C.c_void_p, _i16p]
         lib.aecm_oracle_process_stream.argtypes = [C.c_void_p, _i16p, _i16p, _i16p, C.c_size_t]
         lib.aecm_oracle_digest.argtypes = [C.c_void_p, _u32p]
+        lib.aecm_oracle_get_stats.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")]
         lib.aecm_oracle_sqrt_floor.argtypes = [C.c_int32]
         lib.aecm_oracle_sqrt_floor.restype = C.c_int32
         lib.aecm_oracle_fft128.argtypes = [_i16p, _i16p, C.c_int, C.POINTER(C.c_int)]
@@ -156,6 +157,13 @@ class OracleStream:
         d = np.zeros(DIGEST_WORDS, dtype=np.uint32)
         self.lib.aecm_oracle_digest(self.h, d)
         return d
+
+    def stats(self):
+        """Branch statistics since init (oracle/aecm_oracle.h: ORC_STAT_*) as a dict of block counts."""
+        st = np.zeros(8, dtype=np.uint64)
+        self.lib.aecm_oracle_get_stats(self.h, st)
+        names = ("blocks", "nlms", "gain_zero", "q_steady", "ifft_unscaled", "delayed", "vad")
+        return {n: int(st[i]) for i, n in enumerate(names)}
 
     def echo_path(self):
         p = np.zeros(BINS, dtype=np.int16)

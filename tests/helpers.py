@@ -25,14 +25,25 @@ def oracle_run(seed, n_blocks, fs, cng, echo_mode, profile=None, chunks=None):
     return out, o.digest()
 
 
-def oracle_batch(seeds, n_blocks, fs, configs, workers=None, pairs=None):
-    """Oracle over many streams in parallel threads (ctypes releases the GIL).  pairs = (far, near) [len(seeds), L]
-    arrays already synthesised from these seeds (saves synthesising them a second time)."""
+def checker_name(prefer_reference=True):
+    """Which CPU checker the full-size tests use: the unmodified reference when its prebuilt library travelled with the tree
+    (oracle/_ref), else the restatement (itself pinned to the reference by tests/test_oracle.py where the reference exists)."""
+    return "reference" if prefer_reference and pyoracle.have_reference() else "port"
+
+
+def oracle_batch(seeds, n_blocks, fs, configs, workers=None, pairs=None, prefer_reference=False):
+    """CPU checker over many streams in parallel threads (ctypes releases the GIL).  pairs = (far, near) [len(seeds), L]
+    arrays already synthesised from these seeds (saves synthesising them a second time).  prefer_reference: run the
+    UNMODIFIED REFERENCE (pyoracle.RefCoreStream: WebRtcAecm_ProcessBlock itself) instead of our restatement of it when
+    oracle/_ref is there -- the HIP path is then compared with the reference directly, not through the restatement."""
+    use_ref = checker_name(prefer_reference) == "reference"
+
     def one(i):
         cng, em = configs[i]
-        if pairs is not None:
-            o = pyoracle.OracleStream(fs, cng, em)
-            return o.process(pairs[0][i], pairs[1][i]), o.digest()
+        if pairs is not None or use_ref:
+            far, near = (pairs[0][i], pairs[1][i]) if pairs is not None else synth_pair(seeds[i], n_blocks, fs)
+            o = pyoracle.RefCoreStream(fs, cng, em) if use_ref else pyoracle.OracleStream(fs, cng, em)
+            return o.process(far, near), o.digest()
         return oracle_run(seeds[i], n_blocks, fs, cng, em)
     with ThreadPoolExecutor(max_workers=workers) as ex:
         res = list(ex.map(one, range(len(seeds))))
@@ -123,7 +134,8 @@ def drive_session(sess, far, near, frame, ms_seq, far_present=None, clean=None):
 
 
 # ---- WAV files in the sample formats the reference CLI reads (dr_wav) ----------------------------------------------------
-WAV_FORMATS = ("u8", "s16", "s24", "s32", "s16_ext", "s24_ext", "f32", "f64", "f32_ext", "alaw", "mulaw")
+# "s16_align4": a 16-bit file whose header claims a block alignment of 4 -- dr_wav goes by the bit depth (dr_wav.h:1815-1827)
+WAV_FORMATS = ("u8", "s16", "s24", "s32", "s16_ext", "s24_ext", "f32", "f64", "f32_ext", "alaw", "mulaw", "s16_align4")
 
 
 def write_wav_format(path, rate, x, fmt):
@@ -135,6 +147,9 @@ def write_wav_format(path, rate, x, fmt):
     rs = np.random.RandomState(len(x) * 31 + len(fmt))
     ext = fmt.endswith("_ext")
     base = fmt[:-4] if ext else fmt
+    bad_align = fmt == "s16_align4"
+    if bad_align:
+        base = "s16"
     if base == "u8":
         tag, bits, data = 1, 8, (((x >> 8) + 128) & 0xff).astype(np.uint8).tobytes()
     elif base == "s16":
@@ -156,7 +171,7 @@ def write_wav_format(path, rate, x, fmt):
         tag, bits, data = (6 if base == "alaw" else 7), 8, codes.tobytes()
     else:
         raise ValueError(fmt)
-    align = bits // 8
+    align = 4 if bad_align else bits // 8
     if ext:
         guid_tail = bytes.fromhex("000000001000800000aa00389b71")
         fmt_chunk = struct.pack("<HHIIHHHHI", 0xFFFE, 1, rate, rate * align, align, bits, 22, bits, 4) + struct.pack("<H", tag) + guid_tail

@@ -185,7 +185,7 @@ struct SimWave {
     static vi table_index_for_this_block() { return vi(0); }
     static void begin_stream() {}
     static void begin_block(int, int) {}
-    template <int PHASE> static void phase_priority() {}
+    template <int PHASE> static void phase_priority(int = 0) {}
     static int pin_uniform(int x) { return x; }                            // device: a uniform value pinned to a scalar register
     static int per_block(int x) { return x; }                              // device: keeps launch-invariant conditions in the loop                                   // device: issue-priority rotation
 

@@ -119,6 +119,21 @@ def test_bench_strong_scaling_shards_sum_to_the_total():
     assert d["parity"]["ok"] is True and d["parity"]["ranks_ok"] == 2
 
 
+def test_bench_eight_ranks_preflight_on_one_gpu():
+    """The shape of the driver's 8-GPU run (configs[4]) with the ranks mapped onto the one device present: eight processes
+    under torch.distributed.run, eight HIP engines, the counter collectives over eight ranks, every rank's own parity check
+    (on its share of the host's cores), weak and strong sharding.  tools/scale_preflight.sh runs the same for N = 2, 4, 8."""
+    d = _bench_json(["--gpus", "8", "--share-devices", "--streams", "1024", "--blocks", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                    timeout=1500)
+    assert d["n_gpus"] == 8 and d["ranks"]["ranks_seen"] == 8 and d["ranks"]["world_size"] == 8
+    assert d["ranks"]["per_rank_streams"] == [1024] * 8 and len(set(d["ranks"]["per_rank_device"])) >= 1
+    assert d["parity"]["ok"] is True and d["parity"]["ranks_ok"] == 8 and d["parity"]["checker_threads"] >= 1
+    assert abs(d["value"] * d["config"]["timed_region_s"] - 8 * 1024 * 64 * 2) < 1.0 and d["scaling"] == "weak"
+    d = _bench_json(["--gpus", "8", "--share-devices", "--total-streams", "8191", "--blocks", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                    timeout=1500)
+    assert d["scaling"] == "strong" and d["ranks"]["per_rank_streams"] == [1024] * 7 + [1023] and d["parity"]["ranks_ok"] == 8
+
+
 def test_bench_refuses_more_ranks_than_devices_quickly():
     """`bench.py --gpus 4` on a box with fewer devices must die with ONE clear line before any rendezvous."""
     import time

@@ -588,14 +588,15 @@ def test_block_parity_vs_real_reference():
 
 
 def test_config2_4096_streams_bit_exact():
-    """BASELINE config 2: 4096 streams, 16 kHz, every stream checked against the oracle."""
+    """BASELINE config 2: 4096 streams, 16 kHz, every stream checked against the CPU checker -- the unmodified reference
+    (WebRtcAecm_ProcessBlock, aecm_core_c.cc:368-711) where oracle/_ref is present, our restatement otherwise."""
     S, T, fs = 4096, 2048, 16000                 # SURVEY 8.d Config 2: T >= 2 048
     seeds = list(range(10000, 10000 + S))
     cfgs = [(1, 3)] * S
     far, near = synth_streams(seeds, T, fs)
     b = aecm.AecmBatch(S, fs)
     out = b.process_host(far, near)
-    exp_out, exp_dig = oracle_batch(seeds, T, fs, cfgs, pairs=(far, near))
+    exp_out, exp_dig = oracle_batch(seeds, T, fs, cfgs, pairs=(far, near), prefer_reference=True)     # the reference itself when oracle/_ref travelled
     bad = [s for s in range(S) if not np.array_equal(out[s], exp_out[s])]
     assert not bad, f"{len(bad)} streams differ, first {bad[:5]}"
     for s in range(0, S, 97):
@@ -605,11 +606,12 @@ def test_config2_4096_streams_bit_exact():
 def _replicated_full_size_run(S, T, fs, U, seed0, chunking=None):
     """S streams replicating U distinct seeded (far, near) pairs, one launch of T blocks with everything resident in HBM
     (replication, the launch and the comparison all on the device: the buffers are several GB each).  Every stream's
-    output must equal the oracle's answer for the pair it replicates, and sampled streams' state digests too."""
+    output must equal the CPU checker's answer for the pair it replicates (the unmodified reference where oracle/_ref is
+    present, else the restatement), and sampled streams' state digests too."""
     import torch
     seeds = list(range(seed0, seed0 + U))
     far, near = synth_streams(seeds, T, fs)
-    exp_out, exp_dig = oracle_batch(seeds, T, fs, [(1, 3)] * U, pairs=(far, near))
+    exp_out, exp_dig = oracle_batch(seeds, T, fs, [(1, 3)] * U, pairs=(far, near), prefer_reference=True)    # the reference itself when it travelled
     assert S % U == 0
     L = T * 64
     dfar = torch.from_numpy(far).cuda().unsqueeze(0).expand(S // U, U, L).reshape(S, L)       # stream s replicates pair s % U
@@ -676,6 +678,7 @@ def test_chunk_queue_launch_under_contention(fs, clean):
         for s, (cng, em) in enumerate(cfgs):
             b.set_config(cng, em, s, 1)
         b.set_launch_chunking(chunk, 0)
+        assert b.describe_launch(T, clean) == (2, chunk)                # an explicit chunk length is taken as it is
         out = np.concatenate([b.process_host(far[:, :T * 64], near[:, :T * 64], cln[:, :T * 64] if clean else None),
                               b.process_host(far[:, T * 64:], near[:, T * 64:], cln[:, T * 64:] if clean else None)], axis=1)
         for s in range(S):
@@ -811,7 +814,7 @@ def test_chunk_queue_launch_larger_than_the_chip():
     S, T, fs, U = 9001, 300, 16000, 16
     seeds = list(range(7300, 7300 + U))
     far, near = synth_streams(seeds, 2 * T, fs)
-    exp_out, exp_dig = oracle_batch(seeds, 2 * T, fs, [(1, 3)] * U, pairs=(far, near))
+    exp_out, exp_dig = oracle_batch(seeds, 2 * T, fs, [(1, 3)] * U, pairs=(far, near), prefer_reference=True)
     idx = torch.arange(S) % U
     dfar = torch.from_numpy(far).cuda()[idx].contiguous()
     dnear = torch.from_numpy(near).cuda()[idx].contiguous()
@@ -1583,4 +1586,178 @@ def test_async_tick_event_hooks_order_the_callers_streams():
     assert sb.synchronize() == 0
     torch.cuda.synchronize()
     assert np.array_equal(collected.cpu().numpy(), exp)
+    sb.close()
+
+
+def test_bulk_state_export_import_equals_the_single_stream_forms():
+    """WebRtcAecmBatch_ExportStates / ImportStates (one gather / scatter launch for a range of streams) against the per-stream
+    ExportState / ImportState: the same blobs, and a batch restored through the bulk form continues bit-exactly -- through
+    host memory, through device memory and through a registered host buffer; a range with one bad blob is refused whole."""
+    import struct
+    import torch
+    fs, T1, T2, S = 16000, 300, 200, 70
+    seeds = list(range(8100, 8100 + S))
+    far, near = synth_streams(seeds, T1 + T2, fs)
+    a = aecm.AecmBatch(S, fs, 1, 2)
+    a.process_host(far[:, :T1 * 64], near[:, :T1 * 64])
+    n = aecm.load().WebRtcAecmBatch_state_size_bytes()
+    blobs = a.export_states(3, S - 5)                                     # streams 3 .. S - 3
+    assert blobs.shape == (S - 5, n)
+    for k in (0, 1, 33, S - 6):
+        assert blobs[k].tobytes() == a.export_state(3 + k), k
+    # device memory and a registered host buffer give the same bytes
+    dev = torch.empty((S - 5, n), dtype=torch.uint8, device="cuda")
+    a.export_states_device(3, S - 5, dev.data_ptr())
+    assert np.array_equal(dev.cpu().numpy(), blobs)
+    pinned = np.zeros((S - 5, n), dtype=np.uint8)
+    alias = aecm.ffi.register_host_buffer(pinned)
+    try:
+        a.export_states_device(3, S - 5, alias)
+        assert np.array_equal(pinned, blobs)
+    finally:
+        aecm.ffi.unregister_host_buffer(pinned)
+    exp_out = a.process_host(far[:, T1 * 64:], near[:, T1 * 64:])       # how the exported streams continue
+    # restore into another batch at other slots: host form, then device form
+    for form in ("host", "device"):
+        b = aecm.AecmBatch(S + 9, fs, 0, 4)
+        if form == "host":
+            b.import_states(11, blobs)
+        else:
+            b.import_states_device(11, S - 5, dev.data_ptr())
+        fb = np.zeros((S + 9, T2 * 64), np.int16)
+        nb = np.zeros_like(fb)
+        fb[11:11 + S - 5], nb[11:11 + S - 5] = far[3:S - 2, T1 * 64:], near[3:S - 2, T1 * 64:]
+        out_b = b.process_host(fb, nb)
+        assert np.array_equal(out_b[11:11 + S - 5], exp_out[3:S - 2]), form
+        for k in (0, 20, S - 6):
+            assert np.array_equal(b.digest(11 + k), a.digest(3 + k)), (form, k)
+        b.close()
+    # all or nothing: one bad blob in the middle (history position out of range) -> nothing is touched
+    c = aecm.AecmBatch(S, fs)
+    before = [c.digest(s) for s in (0, 10, 40, S - 6)]
+    bad = blobs.copy()
+    struct.pack_into("<i", bad[40], 32 + 12 * 64 * 4 + 4 * 3, 1000)       # S_HISTPOS of blob 40
+    lib = aecm.load()
+    assert lib.WebRtcAecmBatch_ImportStates(c.h, 0, S - 5, bad.ctypes.data, bad.nbytes) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    dbad = torch.from_numpy(bad).cuda()
+    assert lib.WebRtcAecmBatch_ImportStatesDevice(c.h, 0, S - 5, dbad.data_ptr(), bad.nbytes) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert all(np.array_equal(c.digest(s), d) for s, d in zip((0, 10, 40, S - 6), before))
+    # argument checks: range, size
+    assert lib.WebRtcAecmBatch_ExportStates(c.h, S - 2, 3, bad.ctypes.data, 3 * n) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert lib.WebRtcAecmBatch_ExportStates(c.h, 0, 3, bad.ctypes.data, 3 * n - 1) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert lib.WebRtcAecmBatch_ImportStates(c.h, 0, 1, None, n) == aecm.ffi.AECM_NULL_POINTER_ERROR
+    c.close()
+    a.close()
+
+
+def test_bulk_state_export_of_65536_streams_is_fast():
+    """The point of the range forms: 65 536 streams are exported with one gather launch -- to device memory, and
+    over the link into a registered host buffer -- in well under 50 ms; the per-stream form needs 196 608 blocking copies."""
+    import time
+    import torch
+    S = 65536
+    n = aecm.load().WebRtcAecmBatch_state_size_bytes()
+    b = aecm.AecmBatch(S, 16000)
+    dev = torch.empty((S, n), dtype=torch.uint8, device="cuda")
+    b.export_states_device(0, S, dev.data_ptr())                          # warm-up (first touch of 1.06 GB)
+    t0 = time.perf_counter()
+    b.export_states_device(0, S, dev.data_ptr())
+    t_dev = time.perf_counter() - t0
+    assert dev[S - 1].cpu().numpy().tobytes() == b.export_state(S - 1)
+    assert t_dev < 0.050, t_dev
+    host = np.zeros((S, n), dtype=np.uint8)
+    alias = aecm.ffi.register_host_buffer(host)
+    try:
+        b.export_states_device(0, S, alias)
+        t0 = time.perf_counter()
+        b.export_states_device(0, S, alias)
+        t_link = time.perf_counter() - t0
+        assert host[S // 2].tobytes() == b.export_state(S // 2)
+    finally:
+        aecm.ffi.unregister_host_buffer(host)
+    print(f"\n65 536 states: {t_dev * 1e3:.2f} ms to device memory, {t_link * 1e3:.2f} ms into a registered host buffer "
+          f"({S * n / t_link / 1e9:.1f} GB/s)")
+    assert t_link < 0.050, t_link
+    b.close()
+
+
+@_needs_ref
+@pytest.mark.parametrize("fs,frame,with_clean", [(16000, 160, 0), (8000, 80, 1), (16000, 80, 0)])
+def test_session_migrates_mid_call_between_session_batches(fs, frame, with_clean):
+    """WebRtcAecmSessions_ExportSession / ImportSession: live sessions are moved mid-call -- right after a far-end underrun,
+    in the middle of the delay compensation that follows start-up, during a run of underruns, and late in steady state -- into
+    another AecmSessions object of another size and another age (its near-end ring position differs), into whatever slot.
+    From then on the moved session, the session it was copied from (which keeps running) and the reference session that
+    received exactly the same calls must agree sample for sample and code for code."""
+    S, S2 = 5, 3
+    n_calls = 5 * fs // frame // 2                                        # 2.5 s
+    pairs = [synth_pair(1300 + k, n_calls * frame // 64 + 1, fs, "mixed") for k in range(S)]
+    far = np.stack([p[0][:n_calls * frame] for p in pairs])
+    near = np.stack([p[1][:n_calls * frame] for p in pairs])
+    clean = synth_clean(near) if with_clean else None
+    pats = [call_pattern(90 + k, n_calls) for k in range(S)]
+    refs = [pyoracle.RefSession(fs, 1, 3) for _ in range(S)]
+    sa = aecm.AecmSessions(S, fs, 1, 3)
+    sb = aecm.AecmSessions(S2, fs, 0, 1)
+    rs = np.random.RandomState(3)
+    # the other object has a life of its own (other age: its near-end ring position is not sa's)
+    for _ in range(7):
+        z = rs.randint(-3000, 3000, size=(S2, frame)).astype(np.int16)
+        sb.tick_host(z, z, 40, z if with_clean else None)
+    start_calls = 7 if (fs, frame) == (16000, 160) else 4                 # the first Process after start-up with ms = 40 (+ jitter)
+    underrun = int(np.nonzero(pats[2][1] == 0)[0][0])
+    run_start = int(np.nonzero((np.arange(n_calls) % 211 >= 205) & (np.arange(n_calls) > 100))[0][0])
+    moves = {start_calls + 1: (0, 1), underrun + 1: (2, 0), run_start + 3: (3, 2), n_calls - 40: (4, 1)}    # tick -> (session of sa, slot of sb)
+    where = {}                                                            # slot of sb -> session of sa it now mirrors
+    n_size = aecm.load().WebRtcAecmSessions_session_size_bytes()
+    for i in range(n_calls):
+        sl = slice(i * frame, (i + 1) * frame)
+        if i in moves:
+            k, slot = moves[i]
+            rc, snap = sa.export_session(k)
+            assert rc == 0 and len(snap) == n_size
+            assert sb.import_session(slot, snap) == 0
+            rc2, snap2 = sb.export_session(slot)                         # a snapshot does not depend on the object it is in
+            assert rc2 == 0 and snap2 == snap, (i, k, slot)
+            where[slot] = k
+        ms = np.array([pats[k][0][i] for k in range(S)], dtype=np.int16)
+        fl = np.array([0 if pats[k][1][i] else aecm.ffi.SESSION_NO_FAREND for k in range(S)], dtype=np.uint8)
+        rc, out, codes = sa.tick_host_per_session(far[:, sl], near[:, sl], ms, None if clean is None else clean[:, sl], flags=fl)
+        # sb: moved sessions get the calls of the session they mirror; the other slots idle on noise
+        fb = rs.randint(-3000, 3000, size=(S2, frame)).astype(np.int16)
+        nb = fb.copy()
+        cb = fb.copy() if with_clean else None
+        msb = np.full(S2, 40, dtype=np.int16)
+        flb = np.zeros(S2, dtype=np.uint8)
+        for slot, k in where.items():
+            fb[slot], nb[slot], msb[slot], flb[slot] = far[k, sl], near[k, sl], ms[k], fl[k]
+            if with_clean:
+                cb[slot] = clean[k, sl]
+        rcb, outb, codesb = sb.tick_host_per_session(fb, nb, msb, cb, flags=flb)
+        for k in range(S):
+            if not fl[k]:
+                assert refs[k].buffer_farend(far[k, sl]) == 0
+            rc1, o1 = refs[k].process(near[k, sl], None if clean is None else clean[k, sl], int(ms[k]))
+            assert codes[k] == rc1 and np.array_equal(out[k], o1), (fs, frame, i, k)
+        for slot, k in where.items():
+            assert codesb[slot] == codes[k] and np.array_equal(outb[slot], out[k]), (fs, frame, i, slot, k)
+    assert len(where) == 3 and set(where.values()) == {2, 3, 4}        # slot 1 was overwritten by the last move
+    # refusals leave the slot as it was: wrong size, bad magic, another rate, an impossible wrapper state
+    import struct
+    rc, snap = sa.export_session(1)
+    lib = aecm.load()
+    assert lib.WebRtcAecmSessions_ImportSession(sb.h, 0, snap, len(snap) - 1) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    bad = bytearray(snap); bad[0] ^= 0xff
+    assert sb.import_session(0, bytes(bad)) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    bad = bytearray(snap); struct.pack_into("<I", bad, 8, 24000 - fs)
+    assert sb.import_session(0, bytes(bad)) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    flow0 = 32 + aecm.load().WebRtcAecmBatch_state_size_bytes()
+    bad = bytearray(snap); struct.pack_into("<i", bad, flow0 + 4 * 15, struct.unpack_from("<i", bad, flow0 + 4 * 16)[0] + 6400)   # F_FRM_POS 100 blocks ahead of F_BLK_POS
+    assert sb.import_session(0, bytes(bad)) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    bad = bytearray(snap); struct.pack_into("<i", bad, flow0 + 4 * 9, 2)                                                            # F_EC_STARTUP is a flag
+    assert sb.import_session(0, bytes(bad)) == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    assert sb.import_session(S2, snap) == aecm.ffi.AECM_BAD_PARAMETER_ERROR and sb.export_session(-1)[0] == aecm.ffi.AECM_BAD_PARAMETER_ERROR
+    rc, again = sb.export_session(0)
+    assert rc == 0 and again == sa.export_session(2)[1]                  # slot 0 still mirrors session 2, tick for tick
+    sa.close()
     sb.close()

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Run ON THE GPU BOX with a diagnostics build of the library (tools/ab_build.py trace="-DAECM_PIPE_TRACE ..."):
+where the time of a pipelined launch goes, per wave -- when each workgroup started and finished (100 MHz wall clock) and how
+long each of its six waves sat at the per-block barrier (shader clocks).
+
+    AECM_LIB_PATH=webrtc_aecm_amd/_lib/ab_trace.so python tools/pipe_trace.py --streams 4096 --blocks 2048
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=4096)
+    ap.add_argument("--blocks", type=int, default=2048)
+    ap.add_argument("--fs", type=int, default=16000)
+    a = ap.parse_args()
+    trace = tempfile.NamedTemporaryFile(suffix=".bin", delete=False).name
+    os.environ["AECM_PIPE_TRACE_FILE"] = trace
+    import torch
+
+    import bench
+    import webrtc_aecm_amd as aecm
+    S, T = a.streams, a.blocks
+    dev = torch.device("cuda", 0)
+    far, near = bench.synth_on_device(torch, S, T * 64, 1234, dev)
+    out = torch.empty_like(near)
+    b = aecm.AecmBatch(S, a.fs, cng_mode=1, echo_mode=1)
+    assert b.describe_launch(T)[0] == 3, "not a pipelined launch"
+    torch.cuda.synchronize()
+    for _ in range(2):                       # the second launch (steady state of the signal's second pass) is the one recorded
+        b.process_device(far.data_ptr(), near.data_ptr(), out.data_ptr(), T * 64, 64, T)
+        b.synchronize()
+    ms = b.last_launch_ms()
+    rec = np.fromfile(trace, dtype=np.uint64).reshape(-1, 6, 4).astype(np.int64)       # [workgroup][wave][t0, t1, wait, total]
+    n_wg = (S + 3) // 4
+    rec = rec[:n_wg]
+    t0 = rec[:, :, 0].min()
+    start = (rec[:, :, 0].min(axis=1) - t0) / 100.0          # us
+    end = (rec[:, :, 1].max(axis=1) - t0) / 100.0
+    wait_frac = rec[:, :, 2] / np.maximum(rec[:, :, 3], 1)
+    q = lambda x: [round(float(v), 1) for v in np.percentile(x, [0, 10, 50, 90, 100])]
+    res = {
+        "streams": S, "blocks": T, "kernel_ms": ms, "workgroups": int(n_wg),
+        "start_us_pctl_0_10_50_90_100": q(start), "end_us_pctl_0_10_50_90_100": q(end),
+        "mean_end_over_last_end": round(float(end.mean() / end.max()), 4),
+        "barrier_wait_fraction_back_waves_mean": round(float(wait_frac[:, :4].mean()), 4),
+        "barrier_wait_fraction_front_waves_mean": round(float(wait_frac[:, 4:].mean()), 4),
+        "barrier_wait_fraction_back_pctl": [round(float(v), 3) for v in np.percentile(wait_frac[:, :4], [0, 10, 50, 90, 100])],
+        "barrier_wait_fraction_front_pctl": [round(float(v), 3) for v in np.percentile(wait_frac[:, 4:], [0, 10, 50, 90, 100])],
+        # do the workgroups that finish early share something?  finish time by dispatch order (blockIdx) in eight bands
+        "end_us_by_blockidx_octile": [round(float(v), 1) for v in end.reshape(-1)[: n_wg // 8 * 8].reshape(8, -1).mean(axis=1)] if n_wg >= 8 else None,
+        "end_us_by_blockidx_mod8": [round(float(end[k::8].mean()), 1) for k in range(8)] if n_wg >= 8 else None,
+    }
+    print(json.dumps(res))
+    os.unlink(trace)
+
+
+if __name__ == "__main__":
+    main()

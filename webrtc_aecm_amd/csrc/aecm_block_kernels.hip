@@ -104,8 +104,19 @@ void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, c
 // when the grid is larger than the chip; with S >= the resident waves the wait practically never happens.  The wait is
 // bounded anyway: a wave that gives up raises *err (never cleared by a launch; the engine reports it at the next
 // synchronisation) and leaves.
+#ifndef AECM_QUEUE_FENCES
+#define AECM_QUEUE_FENCES 0
+#endif
+constexpr int kQueueAcquire = AECM_QUEUE_FENCES ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED;
+constexpr int kQueueRelease = AECM_QUEUE_FENCES ? __ATOMIC_RELEASE : __ATOMIC_RELAXED;
 constexpr int kQueueCtlWords = 16;          // [0] next item, then done[stream] = chunks of this launch completed
-constexpr uint32_t kQueueMaxPolls = 1u << 20;      // x (s_sleep 16 = 1 024 cycles + one load): about a second
+// A wait is for a wave that is running a chunk, so its bound grows with the chunk: 2^20 polls (x (s_sleep 16 = 1 024 cycles +
+// one load): a second or two) or 64 polls per block of the chunk, whichever is more (a block takes a wave ~7 us on a full chip:
+// ~3 polls) -- a healthy predecessor on a shared or debugged GPU is not mistaken for a hung one.
+__device__ __forceinline__ uint32_t QueueMaxPolls(int chunk_blocks) {
+    const uint32_t by_chunk = (uint32_t)chunk_blocks << 6;         // chunk_blocks <= 2^20 (BatchEngine::kMaxQueueChunk)
+    return by_chunk > (1u << 20) ? by_chunk : (1u << 20);
+}
 
 template <bool kHasClean>
 __global__ __launch_bounds__(64 * kWavesPerWorkgroup)
@@ -128,9 +139,9 @@ void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blo
         const uint32_t stream = item - chunk * (uint32_t)n_streams;
         if (chunk != 0) {
             uint32_t polls = 0;
-            while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < chunk) {
+            while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + stream, kQueueAcquire, __HIP_MEMORY_SCOPE_AGENT)) < chunk) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++polls > kQueueMaxPolls ||
+                if (++polls > QueueMaxPolls(chunk_blocks) ||
                     ((polls & 1023u) == 0 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)) {
                     __hip_atomic_store(err, 1u + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every wave leaves at its next claim
                     return;
@@ -144,7 +155,7 @@ void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blo
         E::run_stream_io(st, sio, (int64_t)stream, nb);
         // every store of the chunk (state, history rows: sc1, written through) has completed before the flag is raised
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __hip_atomic_store(done + stream, chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done + stream, chunk + 1u, kQueueRelease, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -171,7 +182,65 @@ struct PipeSlot {           // the spectra of one block of one stream on their w
 };
 struct PipeShared {
     PipeSlot slots[2][kPipeStreams];      // [block parity][stream of the workgroup]
+    int ahead;                            // this workgroup leads the launch's slowest one by more than the allowed lead (balance, below)
+    int level;                            // the front waves' base priority for the current group of blocks (balance modes 2, 3)
 };
+
+// Balance.  Every workgroup of a pipelined launch is resident from the start and has the same amount of work, but the SIMD's
+// arbiter serves the highest priority first and then its OLDEST wave: the workgroups dispatched first pull ahead, finish
+// early, and the launch ends at low occupancy (round 4: 4.71 of the 6 placed waves resident on average, vector port 76 %).
+// Progress feedback: blocks are counted in groups of 2^AECM_PIPE_BALANCE_GROUP_LOG2.  At every group boundary the first
+// front wave of a workgroup (the "monitor": front waves finish their step early and would otherwise just park at the
+// barrier) publishes the workgroup's group count in its own word of progress[] (a write-through store, no atomic), reads
+// everybody's words (n_workgroups / 64 loads of 64 lanes, issued at the top of its step and looked at at the end of it) and
+// takes their minimum: a workgroup more than AECM_PIPE_BALANCE_LEAD groups ahead of the slowest one runs its back waves with
+// lowered phase priorities (Gfx950Wave<.., kDynamicPrio>) for the next group -- they still issue whenever the others leave a
+// slot free (a lowered priority is work-conserving, a sleeping wave is not), but no longer win ties.  The flag reaches the
+// other waves through LDS behind the barrier every wave executes anyway.  Stale words only make the verdict late.
+#ifndef AECM_PIPE_BALANCE
+#define AECM_PIPE_BALANCE 2
+#endif
+#ifndef AECM_PIPE_BALANCE_GROUP_LOG2
+#define AECM_PIPE_BALANCE_GROUP_LOG2 4
+#endif
+#ifndef AECM_PIPE_BALANCE_LEAD
+#define AECM_PIPE_BALANCE_LEAD 1
+#endif
+// AECM_PIPE_BALANCE: 0 off; 1 the back waves of a workgroup that is ahead run demoted (and its front waves at
+// AECM_PIPE_FRONT_PRIO instead of .._BEHIND, if those differ); 2 only the front waves' priority follows the flag -- a
+// workgroup advances at the pace of its front waves (the back waves run at higher priorities and park at the barrier until
+// the spectra of the next block are there: measured 30 % of their time at 4 096 streams), so the front waves are the handle.
+// AECM_PIPE_BALANCE_RULE: which workgroups take the LOW front priority: 0 those more than LEAD groups ahead of the slowest,
+// 1 those less than LEAD groups behind the fastest (i.e. only the stragglers are raised).  AECM_PIPE_BALANCE 3: like 2 with
+// one level per group of lead (proportional instead of on / off).
+#ifndef AECM_PIPE_FRONT_PRIO_BEHIND
+#if AECM_PIPE_BALANCE == 3
+#define AECM_PIPE_FRONT_PRIO_BEHIND 2
+#elif AECM_PIPE_BALANCE == 2
+#define AECM_PIPE_FRONT_PRIO_BEHIND 1
+#else
+#define AECM_PIPE_FRONT_PRIO_BEHIND AECM_PIPE_FRONT_PRIO     // the front waves' priority while their workgroup is NOT ahead
+#endif
+#endif
+#ifndef AECM_PIPE_MONITOR_SAMPLE
+#define AECM_PIPE_MONITOR_SAMPLE 0
+#endif
+#ifndef AECM_PIPE_BALANCE_RULE
+#define AECM_PIPE_BALANCE_RULE 0
+#endif
+// A front wave's priority rises by AECM_PIPE_FRONT_SECOND_BOOST while it works on its second stream (the rule of the back
+// waves' phase table -- the priority rises with the progress through the step -- applied to the front waves).
+#ifndef AECM_PIPE_FRONT_SECOND_BOOST
+#define AECM_PIPE_FRONT_SECOND_BOOST 1
+#endif
+__device__ __forceinline__ void SetPrioDynamic(int p) {      // s_setprio takes an immediate
+    if (p <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+constexpr int kPipeGroupLog2 = AECM_PIPE_BALANCE_GROUP_LOG2, kPipeGroupMask = (1 << kPipeGroupLog2) - 1;
+constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of up to 1 024 workgroups (4 096 streams) are balanced, larger ones run as before
 
 // Synchronisation: ONE workgroup barrier per block.  While the back waves work on block b out of slots[b & 1], the front
 // waves write block b + 1 into slots[(b + 1) & 1]; the barrier at the end of the step makes both true for the next one.
@@ -181,10 +250,20 @@ struct PipeShared {
 // issue slots, and at the priority its last phase left it with it starves the wave it is waiting for.)
 __global__ __launch_bounds__(64 * kPipeWaves)
 __attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
-void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks) {
-    FillLdsTables<64 * kPipeWaves>(st.consts);
+void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, uint32_t *progress, int n_workgroups) {
+#if defined(AECM_PIPE_TRACE)     // diagnostics build: per wave, when it started / ended (100 MHz wall clock) and how long it sat at barriers (shader clocks)
+    const uint64_t trace_t0 = wall_clock64(), trace_c0 = clock64();
+    uint64_t trace_wait = 0;
+#define AECM_PIPE_BARRIER() do { const uint64_t c_ = clock64(); __syncthreads(); trace_wait += clock64() - c_; } while (0)
+#else
+#define AECM_PIPE_BARRIER() __syncthreads()
+#endif
     PipeShared &sh = *reinterpret_cast<PipeShared *>(&g_lds[1]);        // behind the tables
-    using W = Gfx950Wave<true, true>;
+    // (without progress words -- a launch too short or too small to balance -- the front waves run at their plain priority)
+    const int front_level0 = AECM_PIPE_BALANCE && progress != nullptr ? AECM_PIPE_FRONT_PRIO_BEHIND : AECM_PIPE_FRONT_PRIO;
+    if (AECM_PIPE_BALANCE && threadIdx.x == 0) { sh.ahead = 0; sh.level = front_level0; }
+    FillLdsTables<64 * kPipeWaves>(st.consts);                          // ends in a barrier
+    using W = Gfx950Wave<true, true, false, false, AECM_PIPE_BALANCE == 1>;
     using E = BlockEngine<W, false>;
     using EF = BlockEngine<Gfx950Wave<true, false>, false>;               // the front waves keep one priority (no per-phase s_setprio)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -200,9 +279,13 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
         uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
         typename E::StridedIo sio{io, stream * io.stream_stride};
         if (live) E::load_state(r, vec, scal);
+        r.u.prio_drop = 0;
         W::begin_stream();
-        __syncthreads();                                                  // the spectra of block 0 are in slots[0]
+        AECM_PIPE_BARRIER();                                                  // the spectra of block 0 are in slots[0]
         for (int blk = 0; blk < n_blocks; ++blk) {
+            // Balance (see above): the monitor wrote the flag at the end of its step blk, which ran next to this wave's block
+            // blk - 1 and ended in the barrier this wave has just passed.
+            if (AECM_PIPE_BALANCE == 1 && (blk & kPipeGroupMask) == 0 && blk != 0) r.u.prio_drop = __builtin_amdgcn_readfirstlane(sh.ahead);
             if (live) {
                 const PipeSlot &slot = sh.slots[blk & 1][wave];
                 const int lane = W::lane_id();
@@ -224,14 +307,15 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 const int out = E::back_block(r, hist, xf, df, df);
                 sio.out(r, blk, out);
             }
-            __syncthreads();                                              // slots[blk & 1] are free again, block blk + 1 is in the others
+            AECM_PIPE_BARRIER();                                              // slots[blk & 1] are free again, block blk + 1 is in the others
         }
         if (live) E::template store_state<false>(r, vec, scal);
     } else {
         // ---- front wave: two streams, the transforms of the block after the one their back waves are at ----
         typename EF::Regs r;
         EF::init_lane_constants(r, st.consts);
-        __builtin_amdgcn_s_setprio(AECM_PIPE_FRONT_PRIO);
+        int level = front_level0;                                         // this group's base priority (constant without balance)
+        SetPrioDynamic(level);
         const int k0 = (wave - kPipeStreams) * kPipeStreamsPerFront;
         int x_old[kPipeStreamsPerFront], d_old[kPipeStreamsPerFront], far_next[kPipeStreamsPerFront], near_next[kPipeStreamsPerFront];
         bool live[kPipeStreamsPerFront];
@@ -247,10 +331,43 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             }
         }
         for (int blk = 0; blk <= n_blocks; ++blk) {                      // trip blk writes block blk (the last trip: nothing)
+            // Balance: the monitor's step at a group boundary (see above).  pv[] is only ever read under the condition it is
+            // loaded under (no initialisation: a register written by a move while a load of an earlier trip may still be
+            // pending in the compiler's eyes costs a wait for everything in flight at the top of every trip).
+            const bool boundary = AECM_PIPE_BALANCE && progress != nullptr && (blk & kPipeGroupMask) == 0 && blk != 0;
+            const bool monitor = boundary && wave == kPipeStreams;
+            int pv[kPipeMonitorLoads];
+            if (monitor) {
+                // a workgroup's word is the 16-bit COMPLEMENT of its group count: the cleared buffer (and the unused half of an
+                // odd last word) then reads as "as far ahead as can be", never as the slowest
+                const int g = blk >> kPipeGroupLog2;
+                __hip_atomic_store(reinterpret_cast<uint16_t *>(progress) + blockIdx.x, (uint16_t)(0xffff - (g < 0xffff ? g : 0xffff)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int lane = W::lane_id(), n_words = (n_workgroups + 1) >> 1;
+#if AECM_PIPE_MONITOR_SAMPLE
+                // a sample instead of everybody: 128 workgroups (one load), a different 128 at every boundary and in every workgroup.
+                // The slow workgroups are a quarter to a half of the launch (the ones dispatched last to each CU), so every sample has some.
+                const int n_chunks = (n_words + 63) >> 6, chunk = (int)((blockIdx.x + (unsigned)g * 7u) % (unsigned)n_chunks);
+                const int w = lane + 64 * chunk;
+                pv[0] = (int)__hip_atomic_load(progress + (w < n_words ? w : n_words - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+#pragma unroll
+                for (int i = 0; i < kPipeMonitorLoads; ++i) {
+                    const int w = lane + 64 * i;
+                    if (64 * i < n_words)
+                        pv[i] = (int)__hip_atomic_load(progress + (w < n_words ? w : n_words - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#endif
+            }
+            if (AECM_PIPE_BALANCE && AECM_PIPE_FRONT_PRIO_BEHIND != AECM_PIPE_FRONT_PRIO && (blk & kPipeGroupMask) == 1 && blk > kPipeGroupMask) {
+                level = __builtin_amdgcn_readfirstlane(sh.level);
+                if (AECM_PIPE_FRONT_SECOND_BOOST == 0) SetPrioDynamic(level);
+            }
             if (blk < n_blocks) {
 #pragma unroll
                 for (int k = 0; k < kPipeStreamsPerFront; ++k) {
                     if (!live[k]) continue;
+                    if (AECM_PIPE_FRONT_SECOND_BOOST != 0) SetPrioDynamic(level + (k == 0 ? 0 : AECM_PIPE_FRONT_SECOND_BOOST));
                     const int far_cur = far_next[k], near_cur = near_next[k];
                     if (blk + 1 < n_blocks) {
                         typename EF::StridedIo sio{io, (first + k0 + k) * io.stream_stride};
@@ -275,12 +392,47 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                     slot.scalars[lane] = sc;
                 }
             }
-            __syncthreads();
+            if (monitor) {
+                const int n_words = (n_workgroups + 1) >> 1;
+                int m = AECM_PIPE_BALANCE_RULE == 0 ? pv[0] : pk_add_u16(pv[0], -1);
+#if !AECM_PIPE_MONITOR_SAMPLE
+#pragma unroll
+                for (int i = 1; i < kPipeMonitorLoads; ++i)
+                    if (64 * i < n_words) m = AECM_PIPE_BALANCE_RULE == 0 ? pk_max_u16(m, pv[i]) : pk_min_u16(m, pk_add_u16(pv[i], -1));
+#endif
+#if AECM_PIPE_BALANCE_RULE == 0
+                const int slowest = 0xffff - W::reduce_max(imax(zext16(m), lsr(m, 16)));      // group count of the slowest workgroup that has published
+                const int lead = (blk >> kPipeGroupLog2) - slowest;
+#if defined(AECM_PIPE_BALANCE_DRY)       // A/B: the monitor runs, nobody is ever demoted (what the mechanism itself costs)
+                sh.ahead = lead > 0x7ffffff ? 1 : 0;
+#else
+                sh.ahead = lead > AECM_PIPE_BALANCE_LEAD ? 1 : 0;
+#endif
+#else
+                // the fastest: the smallest published word (an unpublished or unused half reads 0: minus one it is the largest)
+                const int fastest = 0xfffe - W::reduce_min(imin(zext16(m), lsr(m, 16)));
+                const int lead = AECM_PIPE_BALANCE_LEAD + 1 - (fastest - (blk >> kPipeGroupLog2));     // (> LEAD <=> less than one group behind the fastest)
+                sh.ahead = lead > AECM_PIPE_BALANCE_LEAD ? 1 : 0;
+#endif
+#if AECM_PIPE_BALANCE == 3      // proportional: one priority level per group of lead beyond the allowed one, from .._BEHIND down to AECM_PIPE_FRONT_PRIO
+                sh.level = imax(AECM_PIPE_FRONT_PRIO_BEHIND - imax(lead - AECM_PIPE_BALANCE_LEAD, 0), AECM_PIPE_FRONT_PRIO);
+#else
+                sh.level = sh.ahead ? AECM_PIPE_FRONT_PRIO : AECM_PIPE_FRONT_PRIO_BEHIND;
+#endif
+            }
+            AECM_PIPE_BARRIER();
         }
         for (int k = 0; k < kPipeStreamsPerFront; ++k)
             if (live[k]) EF::store_time_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
     }
+#if defined(AECM_PIPE_TRACE)
+    if ((threadIdx.x & 63u) == 0) {
+        uint64_t *tr = reinterpret_cast<uint64_t *>(progress + 2 * ((n_workgroups + 3) / 4) * 2) + ((size_t)blockIdx.x * kPipeWaves + wave) * 4;
+        tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = trace_wait; tr[3] = clock64() - trace_c0;
+    }
+#endif
 }
+#undef AECM_PIPE_BARRIER
 
 // Streams a pipelined launch keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
 int PipelinedStreamLimit(int compute_units) {
@@ -288,11 +440,40 @@ int PipelinedStreamLimit(int compute_units) {
     return (compute_units > 0 ? compute_units : 256) * (by_waves < by_lds ? by_waves : by_lds) * kPipeStreams;
 }
 
-hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, hipStream_t stream) {
+// The progress words of a pipelined launch: 16 bits per workgroup (cleared by the launch).
+size_t PipelinedControlBytes(int n_streams) {
+    const size_t n_wg = (size_t)(n_streams + kPipeStreams - 1) / kPipeStreams;
+#if defined(AECM_PIPE_TRACE)
+    return 4 * ((n_wg + 3) / 4) * sizeof(uint32_t) + n_wg * kPipeWaves * 4 * sizeof(uint64_t);      // progress halves (padded), then the trace records
+#else
+    return (n_wg + 2) / 2 * sizeof(uint32_t);
+#endif
+}
+size_t PipelinedTraceOffsetBytes(int n_streams) {
+    const size_t n_wg = (size_t)(n_streams + kPipeStreams - 1) / kPipeStreams;
+    return 4 * ((n_wg + 3) / 4) * sizeof(uint32_t);
+}
+
+// Balance pays where a CU holds four workgroups (measured: +3 % at 3 584 streams, +3.5 % at 4 096, -2 % at 3 072 and below, where
+// the monitor costs more than the two or three workgroups of a CU drift apart): from 3 workgroups per CU on average upwards.
+bool PipelinedBalanceApplies(int n_streams, int n_blocks, int compute_units) {
+    const int n_wg = (n_streams + kPipeStreams - 1) / kPipeStreams;
+    return AECM_PIPE_BALANCE != 0 && n_blocks >= (8 << kPipeGroupLog2) && n_wg <= 128 * kPipeMonitorLoads &&
+           n_wg > 3 * (compute_units > 0 ? compute_units : 256);
+}
+
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, uint32_t *progress,
+                                        hipStream_t stream) {
     if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
     const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * kPipeWaves);
     const size_t lds = sizeof(LdsTables) + sizeof(PipeShared);
-    hipLaunchKernelGGL(aecm_process_pipelined_kernel, grid, block, lds, stream, st, io, n_streams, n_blocks);
+    // a launch of a few groups is over before a lead can build up: no counters, no clearing launch in front of it
+    // progress: null = no balance (the engine asks PipelinedBalanceApplies)
+    if (progress) {
+        const hipError_t e = hipMemsetAsync(progress, 0, PipelinedControlBytes(n_streams), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(aecm_process_pipelined_kernel, grid, block, lds, stream, st, io, n_streams, n_blocks, progress, (int)grid.x);
     return hipGetLastError();
 }
 

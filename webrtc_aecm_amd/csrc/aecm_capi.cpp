@@ -238,6 +238,35 @@ int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *st
     return b->engine->ImportState(stream, state);
 }
 
+static int32_t CheckStates(const AecmBatch *b, int32_t first, int32_t count, const void *states, size_t size_bytes) {
+    if (!b) return -1;
+    if (!states) return AECM_NULL_POINTER_ERROR;
+    if (!b->engine->initialized()) return AECM_UNINITIALIZED_ERROR;
+    if (first < 0 || count < 0 || count > b->engine->num_streams() - first) return AECM_BAD_PARAMETER_ERROR;
+    if (size_bytes != (size_t)count * BatchEngine::kStateBytes) return AECM_BAD_PARAMETER_ERROR;
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_ExportStates(AecmBatch *b, int32_t first, int32_t count, void *states_host, size_t size_bytes) {
+    if (int32_t rc = CheckStates(b, first, count, states_host, size_bytes)) return rc;
+    return b->engine->ExportStates(first, count, states_host, false) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_ImportStates(AecmBatch *b, int32_t first, int32_t count, const void *states_host, size_t size_bytes) {
+    if (int32_t rc = CheckStates(b, first, count, states_host, size_bytes)) return rc;
+    return b->engine->ImportStates(first, count, states_host, false);
+}
+
+int32_t WebRtcAecmBatch_ExportStatesDevice(AecmBatch *b, int32_t first, int32_t count, void *states_dev, size_t size_bytes) {
+    if (int32_t rc = CheckStates(b, first, count, states_dev, size_bytes)) return rc;
+    return b->engine->ExportStates(first, count, states_dev, true) ? 0 : AECM_UNSPECIFIED_ERROR;
+}
+
+int32_t WebRtcAecmBatch_ImportStatesDevice(AecmBatch *b, int32_t first, int32_t count, const void *states_dev, size_t size_bytes) {
+    if (int32_t rc = CheckStates(b, first, count, states_dev, size_bytes)) return rc;
+    return b->engine->ImportStates(first, count, states_dev, true);
+}
+
 int32_t WebRtcAecmBatch_GetDigest(AecmBatch *b, int32_t stream, uint32_t digest[AECM_BATCH_DIGEST_WORDS]) {
     if (!b) return -1;
     if (!digest) return AECM_NULL_POINTER_ERROR;
@@ -292,6 +321,22 @@ int32_t WebRtcAecmSessions_set_config(AecmSessions *s, AecmConfig config) {
 }
 
 int32_t WebRtcAecmSessions_InitSession(AecmSessions *s, int32_t session) { return s ? s->batch->InitSession(session) : -1; }
+
+size_t WebRtcAecmSessions_session_size_bytes(void) { return aecm::SessionBatch::kSessionBytes; }
+
+int32_t WebRtcAecmSessions_ExportSession(AecmSessions *s, int32_t session, void *snapshot, size_t size_bytes) {
+    if (!s) return -1;
+    if (!snapshot) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes != aecm::SessionBatch::kSessionBytes) return AECM_BAD_PARAMETER_ERROR;
+    return s->batch->ExportSession(session, snapshot);
+}
+
+int32_t WebRtcAecmSessions_ImportSession(AecmSessions *s, int32_t session, const void *snapshot, size_t size_bytes) {
+    if (!s) return -1;
+    if (!snapshot) return AECM_NULL_POINTER_ERROR;
+    if (size_bytes != aecm::SessionBatch::kSessionBytes) return AECM_BAD_PARAMETER_ERROR;
+    return s->batch->ImportSession(session, snapshot);
+}
 
 int32_t WebRtcAecmSessions_set_config_session(AecmSessions *s, int32_t session, AecmConfig config) {
     return s ? s->batch->SetConfigSession(session, config.cngMode, config.echoMode) : -1;

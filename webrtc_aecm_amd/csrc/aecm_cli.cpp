@@ -125,10 +125,12 @@ bool ReadWav(const std::string &path, Wav *w) {
             }
             have_fmt = true;
         } else if (memcmp(tag, "data", 4) == 0) {
-            // bytes per sample from the block alignment (as dr_wav does: drwav_get_bytes_per_pcm_frame), else from the bit depth
+            // bytes per sample as the reference CLI's reader takes them (dr_wav.h:1815-1827, drwav_get_bytes_per_pcm_frame): from
+            // the bit depth when that is a whole number of bytes, else from the block alignment
             if (!have_fmt || w->channels == 0) { ok = false; break; }
-            unsigned bytes = (block_align && block_align % w->channels == 0) ? block_align / w->channels : 0;
-            if (bytes == 0 && bits % 8 == 0) bytes = bits / 8;
+            unsigned bytes = 0;
+            if (bits != 0 && bits % 8 == 0) bytes = bits / 8;
+            else if (block_align && block_align % w->channels == 0) bytes = block_align / w->channels;
             int16_t probe;
             const uint8_t zero[8] = {0};
             if (bytes == 0 || bytes > 8 || !DecodeSample(format, bytes, zero, &probe)) { ok = false; break; }

@@ -1,7 +1,9 @@
 #include "aecm_engine.h"
 
 #include "aecm_session_flow.h"
+#include "aecm_state_check.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,10 +30,11 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     e->num_streams_ = num_streams;
     int cus = 0;
     if (!AECM_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id))) cus = 0;
+    e->compute_units_ = cus;
     e->rotation_limit_ = RotationStreamLimit(cus);
     e->resident_waves_ = ResidentWaves(cus);
     e->queue_chunk_ = kDefaultQueueChunk;
-    if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::max(0, atoi(env));
+    if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::min(std::max(0, atoi(env)), kMaxQueueChunk);   // the C API's bound
     if (const char *env = getenv("AECM_QUEUE_MIN_STREAMS")) e->queue_min_streams_ = atoi(env);      // experiments: the queue form above this many streams
     e->pipe_max_streams_ = PipelinedStreamLimit(cus);
     if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
@@ -76,6 +79,8 @@ BatchEngine::~BatchEngine() {
     if (mapped_host_) (void)hipHostFree(mapped_host_);
     (void)hipFree(rec_maps_);
     (void)hipFree(rec_scratch_);
+    (void)hipFree(state_stage_);
+    (void)hipFree(state_verdict_);
     if (download_stream_) (void)hipStreamDestroy(download_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -95,6 +100,7 @@ bool BatchEngine::Init(int fs) {
     // finished in an unknown state; re-initialising all of them is what clears the record
     if (queue_err_ && !AECM_HIP_OK(hipMemsetAsync(queue_err_, 0, sizeof(uint32_t), stream_))) return false;
     queue_unchecked_ = false;
+    launch_failed_ = false;
     if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;   // img goes out of scope
     initialized_ = true;
     fs_ = fs;
@@ -176,24 +182,41 @@ bool BatchEngine::EnsureLaunchErrorWord() {
 
 // One launch of the block kernels over `count` streams (st, io already offset to the first of them), in the chunk-queue form
 // when the launch is larger than the chip (see QueueLaunchApplies).
+// The control words of a chunk-queue or pipelined launch (one buffer, grown on first use; launches on stream_ are ordered, so
+// consecutive launches may share it).
+bool BatchEngine::EnsureLaunchControl(size_t need) {
+    if (need <= queue_ctl_bytes_) return true;
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;       // stream-ordered work may still read the old one
+    (void)hipFree(queue_ctl_);
+    queue_ctl_ = nullptr;
+    queue_ctl_bytes_ = 0;
+    if (!AECM_HIP_OK(hipMalloc((void **)&queue_ctl_, need))) return false;
+    queue_ctl_bytes_ = need;
+    return true;
+}
+
 bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev) {
+    if (launch_failed_) return false;                 // streams half processed by an abandoned launch: nothing runs until Init
     const int chunk = QueueChunkFor(count);
     if (QueueLaunchApplies(count, num_blocks, variant_, chunk, QueueMinStreams(), blocks_per_stream_dev != nullptr)) {
-        const size_t need = QueueControlBytes(count);
-        if (need > queue_ctl_bytes_) {                       // grown on first use; stream-ordered work may still read the old one
-            if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
-            (void)hipFree(queue_ctl_);
-            queue_ctl_ = nullptr;
-            queue_ctl_bytes_ = 0;
-            if (!AECM_HIP_OK(hipMalloc((void **)&queue_ctl_, need))) return false;
-            queue_ctl_bytes_ = need;
-        }
+        if (!EnsureLaunchControl(QueueControlBytes(count))) return false;
         if (!EnsureLaunchErrorWord()) return false;
         queue_unchecked_ = true;
         return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, chunk, resident_waves_, queue_ctl_, queue_err_, stream_));
     }
     if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
-        return AECM_HIP_OK(LaunchProcessBlocksPipelined(st, io, count, num_blocks, stream_));
+#if defined(AECM_PIPE_TRACE)
+        trace_streams_ = count;
+    if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
+#endif
+    {
+        bool balance = PipelinedBalanceApplies(count, num_blocks, compute_units_);
+#if defined(AECM_PIPE_TRACE)
+        balance = true;                       // (the diagnostics build keeps the buffer: its per-wave records live behind the progress words)
+#endif
+        if (balance && !EnsureLaunchControl(PipelinedControlBytes(count))) return false;
+        return AECM_HIP_OK(LaunchProcessBlocksPipelined(st, io, count, num_blocks, balance ? queue_ctl_ : nullptr, stream_));
+    }
     return AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, rotation_limit_, stream_, blocks_per_stream_dev));
 }
 
@@ -209,8 +232,9 @@ bool BatchEngine::PipelinedLaunchApplies(int count, bool clean, bool ragged) con
 // with items claimed in order those waves simply take more of the work (4 608 streams 728 -> 830 M frames/s, 6 144
 // 844 -> 930 M, 7 168 917 -> 961 M; profiles/r04_experiments.md section 4).  Shorter chunks there: 32 instead of 128 blocks.
 int BatchEngine::QueueMinStreams() const { return queue_min_streams_ >= 0 ? queue_min_streams_ : pipe_max_streams_; }
+// (The quarter rule is for the default and the environment's chunk; a length set through SetLaunchChunking is taken as it is.)
 int BatchEngine::QueueChunkFor(int count) const {
-    if (queue_chunk_ <= 0 || count > resident_waves_) return queue_chunk_;
+    if (queue_chunk_ <= 0 || count > resident_waves_ || queue_chunk_explicit_) return queue_chunk_;
     return std::max(8, queue_chunk_ / 4);
 }
 
@@ -225,14 +249,33 @@ int BatchEngine::DescribeLaunch(int num_blocks, bool has_clean, int *chunk_block
 }
 
 // Wait for everything enqueued on stream_; false if a HIP call failed or a wave of a chunk-queue launch gave up waiting.
-bool BatchEngine::Drain() { return AECM_HIP_OK(hipStreamSynchronize(stream_)) && CheckQueueError(); }
+bool BatchEngine::Drain() {
+    if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+#if defined(AECM_PIPE_TRACE)     // diagnostics build: the last pipelined launch's per-wave records -> $AECM_PIPE_TRACE_FILE (raw uint64 x 4 per wave)
+    if (const char *path = getenv("AECM_PIPE_TRACE_FILE")) {
+        if (trace_streams_ > 0) {
+            const size_t off = PipelinedTraceOffsetBytes(trace_streams_), bytes = PipelinedControlBytes(trace_streams_) - off;
+            std::vector<uint8_t> host(bytes);
+            if (AECM_HIP_OK(hipMemcpy(host.data(), reinterpret_cast<uint8_t *>(queue_ctl_) + off, bytes, hipMemcpyDeviceToHost))) {
+                if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }
+            }
+            trace_streams_ = 0;
+        }
+    }
+#endif
+    return CheckQueueError();
+}
 
-// After a synchronisation of stream_: did a wave of a chunk-queue launch give up waiting (it never should)?
+// After a synchronisation of stream_: did a wave of a chunk-queue launch give up waiting (it never should)?  The verdict
+// is sticky: an abandoned launch leaves streams half processed, so every later Drain() (ExportState, Digest, GetEchoPath,
+// Synchronize ...) and every later launch fails too, until Init() has re-initialised the streams.
 bool BatchEngine::CheckQueueError() {
+    if (launch_failed_) return false;
     if (!queue_unchecked_) return true;
-    queue_unchecked_ = false;
     uint32_t err = 0;
-    if (!AECM_HIP_OK(hipMemcpy(&err, queue_err_, sizeof err, hipMemcpyDeviceToHost))) return false;
+    if (!AECM_HIP_OK(hipMemcpy(&err, queue_err_, sizeof err, hipMemcpyDeviceToHost))) return false;      // unchecked stays set: asked again next time
+    queue_unchecked_ = false;
+    if (err != 0) launch_failed_ = true;
     return err == 0;
 }
 
@@ -557,15 +600,9 @@ bool BatchEngine::GetEchoPath(int stream, int16_t path[kBins]) {
     return true;
 }
 
-// Snapshot = header + vec + scal + hist.  The header pins the layout the blob was written with, so a blob from
-// another build (different field lists) or a corrupted one is refused instead of being used as addresses.
-namespace {
-struct SnapshotHeader {
-    uint32_t magic, version, fs, num_vec, num_scal, history, lanes, reserved;
-};
-constexpr uint32_t kSnapshotMagic = 0x53434541u;      // "AECS"
-static_assert(sizeof(SnapshotHeader) == BatchEngine::kStateHeaderBytes, "snapshot header size");
-}  // namespace
+// Snapshot = header + vec + scal + hist (aecm_state_check.h: SnapshotHeader).  The header pins the layout the blob was written
+// with, so a blob from another build (different field lists) or a corrupted one is refused instead of being used as addresses.
+static_assert(kStateHeaderBytes == BatchEngine::kStateHeaderBytes && kStateBlobBytes == BatchEngine::kStateBytes, "snapshot blob size");
 
 bool BatchEngine::ExportState(int stream, void *buf) {
     if (stream < 0 || stream >= num_streams_) return false;
@@ -591,10 +628,7 @@ int32_t BatchEngine::ImportState(int stream, const void *buf) {
     const uint8_t *p = static_cast<const uint8_t *>(buf);
     SnapshotHeader h;
     memcpy(&h, p, sizeof h);
-    if (h.magic != kSnapshotMagic || h.version != kStateLayoutVersion || h.num_vec != (uint32_t)kNumVec ||
-        h.num_scal != (uint32_t)kNumScal || h.history != (uint32_t)kHistory || h.lanes != (uint32_t)kLanes ||
-        (h.fs != 8000u && h.fs != 16000u))
-        return kErrBadParameter;
+    if (!SnapshotHeaderOk(h)) return kErrBadParameter;
     const uint8_t *body = p + kStateHeaderBytes;
     int32_t scal[kNumScal];
     memcpy(scal, body + kVecWordsPerStream * 4, sizeof scal);
@@ -610,6 +644,84 @@ int32_t BatchEngine::ImportState(int stream, const void *buf) {
                                 kHistWordsPerStream * 2, hipMemcpyHostToDevice))))
         return kErrUnspecified;
     if ((int)h.fs != fs_) mixed_rates_ = true;       // ProcessRecordings schedules every stream for fs_: refuse until the next Init
+    return 0;
+}
+
+bool BatchEngine::EnsureStateStage(int streams) {
+    const size_t need = (size_t)std::min(streams, kStateStageStreams) * kStateBytes;
+    if (need > state_stage_bytes_) {
+        if (!AECM_HIP_OK(hipStreamSynchronize(stream_))) return false;
+        (void)hipFree(state_stage_);
+        state_stage_ = nullptr;
+        state_stage_bytes_ = 0;
+        if (!AECM_HIP_OK(hipMalloc((void **)&state_stage_, need))) return false;
+        state_stage_bytes_ = need;
+    }
+    return state_verdict_ || AECM_HIP_OK(hipMalloc((void **)&state_verdict_, 2 * sizeof(uint32_t)));
+}
+
+bool BatchEngine::ExportStates(int first, int count, void *states, bool device) {
+    if (first < 0 || count < 0 || first + count > num_streams_) return false;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return false;
+    if (count == 0) return Drain();
+    if (device) return AECM_HIP_OK(LaunchGatherStates(st_, first, count, states, stream_)) && Drain();
+    if (!EnsureStateStage(count)) return false;
+    uint8_t *dst = static_cast<uint8_t *>(states);
+    for (int s0 = 0; s0 < count; s0 += kStateStageStreams) {                      // the copy of a chunk is ordered before the next gather
+        const int n = std::min(kStateStageStreams, count - s0);
+        if (!AECM_HIP_OK(LaunchGatherStates(st_, first + s0, n, state_stage_, stream_)) ||
+            !AECM_HIP_OK(hipMemcpyAsync(dst + (size_t)s0 * kStateBytes, state_stage_, (size_t)n * kStateBytes, hipMemcpyDeviceToHost, stream_)))
+            return false;
+    }
+    return Drain();
+}
+
+int32_t BatchEngine::ImportStates(int first, int count, const void *states, bool device) {
+    if (first < 0 || count < 0 || first + count > num_streams_) return kErrBadParameter;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return kErrUnspecified;
+    if (count == 0) return 0;
+    bool other_rate = false;
+    if (device) {
+        if (!EnsureStateStage(1)) return kErrUnspecified;
+        const uint32_t preset[2] = {0xffffffffu, 0u};
+        uint32_t verdict[2] = {0, 0};
+        if (!AECM_HIP_OK(hipMemcpyAsync(state_verdict_, preset, sizeof preset, hipMemcpyHostToDevice, stream_)) ||
+            !AECM_HIP_OK(LaunchValidateStates(states, count, fs_, state_verdict_, stream_)) ||
+            !AECM_HIP_OK(hipMemcpyAsync(verdict, state_verdict_, sizeof verdict, hipMemcpyDeviceToHost, stream_)) || !Drain())
+            return kErrUnspecified;
+        if (verdict[0] != 0xffffffffu) return kErrBadParameter;
+        other_rate = verdict[1] != 0;
+        if (!AECM_HIP_OK(LaunchScatterStates(st_, first, count, states, stream_)) || !Drain()) return kErrUnspecified;
+    } else {
+        const uint8_t *src = static_cast<const uint8_t *>(states);
+        for (int s = 0; s < count; ++s) {                                        // all or nothing: every blob before any stream
+            const uint8_t *blob = src + (size_t)s * kStateBytes;
+            SnapshotHeader h;
+            memcpy(&h, blob, sizeof h);
+            if (!SnapshotHeaderOk(h)) return kErrBadParameter;
+            const uint32_t *vec = reinterpret_cast<const uint32_t *>(blob + kStateHeaderBytes);      // blobs are 16-byte multiples: aligned if the buffer is
+            const int32_t *scal = reinterpret_cast<const int32_t *>(blob + kStateHeaderBytes + kVecWordsPerStream * 4);
+            uint32_t vec_copy[kVecWordsPerStream];
+            int32_t scal_copy[kNumScal];
+            if (reinterpret_cast<uintptr_t>(blob) & 3) {
+                memcpy(vec_copy, vec, sizeof vec_copy);
+                memcpy(scal_copy, scal, sizeof scal_copy);
+                vec = vec_copy;
+                scal = scal_copy;
+            }
+            if (ValidateStateImage(vec, scal, (int)h.fs) != nullptr) return kErrBadParameter;
+            other_rate = other_rate || (int)h.fs != fs_;
+        }
+        if (!EnsureStateStage(count)) return kErrUnspecified;
+        for (int s0 = 0; s0 < count; s0 += kStateStageStreams) {
+            const int n = std::min(kStateStageStreams, count - s0);
+            if (!AECM_HIP_OK(hipMemcpyAsync(state_stage_, src + (size_t)s0 * kStateBytes, (size_t)n * kStateBytes, hipMemcpyHostToDevice, stream_)) ||
+                !AECM_HIP_OK(LaunchScatterStates(st_, first + s0, n, state_stage_, stream_)))
+                return kErrUnspecified;
+        }
+        if (!Drain()) return kErrUnspecified;
+    }
+    if (other_rate) mixed_rates_ = true;
     return 0;
 }
 

@@ -51,14 +51,25 @@ public:
     bool GetEchoPath(int stream, int16_t path[kBins]);
     bool Digest(int stream, uint32_t digest[kDigestWords]);
     static constexpr size_t kStateHeaderBytes = 32;
-    static constexpr uint32_t kStateLayoutVersion = 3;      // bump whenever aecm_state.h's field lists change
     static constexpr size_t kStateBytes = kStateHeaderBytes + kVecWordsPerStream * 4 + kNumScal * 4 + kHistWordsPerStream * 2;
     bool ExportState(int stream, void *buf);
     int32_t ImportState(int stream, const void *buf);       // 0 / AECM_BAD_PARAMETER_ERROR / AECM_UNSPECIFIED_ERROR
+    // The same for streams [first, first + count) at once: `states` = count blobs of kStateBytes, host memory or (device =
+    // true) anything the device can address -- device memory, or the alias of a registered host buffer.  One gather /
+    // scatter launch (+ one copy per chunk of streams for host memory) instead of three blocking copies per stream.
+    // ImportStates is all or nothing: every blob is validated like ImportState validates one (on the device for device
+    // blobs) before any stream is touched.
+    bool ExportStates(int first, int count, void *states, bool device);
+    int32_t ImportStates(int first, int count, const void *states, bool device);
     void set_variant(int v) { variant_ = v; }
     // blocks = 0: every launch in the one-stream-per-wave form.  min_streams < 0: launches of more streams than the chip
     // holds waves take the queue form (the default); otherwise launches of more than min_streams streams do (tests).
-    void set_queue_chunk(int blocks, int min_streams) { queue_chunk_ = blocks < 0 ? 0 : blocks; queue_min_streams_ = min_streams; }
+    void set_queue_chunk(int blocks, int min_streams) {
+        queue_chunk_ = blocks < 0 ? 0 : blocks > kMaxQueueChunk ? kMaxQueueChunk : blocks;
+        queue_chunk_explicit_ = true;
+        queue_min_streams_ = min_streams;
+    }
+    static constexpr int kMaxQueueChunk = 1 << 20;
     int DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const;
     void set_pipelined_min_streams(int n) { pipe_min_streams_ = n > 0 ? n : 0x7fffffff; }    // n <= 0: never
     int variant() const { return variant_; }
@@ -70,6 +81,7 @@ private:
     bool FlushTimers() { return HarvestTimers(true); }
 
     int device_ = 0;
+    int compute_units_ = 0;
     int rotation_limit_ = 0;             // RotationStreamLimit of device_'s CU count (launch-size switch of the block kernels)
     // The chunk-queue form of large launches (aecm_block_kernels.hip): chunk length in blocks (0 = off; AECM_QUEUE_CHUNK),
     // the chip's resident waves, the queue's control words (grown on first use) and its error word.
@@ -77,6 +89,8 @@ private:
     uint32_t *queue_ctl_ = nullptr, *queue_err_ = nullptr;
     size_t queue_ctl_bytes_ = 0;
     bool queue_unchecked_ = false;       // a queue launch has been enqueued since the error word was last read
+    bool queue_chunk_explicit_ = false;  // queue_chunk_ was set through set_queue_chunk: taken as it is (QueueChunkFor)
+    bool launch_failed_ = false;         // a wave of a queue launch gave up: sticky until Init (CheckQueueError)
     // The pipelined form of launches the chip holds at once: from pipe_min_streams_ (AECM_PIPELINED; SetLaunchPipelining)
     // up to PipelinedStreamLimit of the device.
     int pipe_min_streams_ = kDefaultPipelinedMinStreams, pipe_max_streams_ = 0;
@@ -87,6 +101,8 @@ private:
     bool CheckQueueError();
     bool Drain();
     bool EnsureLaunchErrorWord();
+    bool EnsureLaunchControl(size_t need);
+    int trace_streams_ = 0;              // diagnostics builds (-DAECM_PIPE_TRACE) only
     int num_streams_ = 0;
     bool initialized_ = false;
     int variant_ = kVariantFast;
@@ -125,6 +141,12 @@ private:
     size_t rec_scratch_elems_ = 0;
     bool EnsureRecordingScratch(size_t map_elems, size_t sample_elems);
     bool mixed_rates_ = false;            // ImportState brought in a stream of the other sampling rate
+    // staging of the host forms of ExportStates / ImportStates (grow-only, at most kStateStageStreams blobs) + the validation verdict
+    static constexpr int kStateStageStreams = 8192;
+    uint8_t *state_stage_ = nullptr;
+    size_t state_stage_bytes_ = 0;
+    uint32_t *state_verdict_ = nullptr;
+    bool EnsureStateStage(int streams);
     hipStream_t download_stream_ = nullptr;    // ProcessBlocksHost: downloads overlap the next chunk's uploads
 };
 

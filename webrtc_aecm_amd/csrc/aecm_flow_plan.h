@@ -20,6 +20,8 @@
 
 #include <stdint.h>
 
+#include <initializer_list>
+
 #if defined(__HIPCC__)
 #define AECM_FLOW_HD __host__ __device__ __forceinline__
 #else
@@ -113,6 +115,28 @@ AECM_FLOW_HD bool FlowFieldStartsAtOne(int f) {
 }
 AECM_FLOW_HD void FlowInit(int32_t words[kFlowWords]) {
     for (int i = 0; i < kFlowWords; ++i) words[i] = i < kFlowFieldsUsed && FlowFieldStartsAtOne(i) ? 1 : 0;
+}
+
+// Is this wrapper state one FlowTick and the tick kernel may run on (WebRtcAecmSessions_ImportSession)?  Everything they
+// turn into a loop count, a lane count or a 4-bit field of the plan: the pending frame-stream samples (< one block: the block
+// loop of a frame and the plan's left_count), the jitter buffer's fill, the output ring's fill, the flags.  Positions
+// themselves are free-running counters: any value is a position.  Returns 0 or the 1-based index of the offending field.
+AECM_FLOW_HD int FlowStateDefect(const int32_t v[kFlowWords]) {
+    for (int f : {F_EC_STARTUP, F_CHECK_BUFF_SIZE, F_DELAY_CHANGE, F_FF_VALID, F_OLD_ROW0, F_OLD_ROW1})
+        if (v[f] != 0 && v[f] != 1) return f + 1;
+    if (v[F_BUF_SIZE_START] < 0 || v[F_BUF_SIZE_START] > 50) return F_BUF_SIZE_START + 1;          // BUF_SIZE_FRAMES (:29-36, :322,:332)
+    if (v[F_MS] < 0 || v[F_MS] > 510) return F_MS + 1;                                                // clamped to [0, 500], + 10 (:258-266)
+    for (int f : {F_KNOWN_DELAY, F_COUNTER, F_SUM, F_FIRST_VAL, F_CHECK_BUF_SIZE_CTR, F_FILT_DELAY, F_LAST_DELAY_DIFF})
+        if (v[f] < -32768 || v[f] > 32767) return f + 1;                                              // the reference's short members
+    const uint32_t readable = (uint32_t)v[F_FAR_WP] - (uint32_t)v[F_FAR_RP];
+    if (readable > (uint32_t)kFlowJitterCapacity) return F_FAR_RP + 1;
+    const uint32_t pending = (uint32_t)v[F_FRM_POS] - (uint32_t)v[F_BLK_POS];
+    if (pending >= (uint32_t)kFlowBlock) return F_BLK_POS + 1;
+    const uint32_t out_fill = (uint32_t)v[F_BLK_POS] - (uint32_t)v[F_OUT_RP];
+    if (out_fill > (uint32_t)(kFlowFrame + kFlowBlock)) return F_OUT_RP + 1;                          // the output frame ring holds FRAME_LEN + PART_LEN (aecm_core.cc:204-205)
+    for (int f = kFlowFieldsUsed; f < kFlowWords; ++f)
+        if (v[f] != 0) return f + 1;
+    return 0;
 }
 
 // WebRtc_MoveReadPtr of the jitter buffer (ring_buffer.c:176-211): clamped to what is readable / free.

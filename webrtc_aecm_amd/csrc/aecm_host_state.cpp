@@ -8,6 +8,7 @@
 #include <initializer_list>
 
 #include "aecm_ops.h"
+#include "aecm_state_check.h"
 #include "aecm_tables.h"
 
 namespace aecm {
@@ -68,36 +69,12 @@ void ApplyControl(int32_t *scal, int fixed_delay, int nlp_flag) {
 }
 
 const char *ValidateStateImage(const uint32_t *vec, const int32_t *scal, int fs) {
-    auto in = [&](int f, int lo, int hi) { return scal[f] >= lo && scal[f] <= hi; };
-    auto i16 = [&](int f) { return in(f, -32768, 32767); };
-    // indices, lanes, shift counts
-    if (scal[S_MULT] * 8000 != fs || (fs != 8000 && fs != 16000)) return "mult";
-    if (!in(S_HISTPOS, 0, kHistory)) return "far_history_pos";
-    if (!in(S_LAST_DELAY, -2, kHistory - 1)) return "last_delay";
-    if (!in(S_FIXED_DELAY, -32768, kHistory - 1)) return "fixedDelay";
-    if (!in(S_STARTUP, 0, 2)) return "startupState";
-    // Q domains are norms of a non-negative int16 maximum (WebRtcSpl_NormW16, spl_inl.h:108: at most 14 -- Q 15 would need
-    // a negative one); the nearFilt update's range arguments (aecm_wave.h: near_filt_update) are written for |dQ| <= 14
-    if (!in(S_DFANOISYQ, 0, 14) || !in(S_DFANOISYQ_OLD, 0, 14) || !in(S_DFACLEANQ, 0, 14) || !in(S_DFACLEANQ_OLD, 0, 14)) return "dfaQDomain";
-    // flags and small counters
-    if (!in(S_CNG, 0, 1)) return "cngMode";
-    if (!in(S_CURVAD, 0, 1) || !in(S_FIRSTVAD, 0, 1) || !in(S_FAR_INIT, 0, 1) || !in(S_NEAR_INIT, 0, 1)) return "flag";
-    if (!in(S_B64_LOWCTR, 0, 7) || !in(S_B64_HIGHCTR, 0, 7)) return "noiseEstCtr[64]";
-    // the reference's int16 members (the kernel treats their narrowing casts as the identity)
-    for (int f : {S_FARLOG, S_FE_MIN, S_FE_MAX, S_FE_MAXMIN, S_FE_VAD, S_FE_MSE, S_VADCNT, S_MSECNT, S_SUPGAIN_OLD, S_NOISECTR, S_NLP,
-                  S_SG_A, S_SG_D, S_SG_DAB, S_SG_DBD, S_B64_CHSTORED, S_B64_CHADAPT16, S_B64_NEARFILT})
-        if (!i16(f)) return "int16 member";
-    if (!in(S_SUPGAIN, 0, 32767)) return "supGain";                   // a smoothed maximum of non-negative targets (aecm_core.cc:1000-1052)
-    if (scal[S_SEED] < 0) return "seed";                               // the LCG state is 31 bits (spl.cc:129-147)
-    if (scal[S_MIN_PROB] < 0 || scal[S_LAST_PROB] < 0) return "delay probability";
-    if (scal[S_B64_NOISE] < 0) return "noiseEst[64]";
-    for (int t = 0; t < kLanes; ++t) {
-        const uint32_t w = vec[V_NEARFILT * kLanes + t];
-        if (((w >> 22) & 31u) > 14u || (t < kSecondPass && (w >> 27) > 14u)) return "far_q_domains";
-        if ((int32_t)vec[V_NOISE * kLanes + t] < 0) return "noiseEst";
-        const uint32_t m = vec[V_M01 * kLanes + t];
-        if ((m & 0xffffu) > (32u << 9) || (m >> 16) > (t < kSecondPass ? (32u << 9) : 0u)) return "mean_bit_counts";   // no slot t + 64 for t >= 36: the half stays 0
-    }
+    // the rules themselves: aecm_state_check.h (shared with the device-side validation of the bulk import)
+    for (int f = 0; f < kNumScalUsed; ++f)
+        if (const int d = ScalarFieldDefect(f, scal[f], fs)) return StateDefectName(d);
+    for (int t = 0; t < kLanes; ++t)
+        if (const int d = LaneWordsDefect(t, vec[V_NEARFILT * kLanes + t], vec[V_NOISE * kLanes + t], vec[V_M01 * kLanes + t]))
+            return StateDefectName(d);
     return nullptr;
 }
 

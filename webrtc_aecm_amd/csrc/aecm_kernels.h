@@ -41,8 +41,14 @@ int ResidentWaves(int compute_units);
 // The pipelined form of a launch the chip holds at once (aecm_block_kernels.hip): six waves per four streams, the
 // state-independent transforms of a block in waves of their own, one block ahead.  Fast variant, no clean input, every
 // stream the same number of blocks.
+// progress: PipelinedControlBytes(n_streams) of device memory owned by the engine (cleared by the launch): one word per
+// workgroup, by which the workgroups balance their progress.
 int PipelinedStreamLimit(int compute_units);
-hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, hipStream_t stream);
+size_t PipelinedControlBytes(int n_streams);
+bool PipelinedBalanceApplies(int n_streams, int n_blocks, int compute_units);     // pass progress (else null) to the launcher
+size_t PipelinedTraceOffsetBytes(int n_streams);     // diagnostics builds (-DAECM_PIPE_TRACE): where the per-wave records follow the progress words
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, uint32_t *progress,
+                                        hipStream_t stream);
 
 // Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into
 // streams [first, first + count) and clear their far-spectrum history.
@@ -57,6 +63,14 @@ struct ScalarPatch {
     int32_t field[kMaxPatchFields], value[kMaxPatchFields];
 };
 hipError_t LaunchPatchScalars(const StatePtrs &st, const ScalarPatch &patch, int first, int count, hipStream_t stream);
+
+// Bulk state snapshots of streams [first, first + count): blobs_dev = count blobs of kStateBlobBytes (aecm_state_check.h:
+// 32-byte header + lane vectors + scalars + far-spectrum history), anything the device can address.  Validate: result_dev[0]
+// (preset to 0xffffffff) becomes the index of the first blob the kernels may not run on, result_dev[1] (preset to 0) gets bit 0
+// when a blob of another sampling rate than fs_batch is among them; Scatter writes the blobs into the streams unchecked.
+hipError_t LaunchGatherStates(const StatePtrs &st, int first, int count, void *blobs_dev, hipStream_t stream);
+hipError_t LaunchValidateStates(const void *blobs_dev, int count, int fs_batch, uint32_t *result_dev, hipStream_t stream);
+hipError_t LaunchScatterStates(const StatePtrs &st, int first, int count, const void *blobs_dev, hipStream_t stream);
 
 // Session-schedule gather / scatter (aecm_session_flow.h: RecordingSchedule), all streams at once.
 //   dst[s][j] = map[j] >= 0 ? src[s*src_stride + map[j]] : 0            j in [0, n)

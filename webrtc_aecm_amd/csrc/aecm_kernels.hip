@@ -4,6 +4,7 @@
 #include <initializer_list>
 
 #include "aecm_kernel_common.h"
+#include "aecm_state_check.h"
 
 namespace aecm {
 
@@ -69,6 +70,70 @@ hipError_t LaunchPatchScalars(const StatePtrs &st, const ScalarPatch &patch, int
     if (count <= 0 || patch.n <= 0) return hipSuccess;
     const int64_t total = (int64_t)count * patch.n;
     hipLaunchKernelGGL(aecm_patch_scalars_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, st, patch, first, count);
+    return hipGetLastError();
+}
+
+// ---- bulk state snapshots (aecm_state_check.h: header + vec + scal + hist per stream) ---------------------------------
+// One workgroup per stream; a blob is kStateBlobBytes / 4 words: 8 header words, then the three regions as they lie in HBM.
+constexpr int kBlobHeaderWords = (int)(kStateHeaderBytes / 4), kBlobVecWords = (int)kVecWordsPerStream, kBlobScalWords = kNumScal,
+              kBlobHistWords = (int)(kHistWordsPerStream / 2), kBlobWords = (int)(kStateBlobBytes / 4);
+static_assert(kBlobHeaderWords + kBlobVecWords + kBlobScalWords + kBlobHistWords == kBlobWords, "blob layout");
+
+__global__ __launch_bounds__(256) void aecm_gather_states_kernel(StatePtrs st, int first, uint32_t *blobs) {
+    const int64_t s = (int64_t)first + blockIdx.x;
+    uint32_t *blob = blobs + (int64_t)blockIdx.x * kBlobWords;
+    const uint32_t *vec = st.vec + s * (int64_t)kVecWordsPerStream;
+    const uint32_t *scal = reinterpret_cast<const uint32_t *>(st.scal + s * (int64_t)kNumScal);
+    const uint32_t *hist = reinterpret_cast<const uint32_t *>(st.hist + s * (int64_t)kHistWordsPerStream);
+    if (threadIdx.x < kBlobHeaderWords) {
+        const uint32_t header[kBlobHeaderWords] = {kSnapshotMagic, kStateLayoutVersion, scal[S_MULT] * 8000u, (uint32_t)kNumVec, (uint32_t)kNumScal,
+                                                   (uint32_t)kHistory, (uint32_t)kLanes, 0u};
+        blob[threadIdx.x] = header[threadIdx.x];
+    }
+    for (int i = threadIdx.x; i < kBlobVecWords; i += 256) blob[kBlobHeaderWords + i] = vec[i];
+    if (threadIdx.x < kBlobScalWords) blob[kBlobHeaderWords + kBlobVecWords + threadIdx.x] = scal[threadIdx.x];
+    for (int i = threadIdx.x; i < kBlobHistWords; i += 256) blob[kBlobHeaderWords + kBlobVecWords + kBlobScalWords + i] = hist[i];
+}
+
+// result[0] = index of the first blob that may not be run on (atomicMin; the caller presets 0xffffffff), result[1] |= 1 when a
+// blob of another sampling rate than fs_batch is among them.  64 threads per blob: thread t checks scalar field t and lane t.
+__global__ __launch_bounds__(64) void aecm_validate_states_kernel(const uint32_t *blobs, int fs_batch, uint32_t *result) {
+    const uint32_t *blob = blobs + (int64_t)blockIdx.x * kBlobWords;
+    SnapshotHeader h;
+    h.magic = blob[0]; h.version = blob[1]; h.fs = blob[2]; h.num_vec = blob[3]; h.num_scal = blob[4]; h.history = blob[5]; h.lanes = blob[6]; h.reserved = blob[7];
+    const int t = threadIdx.x;
+    const uint32_t *vec = blob + kBlobHeaderWords, *scal = vec + kBlobVecWords;
+    int defect = SnapshotHeaderOk(h) ? 0 : 1;
+    if (!defect) defect = ScalarFieldDefect(t, (int32_t)scal[t], (int)h.fs);
+    if (!defect) defect = LaneWordsDefect(t, vec[V_NEARFILT * kLanes + t], vec[V_NOISE * kLanes + t], vec[V_M01 * kLanes + t]);
+    if (__ballot(defect != 0) != 0 && t == 0) atomicMin(result, blockIdx.x);
+    if (t == 0 && !defect && (int)h.fs != fs_batch) atomicOr(result + 1, 1u);
+}
+
+__global__ __launch_bounds__(256) void aecm_scatter_states_kernel(StatePtrs st, int first, const uint32_t *blobs) {
+    const int64_t s = (int64_t)first + blockIdx.x;
+    const uint32_t *blob = blobs + (int64_t)blockIdx.x * kBlobWords + kBlobHeaderWords;
+    uint32_t *vec = st.vec + s * (int64_t)kVecWordsPerStream;
+    uint32_t *scal = reinterpret_cast<uint32_t *>(st.scal + s * (int64_t)kNumScal);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(st.hist + s * (int64_t)kHistWordsPerStream);
+    for (int i = threadIdx.x; i < kBlobVecWords; i += 256) vec[i] = blob[i];
+    if (threadIdx.x < kBlobScalWords) scal[threadIdx.x] = blob[kBlobVecWords + threadIdx.x];
+    for (int i = threadIdx.x; i < kBlobHistWords; i += 256) hist[i] = blob[kBlobVecWords + kBlobScalWords + i];
+}
+
+hipError_t LaunchGatherStates(const StatePtrs &st, int first, int count, void *blobs_dev, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_gather_states_kernel, dim3(count), dim3(256), 0, stream, st, first, static_cast<uint32_t *>(blobs_dev));
+    return hipGetLastError();
+}
+hipError_t LaunchValidateStates(const void *blobs_dev, int count, int fs_batch, uint32_t *result_dev, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_validate_states_kernel, dim3(count), dim3(64), 0, stream, static_cast<const uint32_t *>(blobs_dev), fs_batch, result_dev);
+    return hipGetLastError();
+}
+hipError_t LaunchScatterStates(const StatePtrs &st, int first, int count, const void *blobs_dev, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_scatter_states_kernel, dim3(count), dim3(256), 0, stream, st, first, static_cast<const uint32_t *>(blobs_dev));
     return hipGetLastError();
 }
 

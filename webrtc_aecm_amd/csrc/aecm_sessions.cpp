@@ -4,8 +4,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "../../include/echo_control_mobile.h"
+#include "aecm_state_check.h"
 
 namespace aecm {
 
@@ -273,6 +275,99 @@ int32_t SessionBatch::TickAsync(const int16_t *far, const int16_t *near, const i
                                 size_t n_samples, int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session,
                                 int32_t *codes, void *wait_event, void *done_event) {
     return Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, false, wait_event, done_event);
+}
+
+// ---- session snapshots ---------------------------------------------------------------------------------
+namespace {
+struct SessionSnapshotHeader {
+    uint32_t magic, version, fs, has_clean, flow_words, far_ring, out_tail, near_tail;
+};
+constexpr uint32_t kSessionMagic = 0x4e534541u;       // "AESN"
+constexpr uint32_t kSessionVersion = 1;               // bump with aecm_flow_plan.h's field list or the layout below
+static_assert(sizeof(SessionSnapshotHeader) == SessionBatch::kSessionHeaderBytes, "session snapshot header");
+struct SessionOffsets {                                // byte offsets of the parts behind the header
+    size_t state = SessionBatch::kSessionHeaderBytes, flow = state + BatchEngine::kStateBytes, far = flow + kFlowWords * 4,
+           out = far + kFlowFarRing * 2, near = out + SessionBatch::kOutTail * 2, clean = near + SessionBatch::kNearTail * 2,
+           frames = clean + SessionBatch::kNearTail * 2, old = frames + kFlowFarFrameRing * 2, end = old + 2 * kFlowFrame * 2;
+};
+static_assert(SessionOffsets().end == SessionBatch::kSessionBytes, "session snapshot size");
+}  // namespace
+
+int32_t SessionBatch::ExportSession(int session, void *buf) {
+    if (buf == nullptr) return AECM_NULL_POINTER_ERROR;
+    if (int32_t rc = CheckSession(session)) return rc;
+    if (!AECM_HIP_OK(hipSetDevice(device_)) || !engine_->Synchronize()) return Fail();
+    const int S = engine_->num_streams();
+    const SessionOffsets at;
+    uint8_t *p = static_cast<uint8_t *>(buf);
+    const SessionSnapshotHeader h{kSessionMagic, kSessionVersion, (uint32_t)fs_, clean_ring_ ? 1u : 0u, (uint32_t)kFlowWords, (uint32_t)kRing,
+                                  (uint32_t)kOutTail, (uint32_t)kNearTail};
+    memcpy(p, &h, sizeof h);
+    if (!engine_->ExportState(session, p + at.state)) return Fail();
+    int32_t flow[kFlowWords] = {0};
+    std::vector<int16_t> row(kRing);
+    auto tail = [&](const int16_t *ring_row, uint32_t end_pos, int n, uint8_t *dst) -> bool {      // ring positions [end_pos - n, end_pos)
+        if (!AECM_HIP_OK(hipMemcpy(row.data(), ring_row, kRing * 2, hipMemcpyDeviceToHost))) return false;
+        int16_t *d = reinterpret_cast<int16_t *>(dst);
+        for (int k = 0; k < n; ++k) d[k] = row[(end_pos - (uint32_t)n + (uint32_t)k) & (uint32_t)(kRing - 1)];
+        return true;
+    };
+    bool ok = AECM_HIP_OK(hipMemcpy2D(flow, sizeof(int32_t), flow_state_ + session, (size_t)S * sizeof(int32_t), sizeof(int32_t), kFlowFieldsUsed,
+                                      hipMemcpyDeviceToHost));
+    memcpy(p + at.flow, flow, sizeof flow);
+    ok = ok && AECM_HIP_OK(hipMemcpy(p + at.far, far_ring_ + (size_t)session * kRing, kRing * 2, hipMemcpyDeviceToHost)) &&
+         tail(out_ring_ + (size_t)session * kRing, (uint32_t)flow[F_BLK_POS], kOutTail, p + at.out) &&
+         tail(near_ring_ + (size_t)session * kRing, (uint32_t)near_pos_, kNearTail, p + at.near);
+    if (ok && clean_ring_) ok = tail(clean_ring_ + (size_t)session * kRing, (uint32_t)near_pos_, kNearTail, p + at.clean);
+    else memset(p + at.clean, 0, kNearTail * 2);
+    ok = ok && AECM_HIP_OK(hipMemcpy(p + at.frames, far_frames_ + (size_t)session * kFlowFarFrameRing, kFlowFarFrameRing * 2, hipMemcpyDeviceToHost)) &&
+         AECM_HIP_OK(hipMemcpy(p + at.old, far_old_ + (size_t)session * 2 * kFlowFrame, 2 * kFlowFrame * 2, hipMemcpyDeviceToHost));
+    return ok ? 0 : Fail();
+}
+
+int32_t SessionBatch::ImportSession(int session, const void *buf) {
+    if (buf == nullptr) return AECM_NULL_POINTER_ERROR;
+    if (int32_t rc = CheckSession(session)) return rc;
+    const SessionOffsets at;
+    const uint8_t *p = static_cast<const uint8_t *>(buf);
+    SessionSnapshotHeader h;
+    memcpy(&h, p, sizeof h);
+    if (h.magic != kSessionMagic || h.version != kSessionVersion || h.fs != (uint32_t)fs_ || h.has_clean > 1u || h.flow_words != (uint32_t)kFlowWords ||
+        h.far_ring != (uint32_t)kRing || h.out_tail != (uint32_t)kOutTail || h.near_tail != (uint32_t)kNearTail)
+        return AECM_BAD_PARAMETER_ERROR;
+    int32_t flow[kFlowWords];
+    memcpy(flow, p + at.flow, sizeof flow);
+    if (FlowStateDefect(flow) != 0) return AECM_BAD_PARAMETER_ERROR;
+    SnapshotHeader core;                                     // the core state must be of the session's rate
+    memcpy(&core, p + at.state, sizeof core);
+    if (!SnapshotHeaderOk(core) || core.fs != h.fs) return AECM_BAD_PARAMETER_ERROR;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
+    const int S = engine_->num_streams();
+    hipStream_t st = engine_->stream();
+    if (h.has_clean && !clean_ring_) {                      // as the first tick that carries a clean near end would
+        const size_t bytes = (size_t)S * kRing * 2;
+        if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st))) return AECM_UNSPECIFIED_ERROR;
+    }
+    // the block-stream blob last among the checks (ImportState validates it and is the first thing that writes), first among the writes
+    if (const int32_t rc = engine_->ImportState(session, p + at.state)) return rc;
+    std::vector<int16_t> row(kRing, 0);
+    auto place_tail = [&](int16_t *ring_row, uint32_t end_pos, int n, const uint8_t *src, bool zero_rest) -> bool {
+        if (!zero_rest && !AECM_HIP_OK(hipMemcpy(row.data(), ring_row, kRing * 2, hipMemcpyDeviceToHost))) return false;
+        if (zero_rest) std::fill(row.begin(), row.end(), (int16_t)0);
+        const int16_t *s = reinterpret_cast<const int16_t *>(src);
+        for (int k = 0; k < n; ++k) row[(end_pos - (uint32_t)n + (uint32_t)k) & (uint32_t)(kRing - 1)] = s[k];
+        return AECM_HIP_OK(hipMemcpy(ring_row, row.data(), kRing * 2, hipMemcpyHostToDevice));
+    };
+    bool ok = AECM_HIP_OK(hipStreamSynchronize(st)) &&
+              AECM_HIP_OK(hipMemcpy2D(flow_state_ + session, (size_t)S * sizeof(int32_t), flow, sizeof(int32_t), sizeof(int32_t), kFlowFieldsUsed,
+                                      hipMemcpyHostToDevice)) &&
+              AECM_HIP_OK(hipMemcpy(far_ring_ + (size_t)session * kRing, p + at.far, kRing * 2, hipMemcpyHostToDevice)) &&
+              place_tail(out_ring_ + (size_t)session * kRing, (uint32_t)flow[F_BLK_POS], kOutTail, p + at.out, true) &&
+              place_tail(near_ring_ + (size_t)session * kRing, (uint32_t)near_pos_, kNearTail, p + at.near, false);
+    if (ok && clean_ring_) ok = place_tail(clean_ring_ + (size_t)session * kRing, (uint32_t)near_pos_, kNearTail, p + at.clean, false);
+    ok = ok && AECM_HIP_OK(hipMemcpy(far_frames_ + (size_t)session * kFlowFarFrameRing, p + at.frames, kFlowFarFrameRing * 2, hipMemcpyHostToDevice)) &&
+         AECM_HIP_OK(hipMemcpy(far_old_ + (size_t)session * 2 * kFlowFrame, p + at.old, 2 * kFlowFrame * 2, hipMemcpyHostToDevice));
+    return ok ? 0 : Fail();           // a session half written is not a session: the object is poisoned
 }
 
 int32_t SessionBatch::Synchronize() {

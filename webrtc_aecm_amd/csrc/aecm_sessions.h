@@ -58,6 +58,25 @@ public:
     int32_t Synchronize();
     static constexpr uint8_t kNoFarend = kFlowNoFarend, kSplitCalls = kFlowSplitCalls;
 
+    // Snapshot of ONE live session (checkpoint; migration into another object, on another GPU): everything the reference
+    // keeps per instance -- AecMobile's wrapper members and jitter buffer (echo_control_mobile.cc:42-79), the core's frame
+    // buffers (aecm_core.h:41-60) and the core state proper (the block stream's snapshot, aecm_engine.h) -- in a form that
+    // does not depend on the object it came from:
+    //   header (32 B) | block-stream blob (BatchEngine::kStateBytes) | wrapper state kFlowWords int32 | far ring kRing int16
+    //   (indexed by the session's own far-stream positions) | the last kOutTail block-output samples before F_BLK_POS |
+    //   the last kNearTail near-end (and clean near-end) samples ticked (the only ones a later block can still ask for:
+    //   fewer than one block is ever pending) | framed-far ring | the two replay rows.
+    // The near-end rings are indexed by the OBJECT's tick position, so their tails are re-placed at the importing object's.
+    // ImportSession validates everything FlowTick / the tick kernel turn into a count or an index (aecm_flow_plan.h:
+    // FlowStateDefect) and the block-stream blob like ImportState does; a refused blob changes nothing.  The session's rate
+    // must be the object's.  Both calls wait for the ticks enqueued so far.
+    static constexpr int kOutTail = 256, kNearTail = 64;
+    static constexpr size_t kSessionHeaderBytes = 32;
+    static constexpr size_t kSessionBytes = kSessionHeaderBytes + BatchEngine::kStateBytes + kFlowWords * 4 + kFlowFarRing * 2 + kOutTail * 2 +
+                                            2 * kNearTail * 2 + kFlowFarFrameRing * 2 + 2 * kFlowFrame * 2;
+    int32_t ExportSession(int session, void *buf);
+    int32_t ImportSession(int session, const void *buf);
+
 private:
     SessionBatch() {}
     int32_t CheckSession(int session) const;

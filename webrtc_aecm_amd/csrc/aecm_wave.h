@@ -128,6 +128,9 @@ struct Uniform {
     // instead of a move + a whole-wave shift.  Entry k (0 = newest) is lane (log_pos + k) mod 20; load_state starts at 0
     // and store_state writes the canonical order back.
     int log_pos;
+    // Not persistent: set by kernels whose policy lowers the issue priority of a wave that has run ahead of the launch's
+    // other waves (wave_gfx950.h: kDynamicPrio; aecm_block_kernels.hip: the pipelined kernel).  0 everywhere else.
+    int prio_drop = 0;
 };
 
 template <class W, bool kHasClean>
@@ -1162,7 +1165,7 @@ struct BlockEngine {
     static AECM_HD void front_block(const Regs &r, vi x_old, vi far_new, vi d_old, vi near_new, vi c_old, vi clean_new,
                                     Spectrum &xf, Spectrum &df, Spectrum &cf) {
         AECM_PHASE_MARK(0, far_new, near_new);
-        W::template phase_priority<1>();
+        W::template phase_priority<1>(r.u.prio_drop);
         {
             constexpr int kSignals = kHasClean ? 3 : 2;
             int max_abs[3], q[3] = {0, 0, 0};
@@ -1178,7 +1181,7 @@ struct BlockEngine {
             fft128<false, true, kSignals, 1>(fa, fb, r.k_p);
             spectrum(r, fa[0], fb[0], q[0], xf);
             AECM_PHASE_MARK(1, xf.mag, xf.re);
-            W::template phase_priority<2>();
+            W::template phase_priority<2>(r.u.prio_drop);
             spectrum(r, fa[1], fb[1], q[1], df);
             if (kHasClean) spectrum(r, fa[kSignals - 1], fb[kSignals - 1], q[2], cf);
         }
@@ -1200,7 +1203,7 @@ struct BlockEngine {
     // Of xf only mag / mag64 / q are read; cf only with a clean input.
     static AECM_HD vi back_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, const Spectrum &cf) {
         Uniform &u = r.u;
-        W::template phase_priority<3>();
+        W::template phase_priority<3>(r.u.prio_drop);
         u.dfa_noisy_q_old = u.dfa_noisy_q;
         u.dfa_noisy_q = df.q;
         if (kHasClean) {                                                              // :449-464
@@ -1232,14 +1235,14 @@ struct BlockEngine {
             r.bh1 = W::shift_up1(r.bh1, carry);
         }
         AECM_PHASE_MARK(3, r.bh0, r.mean);
-        W::template phase_priority<4>();
+        W::template phase_priority<4>(r.u.prio_drop);
         // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
         int delay = process_binary(r, near_word);
         if (delay == -2) delay = 0;                                                   // :479-483
         if (W::per_block(u.fixed_delay) >= 0) delay = u.fixed_delay;                  // :485-488
 
         AECM_PHASE_MARK(4, r.m01, r.mean);
-        W::template phase_priority<5>();
+        W::template phase_priority<5>(r.u.prio_drop);
         // AlignedFarend (aecm_core.cc:157-172)
         int pos = u.hist_pos - delay;
         if (pos < 0) pos += kHistory;
@@ -1252,15 +1255,15 @@ struct BlockEngine {
         vi echo_est;
         int echo_est64;
         AECM_PHASE_MARK(5, far, r.m01);
-        W::template phase_priority<6>();
+        W::template phase_priority<6>(r.u.prio_drop);
         calc_energies(r, far, far64, far_q, df.mag, df.mag64, echo_est, echo_est64);  // :498
         const int mu = calc_step_size(u);                                             // :503
         u.tot_count = add(u.tot_count, 1);                                            // :506
         AECM_PHASE_MARK(6, echo_est, r.near_log);
-        W::template phase_priority<7>();
+        W::template phase_priority<7>(r.u.prio_drop);
         update_channel(r, far, far64, far_q, df.mag, df.mag64, mu, echo_est, echo_est64);   // :511
         AECM_PHASE_MARK(7, r.b.ch_adapt32, echo_est);
-        W::template phase_priority<8>();
+        W::template phase_priority<8>(r.u.prio_drop);
         const int sup_gain = calc_suppression_gain(r);                                // :514
 
         vi e_re, e_im;
@@ -1295,7 +1298,7 @@ struct BlockEngine {
         const int num_pos = (int)__builtin_popcountll(W::ballot(hnl != 0)) + (hnl64 != 0 ? 1 : 0);   // :612-614
 
         AECM_PHASE_MARK(8, hnl, r.b.near_filt);
-        W::template phase_priority<9>();
+        W::template phase_priority<9>(r.u.prio_drop);
         if (AECM_STEADY_ALWAYS(W::per_block(u.mult) == 2)) {                          // :618-648
             hnl = as_i16(sar(mul24(hnl, hnl), 14));
             hnl64 = sext16(sar(mul(hnl64, hnl64), 14));
@@ -1320,13 +1323,13 @@ struct BlockEngine {
         e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
 
         AECM_PHASE_MARK(9, e_re, e_im);
-        W::template phase_priority<10>();
+        W::template phase_priority<10>(r.u.prio_drop);
         if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1))                             // :702-705
             comfort_noise<false>(r, clean, hnl, hnl64, e_re, e_im, e_re64, e_im64);
         }
 
         AECM_PHASE_MARK(10, e_re, e_im);
-        W::template phase_priority<11>();
+        W::template phase_priority<11>(r.u.prio_drop);
         // InverseFFTAndWindow (:193-246) + RealInverseFFT (real_fft.c:74-102):
         // Y[c] = (re[c], -im[c]) for c <= 64, conj-symmetric extension for c > 64 (T7).
         vi y = pack(e_re, sext16(neg(e_im)));
@@ -1336,7 +1339,7 @@ struct BlockEngine {
         vi b = sel(r.lane == 0, vi(y64), mirrored);
         const int out_cfft = fft128<true, false>(a, b, r.k_p);
         AECM_PHASE_MARK(11, a, b);
-        W::template phase_priority<12>();
+        W::template phase_priority<12>(r.u.prio_drop);
         const int sh = out_cfft - u.dfa_clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b): real parts only, in the UPPER halves (fft_stage_generic: last_real)
         vi first = as_i16(sar(mad16_hi_uc(a, lane_const<LC_HANN_SYN_LO>(r), 8192), 14));                // :219-221
@@ -1344,7 +1347,7 @@ struct BlockEngine {
         vi second = sar(mad16_hi_uc(b, lane_const<LC_HANN_SYN_HI>(r), 0), 14);                          // :229-234
         r.out_ovl = sat16(shift_i31(second, vi(sh)));
         AECM_PHASE_MARK(12, out, r.out_ovl);
-        W::template phase_priority<13>();
+        W::template phase_priority<13>(r.u.prio_drop);
         return out;
     }
 

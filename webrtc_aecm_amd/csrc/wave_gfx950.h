@@ -95,7 +95,13 @@ extern "C" __device__ int aecm_llvm_amdgcn_writelane(int value, int lane, int ol
 // launch (the chunk-queue kernel, aecm_block_kernels.hip): every access to it is a relaxed agent-scope atomic -- on gfx950
 // a plain global_load / global_store with the sc1 bit, which is served at the level all eight XCDs share instead of the
 // CU's L1 or the XCD's L2 -- and the scalars travel as one lane vector instead of through the (non-coherent) scalar cache.
-template <bool kFast, bool kPhasePrio = true, bool kTightRegisters = false, bool kCoherentState = false>
+// kDynamicPrio: the phase priorities can be lowered at run time (phase_priority's `drop`): the pipelined kernel demotes the
+// waves of a workgroup that has run ahead of the launch's slowest one (aecm_block_kernels.hip), so that the SIMD's arbiter --
+// highest priority first, then the OLDEST wave -- stops compounding the head start of the workgroups dispatched first.
+#ifndef AECM_PRIO_DROP_LEVELS
+#define AECM_PRIO_DROP_LEVELS 3        // how far a demoted wave's phase priorities fall (3: all the way to 0)
+#endif
+template <bool kFast, bool kPhasePrio = true, bool kTightRegisters = false, bool kCoherentState = false, bool kDynamicPrio = false>
 struct Gfx950Wave {
     static constexpr bool kTight = kTightRegisters;
     static constexpr bool kCoherent = kCoherentState;
@@ -144,18 +150,30 @@ struct Gfx950Wave {
     static constexpr bool kPhasePriority = kPhasePrio;
 #endif
     // Called where phase PHASE begins (after marker PHASE - 1 ... the marker ids of aecm_wave.h).
+    template <int P>
+    static __device__ __forceinline__ void set_prio() {
+        if constexpr (P <= 0) __builtin_amdgcn_s_setprio(0);
+        else if constexpr (P == 1) __builtin_amdgcn_s_setprio(1);
+        else if constexpr (P == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+    // drop (wave-uniform, kDynamicPrio only): non-zero = this wave runs AECM_PRIO_DROP_LEVELS below the table.
     template <int PHASE>
-    static __device__ __forceinline__ void phase_priority() {
+    static __device__ __forceinline__ void phase_priority(int drop = 0) {
         if constexpr (kPhasePriority) {
             constexpr int n = (int)(sizeof(kPhasePrios) / sizeof(int)) - 1;             // entries 0 (unused) .. 13
             static_assert(n == 14 && PHASE >= 1 && PHASE <= 13, "one priority per phase 1..13 (entry 0 is unused)");
             constexpr int now = kPhasePrios[PHASE];
             constexpr int before = PHASE == 1 ? kPhasePrios[n - 1] : kPhasePrios[PHASE - 1];   // phase 13 of the block before; begin_stream() makes that true of the first block too
             if constexpr (now != before) {
-                if constexpr (now == 0) __builtin_amdgcn_s_setprio(0);
-                else if constexpr (now == 1) __builtin_amdgcn_s_setprio(1);
-                else if constexpr (now == 2) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(3);
+                if constexpr (kDynamicPrio) {
+                    // set at every change of the table, demoted or not: the flag may have changed since the block before
+                    constexpr int low = now > AECM_PRIO_DROP_LEVELS ? now - AECM_PRIO_DROP_LEVELS : 0;
+                    if (drop != 0) set_prio<low>();
+                    else set_prio<now>();
+                } else {
+                    set_prio<now>();
+                }
             }
         }
     }

@@ -39,7 +39,8 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_Synchronize", "WebRtcAecmBatch_GetLastLaunchMs",
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
-    "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_SetLaunchPipelining", "WebRtcAecmBatch_DescribeLaunch",
+    "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_ExportStates", "WebRtcAecmBatch_ImportStates", "WebRtcAecmBatch_ExportStatesDevice",
+    "WebRtcAecmBatch_ImportStatesDevice", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_SetLaunchPipelining", "WebRtcAecmBatch_DescribeLaunch",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
     "WebRtcAecmBatch_RegisterHostBuffer", "WebRtcAecmBatch_UnregisterHostBuffer",
 ]
@@ -49,7 +50,8 @@ SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_TickPerSessionHost", "WebRtcAecmSessions_TickFlags", "WebRtcAecmSessions_TickFlagsHost",
     "WebRtcAecmSessions_InitSession", "WebRtcAecmSessions_set_config_session", "WebRtcAecmSessions_InitEchoPath",
     "WebRtcAecmSessions_GetEchoPath", "WebRtcAecmSessions_TickAsync", "WebRtcAecmSessions_Synchronize",
-    "WebRtcAecmSessions_SetKernelVariant",
+    "WebRtcAecmSessions_SetKernelVariant", "WebRtcAecmSessions_session_size_bytes", "WebRtcAecmSessions_ExportSession",
+    "WebRtcAecmSessions_ImportSession",
 ]
 SESSION_NO_FAREND = 1
 SESSION_SPLIT_CALLS = 2
@@ -117,6 +119,11 @@ def load():
     lib.WebRtcAecmBatch_ExportState.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmBatch_ImportState.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmBatch_GetDigest.argtypes = [vp, C.c_int32, vp]
+    for name in ("ExportStates", "ImportStates", "ExportStatesDevice", "ImportStatesDevice"):
+        getattr(lib, "WebRtcAecmBatch_" + name).argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmSessions_session_size_bytes.restype = C.c_size_t
+    lib.WebRtcAecmSessions_ExportSession.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.WebRtcAecmSessions_ImportSession.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmBatch_SetKernelVariant.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmBatch_SetLaunchChunking.argtypes = [vp, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DescribeLaunch.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
@@ -347,6 +354,25 @@ class AecmBatch:
     def import_state(self, stream: int, state: bytes):
         self._check(self.lib.WebRtcAecmBatch_ImportState(self.h, stream, state, len(state)), "ImportState")
 
+    def export_states(self, first: int, count: int) -> np.ndarray:
+        """Snapshots of streams [first, first + count) as a [count, state_size] uint8 array (one gather launch + chunked copies)."""
+        n = self.lib.WebRtcAecmBatch_state_size_bytes()
+        buf = np.empty((count, n), dtype=np.uint8)
+        self._check(self.lib.WebRtcAecmBatch_ExportStates(self.h, first, count, buf.ctypes.data, buf.nbytes), "ExportStates")
+        return buf
+
+    def import_states(self, first: int, states: np.ndarray):
+        states = np.ascontiguousarray(states, dtype=np.uint8)
+        self._check(self.lib.WebRtcAecmBatch_ImportStates(self.h, first, states.shape[0], states.ctypes.data, states.nbytes), "ImportStates")
+
+    def export_states_device(self, first: int, count: int, dev_ptr: int):
+        n = self.lib.WebRtcAecmBatch_state_size_bytes()
+        self._check(self.lib.WebRtcAecmBatch_ExportStatesDevice(self.h, first, count, dev_ptr, count * n), "ExportStatesDevice")
+
+    def import_states_device(self, first: int, count: int, dev_ptr: int):
+        n = self.lib.WebRtcAecmBatch_state_size_bytes()
+        self._check(self.lib.WebRtcAecmBatch_ImportStatesDevice(self.h, first, count, dev_ptr, count * n), "ImportStatesDevice")
+
     def init_echo_path(self, stream, path):
         a, p = _i16(path)
         self._check(self.lib.WebRtcAecmBatch_InitEchoPath(self.h, stream, p, a.nbytes), "InitEchoPath")
@@ -446,6 +472,15 @@ class AecmSessions:
         out = np.zeros(BINS, dtype=np.int16)
         rc = self.lib.WebRtcAecmSessions_GetEchoPath(self.h, session, out.ctypes.data, out.nbytes)
         return rc, out
+
+    def export_session(self, session: int):
+        """(code, snapshot bytes) of one live session (include/aecm_batch.h: WebRtcAecmSessions_ExportSession)."""
+        buf = C.create_string_buffer(self.lib.WebRtcAecmSessions_session_size_bytes())
+        rc = self.lib.WebRtcAecmSessions_ExportSession(self.h, session, buf, len(buf))
+        return rc, buf.raw
+
+    def import_session(self, session: int, snapshot: bytes) -> int:
+        return self.lib.WebRtcAecmSessions_ImportSession(self.h, session, snapshot, len(snapshot))
 
     def tick_device_per_session(self, far_ptr, near_ptr, out_ptr, stream_stride, n, ms_per_session, clean_ptr=None):
         ms = np.ascontiguousarray(ms_per_session, dtype=np.int16)
