@@ -374,7 +374,7 @@ def main():
         from webrtc_aecm_amd import isa_census
         form, chunk = batch.describe_launch(C, bool(args.clean))              # which block kernel a launch of this shape takes
         if args.variant == "fast":
-            kernel_substr, kernel_name = isa_census.BLOCK_KERNELS[(form, bool(args.clean))]
+            kernel_substr, kernel_name = isa_census.block_kernel(form, bool(args.clean), chunk)
             traffic, issue = load_profile_record(aecm.library_path(), workload_key, kernel_substr)
         else:
             kernel_name, traffic, issue = f"aecm_process_kernel<safe,{'clean' if args.clean else 'noclean'}>", None, None
@@ -391,7 +391,7 @@ def main():
             "config": {"workload": workload_name(S, T, args.fs, world, args.clean) + ("" if args.profile == "recipe" else f", content profile {args.profile}"),
                        "content_profile": args.profile,
                        "streams_per_gpu": S, "blocks_per_step": T, "launches_per_step": len(chunks), "launch_form": form,
-                       "launch_chunk_blocks": chunk, "fs": args.fs, "kernel_variant": args.variant,
+                       "launch_chunk_blocks": chunk if form == 2 else 0, "pipelined_tail_waves": (chunk & 0xff) if form == 3 else None, "fs": args.fs, "kernel_variant": args.variant,
                        "sharding": f"static, {world} x {S} independent streams, no data-path collective",
                        "timed_region_s": c["seconds"], "commit": commit},
             "device": dict(zip(("name", "compute_units", "clock_khz"), aecm.device_info(local_rank))),
@@ -405,7 +405,9 @@ def main():
                          "kernel": kernel_name,
                          "launch_form": {0: "one wavefront per stream (launch resident at once)", 1: "one wavefront per stream",
                                          2: f"chunk queue: items of {chunk} blocks claimed in order by resident wavefronts",
-                                         3: "pipelined: six wavefronts per four streams, the transforms one block ahead in wavefronts of their own"}[form],
+                                         3: f"pipelined: {6 + (chunk & 0xff)} wavefronts per four streams, the forward transforms one block ahead in wavefronts of their own"
+                                            + (f", the inverse transforms one block behind in {chunk & 0xff} more" if chunk & 0xff else "")
+                                            + (", front-wave priorities balanced by progress feedback" if chunk & 0x100 else "")}[form],
                          "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_frame": algo_bytes,
                          "algorithmic_bytes_per_launch": algo_bytes * S * T,
                          "note": "instruction-issue-bound integer kernel (SURVEY.md 8.d): 384 B/frame cannot approach the HBM peak; "

@@ -780,12 +780,15 @@ def test_chunk_queue_half_a_million_hand_overs():
 
 def test_launch_form_by_size():
     """Which kernel a launch takes (WebRtcAecmBatch_DescribeLaunch; INTEGRATION.md has the table): one stream -> one wavefront
-    per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant); more -> chunk queue if
+    per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant; with two tail waves per
+    workgroup up to 3 x 4 x CUs streams, above that without them and -- in launches long enough -- balanced); more -> chunk queue if
     the launch is at least two chunks long (chunks of 32 blocks up to the chip's resident waves, of 128 above), else one
     wavefront per stream."""
     cus = aecm.device_info(0)[1]
     pipe_max, resident, rotation = cus * 16, cus * 28, cus * 24
-    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 0), (pipe_max, 3, False, 3, 0), (pipe_max, 300, True, 0, 0),
+    tail_max = cus * 12                       # eight-wave workgroups (two tail waves) come three to a CU
+    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 2), (tail_max, 300, False, 3, 2), (tail_max + 1, 300, False, 3, 0x100),
+                                          (pipe_max, 3, False, 3, 0), (pipe_max, 300, False, 3, 0x100), (pipe_max, 300, True, 0, 0),
                                           (pipe_max + 1, 300, False, 2, 32), (pipe_max + 1, 63, False, 0, 0), (rotation + 1, 63, False, 1, 0),
                                           (resident, 64, True, 2, 32), (resident + 1, 255, False, 1, 0), (resident + 1, 256, False, 2, 128),
                                           (resident + 1, 256, True, 2, 128)):

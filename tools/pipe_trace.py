@@ -36,27 +36,32 @@ def main():
     out = torch.empty_like(near)
     b = aecm.AecmBatch(S, a.fs, cng_mode=1, echo_mode=1)
     assert b.describe_launch(T)[0] == 3, "not a pipelined launch"
+    tail_waves = b.describe_launch(T)[1] & 0xff
     torch.cuda.synchronize()
     for _ in range(2):                       # the second launch (steady state of the signal's second pass) is the one recorded
         b.process_device(far.data_ptr(), near.data_ptr(), out.data_ptr(), T * 64, 64, T)
         b.synchronize()
     ms = b.last_launch_ms()
-    rec = np.fromfile(trace, dtype=np.uint64).reshape(-1, 6, 4).astype(np.int64)       # [workgroup][wave][t0, t1, wait, total]
+    rec = np.fromfile(trace, dtype=np.uint64).reshape(-1, 8, 4).astype(np.int64)       # [workgroup][wave][t0, t1, wait, total]; waves a workgroup does not have read 0
     n_wg = (S + 3) // 4
     rec = rec[:n_wg]
+    n_waves = int((rec[0, :, 3] > 0).sum())
+    rec = rec[:, :n_waves]
     t0 = rec[:, :, 0].min()
     start = (rec[:, :, 0].min(axis=1) - t0) / 100.0          # us
     end = (rec[:, :, 1].max(axis=1) - t0) / 100.0
     wait_frac = rec[:, :, 2] / np.maximum(rec[:, :, 3], 1)
     q = lambda x: [round(float(v), 1) for v in np.percentile(x, [0, 10, 50, 90, 100])]
     res = {
-        "streams": S, "blocks": T, "kernel_ms": ms, "workgroups": int(n_wg),
+        "streams": S, "blocks": T, "tail_waves": tail_waves, "kernel_ms": ms, "workgroups": int(n_wg),
         "start_us_pctl_0_10_50_90_100": q(start), "end_us_pctl_0_10_50_90_100": q(end),
         "mean_end_over_last_end": round(float(end.mean() / end.max()), 4),
         "barrier_wait_fraction_back_waves_mean": round(float(wait_frac[:, :4].mean()), 4),
-        "barrier_wait_fraction_front_waves_mean": round(float(wait_frac[:, 4:].mean()), 4),
+        "waves_per_workgroup": n_waves,
+        "barrier_wait_fraction_front_waves_mean": round(float(wait_frac[:, 4:6].mean()), 4),
+        "barrier_wait_fraction_tail_waves_mean": round(float(wait_frac[:, 6:].mean()), 4) if n_waves > 6 else None,
         "barrier_wait_fraction_back_pctl": [round(float(v), 3) for v in np.percentile(wait_frac[:, :4], [0, 10, 50, 90, 100])],
-        "barrier_wait_fraction_front_pctl": [round(float(v), 3) for v in np.percentile(wait_frac[:, 4:], [0, 10, 50, 90, 100])],
+        "barrier_wait_fraction_front_pctl": [round(float(v), 3) for v in np.percentile(wait_frac[:, 4:6], [0, 10, 50, 90, 100])],
         # do the workgroups that finish early share something?  finish time by dispatch order (blockIdx) in eight bands
         "end_us_by_blockidx_octile": [round(float(v), 1) for v in end.reshape(-1)[: n_wg // 8 * 8].reshape(8, -1).mean(axis=1)] if n_wg >= 8 else None,
         "end_us_by_blockidx_mod8": [round(float(end[k::8].mean()), 1) for k in range(8)] if n_wg >= 8 else None,

@@ -104,6 +104,21 @@ void aecm_process_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, c
 // when the grid is larger than the chip; with S >= the resident waves the wait practically never happens.  The wait is
 // bounded anyway: a wave that gives up raises *err (never cleared by a launch; the engine reports it at the next
 // synchronisation) and leaves.
+// What the hand-over rests on.  This is the write-through publish form of the platform guide (cdna_hip_programming.md section 6,
+// Guideline 16 / R1, and MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility: valid forms"):
+//   producer: every byte of the payload (state words, scalars, history rows) leaves the wave as an sc1 store -- a relaxed
+//             agent-scope __hip_atomic_store of 4 / 2 bytes per lane, the kernel's natural store width, which the guide names as
+//             the right form for such epilogues; sc1 stores are written through to memory and DROP the line from the XCD's L2 --
+//             then `asm volatile("s_waitcnt vmcnt(0)")` in the publishing wave (inline asm: the compiler cannot drop or move
+//             it), then ONE relaxed agent-scope flag store;
+//   consumer: relaxed polls of the flag, then sc1 loads of the payload ("sc1 loads may replace the acquire only when the producer
+//             stored sc1": they bypass the CU's L1 and are served where the eight XCDs agree).
+// One wave produces and one wave consumes a stream's chunk, so "every writing wave drains" is that one s_waitcnt.  No
+// buffer_wbl2 / buffer_inv anywhere: a release fence is a write-back of the XCD's whole L2 (the audio output rows of every
+// resident wave), an acquire drops the CU's L1 under three other workgroups.  Measured cost of the fenced form
+// (-DAECM_QUEUE_FENCES=1: release store / acquire poll on done[]; the same results): 65 536 streams 1 053 -> 1 030 M frames/s,
+// 8 192 streams (32-block chunks) 983 -> 899 M.  The build switch stays for a platform whose sc1 semantics differ;
+// tests/test_gpu_parity.py::test_chunk_queue_half_a_million_hand_overs and tools/soak_parity.py are the gate either way.
 #ifndef AECM_QUEUE_FENCES
 #define AECM_QUEUE_FENCES 0
 #endif
@@ -173,18 +188,34 @@ void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blo
 #ifndef AECM_PIPE_FRONT_PRIO
 #define AECM_PIPE_FRONT_PRIO 0        // the front waves' issue priority (the back waves': by phase, 1..3)
 #endif
-constexpr int kPipeStreams = 4, kPipeFrontWaves = 2, kPipeWaves = kPipeStreams + kPipeFrontWaves;
+constexpr int kPipeStreams = 4, kPipeFrontWaves = 2;
 constexpr int kPipeStreamsPerFront = kPipeStreams / kPipeFrontWaves;
+// A third role (round 5): tail_block -- inverse transform, synthesis window, overlap-add, the output store: 19 % of a block's
+// vector instructions and a long chain of LDS table reads and lane exchanges -- in kTail "tail" waves of their own, one block
+// BEHIND the middle waves (which then run middle_block only).  kTail = 1: one wave for the workgroup's four streams, seven
+// waves per workgroup = 28 per CU with four workgroups, every wave slot of the SIMDs taken; kTail = 2: two waves of two
+// streams, eight waves per workgroup, three workgroups per CU (launches of up to 3 072 streams).  The stream's sequential part
+// shrinks once more (what a small launch is bound by) and a SIMD gets one more wave of dense vector work to fill its port with.
+constexpr int PipeWaves(int tail_waves) { return kPipeStreams + kPipeFrontWaves + tail_waves; }
 struct PipeSlot {           // the spectra of one block of one stream on their way from the front to the back wave
     int near_x[kLanes];     // near-end spectrum, bins 0..63: re | im << 16 (im conjugated as the block path uses it)
     int mags[kLanes];       // far-end magnitude | near-end magnitude << 16 (both <= 46 340)
     int scalars[kLanes];    // lanes 0..4: far mag[64], far Q, near re[64], near mag[64], near Q
 };
+struct PipeTailSlot {       // the residual spectrum of one block of one stream on its way from the middle to the tail wave
+    int a[kLanes], b[kLanes];   // BlockEngine::TailInput
+    int clean_q, pad[3];
+};
+template <int kTail>
 struct PipeShared {
     PipeSlot slots[2][kPipeStreams];      // [block parity][stream of the workgroup]
+    PipeTailSlot tails[kTail ? 2 : 1][kTail ? kPipeStreams : 1];
     int ahead;                            // this workgroup leads the launch's slowest one by more than the allowed lead (balance, below)
     int level;                            // the front waves' base priority for the current group of blocks (balance modes 2, 3)
 };
+#ifndef AECM_PIPE_TAIL_PRIO
+#define AECM_PIPE_TAIL_PRIO 1         // the tail waves' issue priority
+#endif
 
 // Balance.  Every workgroup of a pipelined launch is resident from the start and has the same amount of work, but the SIMD's
 // arbiter serves the highest priority first and then its OLDEST wave: the workgroups dispatched first pull ahead, finish
@@ -240,17 +271,33 @@ __device__ __forceinline__ void SetPrioDynamic(int p) {      // s_setprio takes 
     else __builtin_amdgcn_s_setprio(3);
 }
 constexpr int kPipeGroupLog2 = AECM_PIPE_BALANCE_GROUP_LOG2, kPipeGroupMask = (1 << kPipeGroupLog2) - 1;
+constexpr int kPipeTraceWaves = 8;        // per-wave records per workgroup in the diagnostics build (the largest workgroup)
 constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of up to 1 024 workgroups (4 096 streams) are balanced, larger ones run as before
 
-// Synchronisation: ONE workgroup barrier per block.  While the back waves work on block b out of slots[b & 1], the front
-// waves write block b + 1 into slots[(b + 1) & 1]; the barrier at the end of the step makes both true for the next one.
-// Every wave of the workgroup executes 1 + n_blocks barriers whatever its role and whether or not its streams exist.
+// Synchronisation: ONE workgroup barrier per step.  In step s the front waves write the spectra of block s into slots[s & 1],
+// the middle (back) waves work on block s - 1 out of slots[(s - 1) & 1] and, with tail waves, leave its residual spectrum in
+// tails[(s - 1) & 1], which the tail waves turn into output samples in step s + 1.  Every wave of the workgroup executes
+// n_blocks + 1 + (kTail ? 1 : 0) barriers whatever its role and whether or not its streams exist (a role's idle steps are the
+// bare barriers in front of / behind its block loop).
 // (Measured against rings with per-stream counters and no barrier -- pairs of waves that only wait for each other:
 // slower, 4 096 streams 783 vs 818 M frames/s.  A wave parked at a barrier costs nothing; a wave polling a counter costs
 // issue slots, and at the priority its last phase left it with it starves the wave it is waiting for.)
-__global__ __launch_bounds__(64 * kPipeWaves)
-__attribute__((amdgpu_waves_per_eu(AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
+// Seven-wave workgroups (kTail = 1) are built for EIGHT waves per SIMD: four of them per CU are 28 waves, exactly the 4 x 7 slots
+// the usual budget leaves -- and the dispatcher does not find that exact fit (a workgroup's seven waves go 2 + 2 + 2 + 1 over the
+// SIMDs): measured, the fourth workgroup of every CU only started when the first had finished.  At 8 slots per SIMD (<= 64
+// VGPRs, which the kernel needs anyway, and <= 80 SGPRs) there is room to spare.
+#ifndef AECM_PIPE_TAIL1_WAVES_PER_EU
+#define AECM_PIPE_TAIL1_WAVES_PER_EU 8
+#endif
+// kBalance: the progress feedback of the front waves' priority (above) is compiled in; launches that do not use it (fewer than
+// four workgroups per CU) take the instantiation without it -- the same kernel with its monitor and its run-time priority
+// levels switched off at run time measured 2 % slower there.
+template <int kTail, bool kBalance>
+__global__ __launch_bounds__(64 * PipeWaves(kTail))
+__attribute__((amdgpu_waves_per_eu(kTail == 1 ? AECM_PIPE_TAIL1_WAVES_PER_EU : AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, uint32_t *progress, int n_workgroups) {
+    constexpr int kMode = kBalance ? AECM_PIPE_BALANCE : 0;               // AECM_PIPE_BALANCE's meaning, per instantiation
+    constexpr int kFrontBehind = kBalance ? AECM_PIPE_FRONT_PRIO_BEHIND : AECM_PIPE_FRONT_PRIO;
 #if defined(AECM_PIPE_TRACE)     // diagnostics build: per wave, when it started / ended (100 MHz wall clock) and how long it sat at barriers (shader clocks)
     const uint64_t trace_t0 = wall_clock64(), trace_c0 = clock64();
     uint64_t trace_wait = 0;
@@ -258,18 +305,17 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #else
 #define AECM_PIPE_BARRIER() __syncthreads()
 #endif
-    PipeShared &sh = *reinterpret_cast<PipeShared *>(&g_lds[1]);        // behind the tables
-    // (without progress words -- a launch too short or too small to balance -- the front waves run at their plain priority)
-    const int front_level0 = AECM_PIPE_BALANCE && progress != nullptr ? AECM_PIPE_FRONT_PRIO_BEHIND : AECM_PIPE_FRONT_PRIO;
-    if (AECM_PIPE_BALANCE && threadIdx.x == 0) { sh.ahead = 0; sh.level = front_level0; }
-    FillLdsTables<64 * kPipeWaves>(st.consts);                          // ends in a barrier
-    using W = Gfx950Wave<true, true, false, false, AECM_PIPE_BALANCE == 1>;
+    constexpr int kWaves = PipeWaves(kTail);
+    PipeShared<kTail> &sh = *reinterpret_cast<PipeShared<kTail> *>(&g_lds[1]);        // behind the tables
+    if (kMode != 0 && threadIdx.x == 0) { sh.ahead = 0; sh.level = kFrontBehind; }
+    FillLdsTables<64 * kWaves>(st.consts);                              // ends in a barrier
+    using W = Gfx950Wave<true, true, false, false, kMode == 1>;
     using E = BlockEngine<W, false>;
-    using EF = BlockEngine<Gfx950Wave<true, false>, false>;               // the front waves keep one priority (no per-phase s_setprio)
+    using EF = BlockEngine<Gfx950Wave<true, false>, false>;               // the front and tail waves keep one priority (no per-phase s_setprio)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t first = (int64_t)blockIdx.x * kPipeStreams;
     if (wave < kPipeStreams) {
-        // ---- back wave: one stream, everything of a block after the transforms ----
+        // ---- back (middle) wave: one stream, everything of a block after the forward transforms (and before the inverse one, with tail waves) ----
         typename E::Regs r;
         E::init_lane_constants(r, st.consts);
         const int64_t stream = first + wave;
@@ -281,11 +327,11 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
         if (live) E::load_state(r, vec, scal);
         r.u.prio_drop = 0;
         W::begin_stream();
-        AECM_PIPE_BARRIER();                                                  // the spectra of block 0 are in slots[0]
-        for (int blk = 0; blk < n_blocks; ++blk) {
-            // Balance (see above): the monitor wrote the flag at the end of its step blk, which ran next to this wave's block
-            // blk - 1 and ended in the barrier this wave has just passed.
-            if (AECM_PIPE_BALANCE == 1 && (blk & kPipeGroupMask) == 0 && blk != 0) r.u.prio_drop = __builtin_amdgcn_readfirstlane(sh.ahead);
+        AECM_PIPE_BARRIER();                                              // step 0: the spectra of block 0 are in slots[0]
+        for (int blk = 0; blk < n_blocks; ++blk) {                        // step blk + 1
+            // Balance, mode 1 (see above): the monitor wrote the flag at the end of its step blk, which ran next to this wave's
+            // block blk - 1 and ended in the barrier this wave has just passed.
+            if (kMode == 1 && (blk & kPipeGroupMask) == 0 && blk != 0) r.u.prio_drop = __builtin_amdgcn_readfirstlane(sh.ahead);
             if (live) {
                 const PipeSlot &slot = sh.slots[blk & 1][wave];
                 const int lane = W::lane_id();
@@ -304,17 +350,26 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 df.q = __builtin_amdgcn_readlane(sc, 4);
                 E::update_startup(r.u);
                 r.table_index = W::table_index_for_this_block();
-                const int out = E::back_block(r, hist, xf, df, df);
-                sio.out(r, blk, out);
+                if constexpr (kTail != 0) {
+                    const typename E::TailInput t = E::middle_block(r, hist, xf, df, df);
+                    PipeTailSlot &ts = sh.tails[blk & 1][wave];
+                    ts.a[lane] = t.a;
+                    ts.b[lane] = t.b;
+                    if (lane == 0) ts.clean_q = t.clean_q;
+                } else {
+                    const int out = E::back_block(r, hist, xf, df, df);
+                    sio.out(r, blk, out);
+                }
             }
-            AECM_PIPE_BARRIER();                                              // slots[blk & 1] are free again, block blk + 1 is in the others
+            AECM_PIPE_BARRIER();                                          // slots[blk & 1] are free again, block blk + 1 is in the others
         }
-        if (live) E::template store_state<false>(r, vec, scal);
-    } else {
+        if (kTail != 0) AECM_PIPE_BARRIER();                              // the tail waves' last step
+        if (live) E::template store_state<false, kTail == 0>(r, vec, scal);
+    } else if (wave < kPipeStreams + kPipeFrontWaves) {
         // ---- front wave: two streams, the transforms of the block after the one their back waves are at ----
         typename EF::Regs r;
         EF::init_lane_constants(r, st.consts);
-        int level = front_level0;                                         // this group's base priority (constant without balance)
+        int level = kFrontBehind;                                         // this group's base priority (constant without balance)
         SetPrioDynamic(level);
         const int k0 = (wave - kPipeStreams) * kPipeStreamsPerFront;
         int x_old[kPipeStreamsPerFront], d_old[kPipeStreamsPerFront], far_next[kPipeStreamsPerFront], near_next[kPipeStreamsPerFront];
@@ -330,11 +385,11 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 near_next[k] = sio.near(r, 0);
             }
         }
-        for (int blk = 0; blk <= n_blocks; ++blk) {                      // trip blk writes block blk (the last trip: nothing)
+        for (int blk = 0; blk <= n_blocks; ++blk) {                      // step blk writes block blk (the last step: nothing)
             // Balance: the monitor's step at a group boundary (see above).  pv[] is only ever read under the condition it is
             // loaded under (no initialisation: a register written by a move while a load of an earlier trip may still be
             // pending in the compiler's eyes costs a wait for everything in flight at the top of every trip).
-            const bool boundary = AECM_PIPE_BALANCE && progress != nullptr && (blk & kPipeGroupMask) == 0 && blk != 0;
+            const bool boundary = kMode != 0 && (blk & kPipeGroupMask) == 0 && blk != 0;
             const bool monitor = boundary && wave == kPipeStreams;
             int pv[kPipeMonitorLoads];
             if (monitor) {
@@ -359,7 +414,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 }
 #endif
             }
-            if (AECM_PIPE_BALANCE && AECM_PIPE_FRONT_PRIO_BEHIND != AECM_PIPE_FRONT_PRIO && (blk & kPipeGroupMask) == 1 && blk > kPipeGroupMask) {
+            if (kMode != 0 && kFrontBehind != AECM_PIPE_FRONT_PRIO && (blk & kPipeGroupMask) == 1 && blk > kPipeGroupMask) {
                 level = __builtin_amdgcn_readfirstlane(sh.level);
                 if (AECM_PIPE_FRONT_SECOND_BOOST == 0) SetPrioDynamic(level);
             }
@@ -367,7 +422,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #pragma unroll
                 for (int k = 0; k < kPipeStreamsPerFront; ++k) {
                     if (!live[k]) continue;
-                    if (AECM_PIPE_FRONT_SECOND_BOOST != 0) SetPrioDynamic(level + (k == 0 ? 0 : AECM_PIPE_FRONT_SECOND_BOOST));
+                    if (AECM_PIPE_FRONT_SECOND_BOOST != 0) SetPrioDynamic(level + (k == 0 ? 0 : AECM_PIPE_FRONT_SECOND_BOOST));      // folds to immediates without balance
                     const int far_cur = far_next[k], near_cur = near_next[k];
                     if (blk + 1 < n_blocks) {
                         typename EF::StridedIo sio{io, (first + k0 + k) * io.stream_stride};
@@ -414,20 +469,57 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 const int lead = AECM_PIPE_BALANCE_LEAD + 1 - (fastest - (blk >> kPipeGroupLog2));     // (> LEAD <=> less than one group behind the fastest)
                 sh.ahead = lead > AECM_PIPE_BALANCE_LEAD ? 1 : 0;
 #endif
-#if AECM_PIPE_BALANCE == 3      // proportional: one priority level per group of lead beyond the allowed one, from .._BEHIND down to AECM_PIPE_FRONT_PRIO
-                sh.level = imax(AECM_PIPE_FRONT_PRIO_BEHIND - imax(lead - AECM_PIPE_BALANCE_LEAD, 0), AECM_PIPE_FRONT_PRIO);
-#else
-                sh.level = sh.ahead ? AECM_PIPE_FRONT_PRIO : AECM_PIPE_FRONT_PRIO_BEHIND;
-#endif
+                if (kMode == 3)      // proportional: one priority level per group of lead beyond the allowed one, from .._BEHIND down to AECM_PIPE_FRONT_PRIO
+                    sh.level = imax(kFrontBehind - imax(lead - AECM_PIPE_BALANCE_LEAD, 0), AECM_PIPE_FRONT_PRIO);
+                else
+                    sh.level = sh.ahead ? AECM_PIPE_FRONT_PRIO : kFrontBehind;
             }
             AECM_PIPE_BARRIER();
         }
+        if (kTail != 0) AECM_PIPE_BARRIER();                              // the tail waves' last step
         for (int k = 0; k < kPipeStreamsPerFront; ++k)
             if (live[k]) EF::store_time_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
+    } else {
+        // ---- tail wave: kPipeStreams / kTail streams, inverse transform + synthesis + output of the block BEFORE the one the middle waves are at ----
+        constexpr int kPer = kTail ? kPipeStreams / kTail : 1;
+        typename EF::Regs r;
+        EF::init_lane_constants(r, st.consts);
+        r.u.prio_drop = 0;
+        __builtin_amdgcn_s_setprio(AECM_PIPE_TAIL_PRIO);
+        const int k0 = (wave - kPipeStreams - kPipeFrontWaves) * kPer;
+        int ovl[kPer], c_old[kPer];
+        bool live[kPer];
+        for (int k = 0; k < kPer; ++k) {
+            const int64_t stream = first + k0 + k;
+            live[k] = stream < n_streams;
+            ovl[k] = c_old[k] = 0;
+            if (live[k]) EF::load_tail_state(st.vec + stream * (int64_t)kVecWordsPerStream, r.lane, ovl[k], c_old[k]);
+        }
+        AECM_PIPE_BARRIER();                                              // steps 0 and 1: nothing to do yet
+        AECM_PIPE_BARRIER();
+        for (int blk = 0; blk < n_blocks; ++blk) {                        // step blk + 2
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                if (!live[k]) continue;
+                const PipeTailSlot &ts = sh.tails[blk & 1][k0 + k];
+                const int lane = W::lane_id();
+                const int a = ts.a[lane], b = ts.b[lane];
+                const int clean_q = __builtin_amdgcn_readfirstlane(ts.clean_q);
+                r.table_index = Gfx950Wave<true, false>::table_index_for_this_block();
+                r.out_ovl = ovl[k];
+                const int out = EF::tail_block(r, a, b, clean_q);
+                ovl[k] = r.out_ovl;
+                typename EF::StridedIo sio{io, (first + k0 + k) * io.stream_stride};
+                sio.out(r, blk, out);
+            }
+            AECM_PIPE_BARRIER();
+        }
+        for (int k = 0; k < kPer; ++k)
+            if (live[k]) EF::store_tail_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, ovl[k], c_old[k]);
     }
 #if defined(AECM_PIPE_TRACE)
     if ((threadIdx.x & 63u) == 0) {
-        uint64_t *tr = reinterpret_cast<uint64_t *>(progress + 2 * ((n_workgroups + 3) / 4) * 2) + ((size_t)blockIdx.x * kPipeWaves + wave) * 4;
+        uint64_t *tr = reinterpret_cast<uint64_t *>(progress + 2 * ((n_workgroups + 3) / 4) * 2) + ((size_t)blockIdx.x * kPipeTraceWaves + wave) * 4;
         tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = trace_wait; tr[3] = clock64() - trace_c0;
     }
 #endif
@@ -435,16 +527,21 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #undef AECM_PIPE_BARRIER
 
 // Streams a pipelined launch keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
-int PipelinedStreamLimit(int compute_units) {
-    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / kPipeWaves, by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + sizeof(PipeShared)));
-    return (compute_units > 0 ? compute_units : 256) * (by_waves < by_lds ? by_waves : by_lds) * kPipeStreams;
+template <int kTail>
+constexpr int PipeWorkgroupsPerCu() {
+    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / PipeWaves(kTail), by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + sizeof(PipeShared<kTail>)));
+    return by_waves < by_lds ? by_waves : by_lds;
+}
+int PipelinedStreamLimit(int compute_units, int tail_waves) {
+    const int per_cu = tail_waves == 0 ? PipeWorkgroupsPerCu<0>() : PipeWorkgroupsPerCu<2>();
+    return (compute_units > 0 ? compute_units : 256) * per_cu * kPipeStreams;
 }
 
 // The progress words of a pipelined launch: 16 bits per workgroup (cleared by the launch).
 size_t PipelinedControlBytes(int n_streams) {
     const size_t n_wg = (size_t)(n_streams + kPipeStreams - 1) / kPipeStreams;
 #if defined(AECM_PIPE_TRACE)
-    return 4 * ((n_wg + 3) / 4) * sizeof(uint32_t) + n_wg * kPipeWaves * 4 * sizeof(uint64_t);      // progress halves (padded), then the trace records
+    return 4 * ((n_wg + 3) / 4) * sizeof(uint32_t) + n_wg * kPipeTraceWaves * 4 * sizeof(uint64_t);      // progress halves (padded), then the trace records
 #else
     return (n_wg + 2) / 2 * sizeof(uint32_t);
 #endif
@@ -462,18 +559,26 @@ bool PipelinedBalanceApplies(int n_streams, int n_blocks, int compute_units) {
            n_wg > 3 * (compute_units > 0 ? compute_units : 256);
 }
 
-hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, uint32_t *progress,
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int tail_waves, uint32_t *progress,
                                         hipStream_t stream) {
     if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
-    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * kPipeWaves);
-    const size_t lds = sizeof(LdsTables) + sizeof(PipeShared);
-    // a launch of a few groups is over before a lead can build up: no counters, no clearing launch in front of it
+    if (tail_waves != 0 && tail_waves != 2) return hipErrorInvalidValue;
+    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * PipeWaves(tail_waves));
     // progress: null = no balance (the engine asks PipelinedBalanceApplies)
     if (progress) {
         const hipError_t e = hipMemsetAsync(progress, 0, PipelinedControlBytes(n_streams), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(aecm_process_pipelined_kernel, grid, block, lds, stream, st, io, n_streams, n_blocks, progress, (int)grid.x);
+#define AECM_LAUNCH_PIPE(T, B) hipLaunchKernelGGL((aecm_process_pipelined_kernel<T, B>), grid, block, sizeof(LdsTables) + sizeof(PipeShared<T>), stream, st, \
+                                                  io, n_streams, n_blocks, progress, (int)grid.x)
+    // The instantiations the library carries: no tail waves with and without balance (launches of four / fewer workgroups per CU),
+    // two tail waves without (eight-wave workgroups come three to a CU).  One tail wave for four streams (kTail = 1, seven-wave
+    // workgroups) measured slower than either at every size (profiles/r05_experiments.md) and is not built.
+    const bool balance = progress != nullptr && AECM_PIPE_BALANCE != 0;
+    if (tail_waves == 2) { if (balance) return hipErrorInvalidValue; AECM_LAUNCH_PIPE(2, false); }
+    else if (balance) AECM_LAUNCH_PIPE(0, true);
+    else AECM_LAUNCH_PIPE(0, false);
+#undef AECM_LAUNCH_PIPE
     return hipGetLastError();
 }
 

@@ -38,16 +38,16 @@ hipError_t LaunchProcessBlocksQueued(const StatePtrs &st, const IoView &io, int 
                                      int resident_waves, uint32_t *ctl, uint32_t *err, hipStream_t stream);
 int ResidentWaves(int compute_units);
 
-// The pipelined form of a launch the chip holds at once (aecm_block_kernels.hip): six waves per four streams, the
-// state-independent transforms of a block in waves of their own, one block ahead.  Fast variant, no clean input, every
-// stream the same number of blocks.
+// The pipelined form of a launch the chip holds at once (aecm_block_kernels.hip): six (+ tail_waves) waves per four streams, the
+// state-independent transforms of a block in waves of their own, one block ahead; with tail_waves = 1 / 2 the inverse transform
+// and synthesis too, one block behind.  Fast variant, no clean input, every stream the same number of blocks.
 // progress: PipelinedControlBytes(n_streams) of device memory owned by the engine (cleared by the launch): one word per
-// workgroup, by which the workgroups balance their progress.
-int PipelinedStreamLimit(int compute_units);
+// workgroup, by which the workgroups balance their progress; null = no balance (PipelinedBalanceApplies says when it pays).
+int PipelinedStreamLimit(int compute_units, int tail_waves);
 size_t PipelinedControlBytes(int n_streams);
-bool PipelinedBalanceApplies(int n_streams, int n_blocks, int compute_units);     // pass progress (else null) to the launcher
+bool PipelinedBalanceApplies(int n_streams, int n_blocks, int compute_units);
 size_t PipelinedTraceOffsetBytes(int n_streams);     // diagnostics builds (-DAECM_PIPE_TRACE): where the per-wave records follow the progress words
-hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, uint32_t *progress,
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int tail_waves, uint32_t *progress,
                                         hipStream_t stream);
 
 // Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into

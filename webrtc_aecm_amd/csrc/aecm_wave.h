@@ -1107,8 +1107,19 @@ struct BlockEngine {
         W::store_u32(vec + V_XD_OLD * kLanes, lane, pack(x_old, d_old));
     }
 
-    // kTimeState = false: without V_XD_OLD (a wave that only ran back_block does not have it: store_time_state)
-    template <bool kTimeState = true>
+    // The overlap buffer (and the clean input's previous block, which shares its word): the only state tail_block touches.
+    static AECM_HD void load_tail_state(const uint32_t *vec, vi lane, vi &out_ovl, vi &c_old) {
+        const vi w = W::load_u32(vec + V_OUTBUF * kLanes, lane);
+        out_ovl = lo16(w);
+        c_old = hi16(w);
+    }
+    static AECM_HD void store_tail_state(uint32_t *vec, vi lane, vi out_ovl, vi c_old) {
+        W::store_u32(vec + V_OUTBUF * kLanes, lane, pack(out_ovl, c_old));
+    }
+
+    // kTimeState = false: without V_XD_OLD (a wave that only ran back_block does not have it: store_time_state);
+    // kTailState = false: without V_OUTBUF (a wave that only ran middle_block: store_tail_state)
+    template <bool kTimeState = true, bool kTailState = true>
     static AECM_HD void store_state(const Regs &r, uint32_t *vec, int32_t *scal) {
         auto V = [&](int f, vi w) { W::store_u32(vec + f * kLanes, r.lane, w); };
         const vb second = r.lane < kSecondPass;                  // live lanes of the second-pass words
@@ -1117,7 +1128,7 @@ struct BlockEngine {
         const vi ring = (r.lane - kSecondPass) + r.u.log_pos;
         const vi down36 = sel(ring >= kLogEntries, ring - kLogEntries, ring) & 63;
         if constexpr (kTimeState) V(V_XD_OLD, pack(r.x_old, r.d_old));
-        V(V_OUTBUF, pack(r.out_ovl, r.c_old));
+        if constexpr (kTailState) V(V_OUTBUF, pack(r.out_ovl, r.c_old));
         V(V_CH16, pack(r.b.ch_stored, r.b.ch_adapt16));
         V(V_CH32, r.b.ch_adapt32);
         V(V_ECHOFILT, r.b.echo_filt);
@@ -1200,8 +1211,21 @@ struct BlockEngine {
         return out;
     }
 
+    // back_block itself is two parts again.  middle_block: delay estimator ... comfort noise, the sequential heart of a stream;
+    // it ends with the residual spectrum packed as the inverse transform's operands.  tail_block: inverse transform, synthesis
+    // window and overlap-add (:193-246) -- a function of those operands, the block's Q domain and the overlap buffer alone.
+    // The pipelined kernel can run the tails of a workgroup's streams in a wave of their own, one block behind the middles.
+    struct TailInput {
+        vi a, b;              // lane t: Y[t] and Y[64 - t] (lane 0: Y[64]), packed (re, -im)
+        int clean_q;          // dfaCleanQDomain of the block
+    };
     // Of xf only mag / mag64 / q are read; cf only with a clean input.
     static AECM_HD vi back_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, const Spectrum &cf) {
+        const TailInput t = middle_block(r, hist, xf, df, cf);
+        return tail_block(r, t.a, t.b, t.clean_q);
+    }
+
+    static AECM_HD TailInput middle_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, const Spectrum &cf) {
         Uniform &u = r.u;
         W::template phase_priority<3>(r.u.prio_drop);
         u.dfa_noisy_q_old = u.dfa_noisy_q;
@@ -1335,12 +1359,19 @@ struct BlockEngine {
         vi y = pack(e_re, sext16(neg(e_im)));
         vi mirrored = W::bpermute(pack(e_re, e_im), (vi(64) - r.lane) & 63);           // lane t <- bin 64-t
         int y64 = zext16(e_re64) | shl(sext16(neg(e_im64)), 16);
-        vi a = y;
-        vi b = sel(r.lane == 0, vi(y64), mirrored);
+        TailInput t;
+        t.a = y;
+        t.b = sel(r.lane == 0, vi(y64), mirrored);
+        t.clean_q = u.dfa_clean_q;
+        return t;
+    }
+
+    // r: the overlap buffer (out_ovl) and the lane constants (lane, table_index, k_p) are used.
+    static AECM_HD vi tail_block(Regs &r, vi a, vi b, int clean_q) {
         const int out_cfft = fft128<true, false>(a, b, r.k_p);
         AECM_PHASE_MARK(11, a, b);
         W::template phase_priority<12>(r.u.prio_drop);
-        const int sh = out_cfft - u.dfa_clean_q;
+        const int sh = out_cfft - clean_q;
         // lane t holds y[bitrev6(t)] (a) and y[bitrev6(t)+64] (b): real parts only, in the UPPER halves (fft_stage_generic: last_real)
         vi first = as_i16(sar(mad16_hi_uc(a, lane_const<LC_HANN_SYN_LO>(r), 8192), 14));                // :219-221
         vi out = sat16(add(shift_i31(first, vi(sh)), r.out_ovl));                     // :222-227; |sh| <= 14

@@ -130,8 +130,17 @@ BLOCK_KERNELS = {
     (1, True): ("aecm_process_kernelILb1ELb1ELb1", "aecm_process_kernel<fast,clean>"),
     (2, False): ("aecm_process_queue_kernelILb0E", "aecm_process_queue_kernel<noclean>"),
     (2, True): ("aecm_process_queue_kernelILb1E", "aecm_process_queue_kernel<clean>"),
-    (3, False): ("aecm_process_pipelined_kernel", "aecm_process_pipelined_kernel"),
+    (3, False): ("aecm_process_pipelined_kernelILi0ELb1E", "aecm_process_pipelined_kernel<tail=0,balance>"),
 }
+
+
+def block_kernel(form: int, clean: bool, detail: int = 0):
+    """(mangled-name fragment, printed name) of the kernel a launch takes; detail = DescribeLaunch's second value (for the
+    pipelined form: the tail waves per workgroup + 0x100 for the balanced instantiation, the kernel's template arguments)."""
+    if form == 3:
+        tail, bal = detail & 0xff, (detail >> 8) & 1
+        return f"aecm_process_pipelined_kernelILi{tail}ELb{bal}E", f"aecm_process_pipelined_kernel<tail={tail}{',balance' if bal else ''}>"
+    return BLOCK_KERNELS[(form, clean)]
 HEADLINE_KERNEL = BLOCK_KERNELS[(2, False)][0]       # bench.py's default workload (65 536 streams: larger than the chip)
 
 
