@@ -38,13 +38,18 @@ PROFILE_SUMMARY = ROOT / "profiles" / "r04_rocprof_summary.json"
 
 
 PROFILES = {
-    # name: (far-end envelope levels, near-end talk levels, what it is)
-    "recipe": ([15., 60., 500., 3000., 9000., 20000.], [0., 0., 0., 2000., 8000.],
+    # name: (far-end envelope levels, near-end talk levels, envelope segment in samples, what it is)
+    "recipe": ([15., 60., 500., 3000., 9000., 20000.], [0., 0., 0., 2000., 8000.], 6400,
                "the default: far end with pauses (0.4 s segments from 15 to 20 000), echo + near-end talk bursts 2 segments in 5"),
-    "always_active": ([500., 3000., 9000., 20000.], [2000., 8000.],
-                      "far end never below 500 and near-end talk in every segment: double talk in every block, the VAD never drops"),
-    "full_scale": ([60000.], [60000.], "far end and near-end talk clipped to +-32767 nearly everywhere: every inverse-transform stage rescales"),
-    "silent": ([0.], [0.], "digital silence on both ends"),
+    "always_active": ([500., 3000., 9000., 20000.], [2000., 8000.], 6400,
+                      "far end never below 500 and near-end talk in every segment"),
+    "double_talk": ([2000., 30000.], [60000.], 128,
+                    "far end switching between 2 000 and 30 000 every 8 ms under full-scale near-end talk: the VAD fires on the loud half, the "
+                    "suppression gain never decays to zero (no pass-through blocks), the output is loud enough to rescale inverse-transform stages"),
+    "full_scale": ([60000.], [60000.], 6400,
+                   "both ends clipped to +-32767 nearly everywhere: every inverse-transform stage rescales -- but a far end without level "
+                   "changes never trips the VAD (farEnergyMaxMin stays 0, aecm_core.cc:733-740), so no NLMS and gain zero: a CHEAP case"),
+    "silent": ([0.], [0.], 6400, "digital silence on both ends"),
 }
 
 
@@ -59,7 +64,7 @@ def synth_on_device(torch, S, L, seed, device, chunk=8192, profile="recipe"):
     g.manual_seed(seed)
     levels = torch.tensor(PROFILES[profile][0], device=device)
     talk_levels = torch.tensor(PROFILES[profile][1], device=device)
-    seg = 6400
+    seg = PROFILES[profile][2]
     nseg = L // seg + 2
     taps = ((100, 0.5), (180, -0.3), (333, 0.2), (600, 0.1))
     for s0 in range(0, S, chunk):
@@ -279,7 +284,7 @@ def main():
                          "step, the measured configuration); separates launch-length effects from the data's")
     ap.add_argument("--profile", choices=sorted(PROFILES), default="recipe",
                     help="content of the synthetic signals (the frame rate depends on which data-dependent paths the blocks take): "
-                         + "; ".join(f"{k} = {v[2]}" for k, v in PROFILES.items()))
+                         + "; ".join(f"{k} = {v[3]}" for k, v in PROFILES.items()))
     ap.add_argument("--fixed-delay", type=int, default=-1,
                     help="WebRtcAecm_Control fixed delay (>= 0 disables the estimator's choice; 0 = no far-history reads; "
                          "used to calibrate the FETCH_SIZE counter on a known byte count)")
@@ -405,8 +410,10 @@ def main():
                          "kernel": kernel_name,
                          "launch_form": {0: "one wavefront per stream (launch resident at once)", 1: "one wavefront per stream",
                                          2: f"chunk queue: items of {chunk} blocks claimed in order by resident wavefronts",
-                                         3: f"pipelined: {6 + (chunk & 0xff)} wavefronts per four streams, the forward transforms one block ahead in wavefronts of their own"
+                                         3: f"pipelined: {4 + (4 if chunk & 0x200 else 2) + (chunk & 0xff)} wavefronts per four streams, the forward transforms one block "
+                                            f"ahead in {4 if chunk & 0x200 else 2} wavefronts of their own"
                                             + (f", the inverse transforms one block behind in {chunk & 0xff} more" if chunk & 0xff else "")
+                                            + (", spectra formed by the back wavefronts" if chunk & 0x400 else "")
                                             + (", front-wave priorities balanced by progress feedback" if chunk & 0x100 else "")}[form],
                          "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_frame": algo_bytes,
                          "algorithmic_bytes_per_launch": algo_bytes * S * T,
@@ -417,7 +424,7 @@ def main():
         shares = parity.pop("content_shares", None) if parity is not None else None
         # what the frame rate was measured ON: the signal profile and, from the checker's streams over the timed passes, how many
         # blocks took the data-dependent paths that cost or save work (profiles/r05_content_sweep.txt has all profiles side by side)
-        res["content"] = {"profile": args.profile, "what": PROFILES[args.profile][2],
+        res["content"] = {"profile": args.profile, "what": PROFILES[args.profile][3],
                           "nlms_share": shares and shares.get("nlms_share"), "passthrough_share": shares and shares.get("gain_zero_share"),
                           "q_steady_share": shares and shares.get("q_steady_share"), "ifft_unscaled_share": shares and shares.get("ifft_unscaled_share"),
                           "delayed_share": shares and shares.get("delayed_share"),

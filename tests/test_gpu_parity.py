@@ -787,8 +787,10 @@ def test_launch_form_by_size():
     cus = aecm.device_info(0)[1]
     pipe_max, resident, rotation = cus * 16, cus * 28, cus * 24
     tail_max = cus * 12                       # eight-wave workgroups (two tail waves) come three to a CU
-    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 2), (tail_max, 300, False, 3, 2), (tail_max + 1, 300, False, 3, 0x100),
-                                          (pipe_max, 3, False, 3, 0), (pipe_max, 300, False, 3, 0x100), (pipe_max, 300, True, 0, 0),
+    # pipelined launches: the second value is the shape (tail waves | 0x100 balanced | 0x200 four front waves | 0x400 raw hand-over)
+    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 2), (cus * 4, 300, False, 3, 2), (cus * 8, 300, False, 3, 0x602),
+                                          (tail_max, 300, False, 3, 0x402), (tail_max + 1, 300, False, 3, 0x500),
+                                          (pipe_max, 3, False, 3, 0), (pipe_max, 300, False, 3, 0x500), (pipe_max, 300, True, 0, 0),
                                           (pipe_max + 1, 300, False, 2, 32), (pipe_max + 1, 63, False, 0, 0), (rotation + 1, 63, False, 1, 0),
                                           (resident, 64, True, 2, 32), (resident + 1, 255, False, 1, 0), (resident + 1, 256, False, 2, 128),
                                           (resident + 1, 256, True, 2, 128)):

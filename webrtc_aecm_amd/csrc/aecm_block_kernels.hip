@@ -23,6 +23,8 @@
 #if defined(AECM_CHECKED)
 #define g_aecm_check_fail g_aecm_check_fail_blocks      // device symbols are per translation unit (no relocatable device code)
 #endif
+#include <type_traits>
+
 #include "aecm_kernel_common.h"
 
 namespace aecm {
@@ -188,27 +190,33 @@ void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blo
 #ifndef AECM_PIPE_FRONT_PRIO
 #define AECM_PIPE_FRONT_PRIO 0        // the front waves' issue priority (the back waves': by phase, 1..3)
 #endif
-constexpr int kPipeStreams = 4, kPipeFrontWaves = 2;
-constexpr int kPipeStreamsPerFront = kPipeStreams / kPipeFrontWaves;
+constexpr int kPipeStreams = 4;
+// kFront front waves per workgroup: 2 (two streams each; the form for launches that fill the chip) or 4 (one stream each: ten-wave
+// workgroups with two tail waves, two to a CU -- launches of up to 2 048 streams, where the chip has wave slots to spare and a
+// front wave with two streams' transforms is the longest link of the chain).
 // A third role (round 5): tail_block -- inverse transform, synthesis window, overlap-add, the output store: 19 % of a block's
 // vector instructions and a long chain of LDS table reads and lane exchanges -- in kTail "tail" waves of their own, one block
 // BEHIND the middle waves (which then run middle_block only).  kTail = 1: one wave for the workgroup's four streams, seven
 // waves per workgroup = 28 per CU with four workgroups, every wave slot of the SIMDs taken; kTail = 2: two waves of two
 // streams, eight waves per workgroup, three workgroups per CU (launches of up to 3 072 streams).  The stream's sequential part
 // shrinks once more (what a small launch is bound by) and a SIMD gets one more wave of dense vector work to fill its port with.
-constexpr int PipeWaves(int tail_waves) { return kPipeStreams + kPipeFrontWaves + tail_waves; }
+constexpr int PipeWaves(int tail_waves, int front_waves = 2) { return kPipeStreams + front_waves + tail_waves; }
 struct PipeSlot {           // the spectra of one block of one stream on their way from the front to the back wave
     int near_x[kLanes];     // near-end spectrum, bins 0..63: re | im << 16 (im conjugated as the block path uses it)
     int mags[kLanes];       // far-end magnitude | near-end magnitude << 16 (both <= 46 340)
     int scalars[kLanes];    // lanes 0..4: far mag[64], far Q, near re[64], near mag[64], near Q
 };
+struct PipeRawSlot {        // the same hand-over BEFORE the spectra are formed (kRaw instantiations): the transforms' outputs
+    int fa[2][kLanes], fb[2][kLanes];     // BlockEngine::front_transforms: far end [0], near end [1]
+    int q[2], pad[2];
+};
 struct PipeTailSlot {       // the residual spectrum of one block of one stream on its way from the middle to the tail wave
     int a[kLanes], b[kLanes];   // BlockEngine::TailInput
     int clean_q, pad[3];
 };
-template <int kTail>
+template <int kTail, bool kRaw = false>
 struct PipeShared {
-    PipeSlot slots[2][kPipeStreams];      // [block parity][stream of the workgroup]
+    typename std::conditional<kRaw, PipeRawSlot, PipeSlot>::type slots[2][kPipeStreams];      // [block parity][stream of the workgroup]
     PipeTailSlot tails[kTail ? 2 : 1][kTail ? kPipeStreams : 1];
     int ahead;                            // this workgroup leads the launch's slowest one by more than the allowed lead (balance, below)
     int level;                            // the front waves' base priority for the current group of blocks (balance modes 2, 3)
@@ -264,6 +272,9 @@ struct PipeShared {
 #ifndef AECM_PIPE_FRONT_SECOND_BOOST
 #define AECM_PIPE_FRONT_SECOND_BOOST 1
 #endif
+#ifndef AECM_PIPE_FRONT_SECOND_BOOST_BALANCED
+#define AECM_PIPE_FRONT_SECOND_BOOST_BALANCED 0
+#endif
 __device__ __forceinline__ void SetPrioDynamic(int p) {      // s_setprio takes an immediate
     if (p <= 0) __builtin_amdgcn_s_setprio(0);
     else if (p == 1) __builtin_amdgcn_s_setprio(1);
@@ -292,12 +303,20 @@ constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of 
 // kBalance: the progress feedback of the front waves' priority (above) is compiled in; launches that do not use it (fewer than
 // four workgroups per CU) take the instantiation without it -- the same kernel with its monitor and its run-time priority
 // levels switched off at run time measured 2 % slower there.
-template <int kTail, bool kBalance>
-__global__ __launch_bounds__(64 * PipeWaves(kTail))
+// kRaw: the front waves hand over the transforms' raw outputs and the back waves form the spectra (bin order, magnitudes: 40 of a
+// stream's 198 front-part vector instructions) themselves.  For the balanced instantiation: with four workgroups per CU a
+// workgroup advances at the pace of its front waves while its back waves sit at the barrier for a third of their time.
+#ifndef AECM_PIPE_RAW_HANDOVER
+#define AECM_PIPE_RAW_HANDOVER 1
+#endif
+template <int kTail, bool kBalance, bool kRaw = false, int kFront = 2>
+__global__ __launch_bounds__(64 * PipeWaves(kTail, kFront))
 __attribute__((amdgpu_waves_per_eu(kTail == 1 ? AECM_PIPE_TAIL1_WAVES_PER_EU : AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, uint32_t *progress, int n_workgroups) {
     constexpr int kMode = kBalance ? AECM_PIPE_BALANCE : 0;               // AECM_PIPE_BALANCE's meaning, per instantiation
     constexpr int kFrontBehind = kBalance ? AECM_PIPE_FRONT_PRIO_BEHIND : AECM_PIPE_FRONT_PRIO;
+    // the second-stream boost is for the launches without balance: on top of it, it costs (4 096 streams: 862 M frames/s without, 844 with)
+    constexpr int kBoost = kBalance ? AECM_PIPE_FRONT_SECOND_BOOST_BALANCED : AECM_PIPE_FRONT_SECOND_BOOST;
 #if defined(AECM_PIPE_TRACE)     // diagnostics build: per wave, when it started / ended (100 MHz wall clock) and how long it sat at barriers (shader clocks)
     const uint64_t trace_t0 = wall_clock64(), trace_c0 = clock64();
     uint64_t trace_wait = 0;
@@ -305,8 +324,8 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #else
 #define AECM_PIPE_BARRIER() __syncthreads()
 #endif
-    constexpr int kWaves = PipeWaves(kTail);
-    PipeShared<kTail> &sh = *reinterpret_cast<PipeShared<kTail> *>(&g_lds[1]);        // behind the tables
+    constexpr int kWaves = PipeWaves(kTail, kFront), kPipeFrontWaves = kFront, kPipeStreamsPerFront = kPipeStreams / kFront;
+    PipeShared<kTail, kRaw> &sh = *reinterpret_cast<PipeShared<kTail, kRaw> *>(&g_lds[1]);        // behind the tables
     if (kMode != 0 && threadIdx.x == 0) { sh.ahead = 0; sh.level = kFrontBehind; }
     FillLdsTables<64 * kWaves>(st.consts);                              // ends in a barrier
     using W = Gfx950Wave<true, true, false, false, kMode == 1>;
@@ -333,23 +352,31 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             // block blk - 1 and ended in the barrier this wave has just passed.
             if (kMode == 1 && (blk & kPipeGroupMask) == 0 && blk != 0) r.u.prio_drop = __builtin_amdgcn_readfirstlane(sh.ahead);
             if (live) {
-                const PipeSlot &slot = sh.slots[blk & 1][wave];
                 const int lane = W::lane_id();
-                const int x = slot.near_x[lane], m = slot.mags[lane], sc = slot.scalars[lane];
                 typename E::Spectrum xf, df;
-                xf.mag = zext16(m);
-                xf.mag64 = __builtin_amdgcn_readlane(sc, 0);
-                xf.q = __builtin_amdgcn_readlane(sc, 1);
-                xf.re = xf.im = 0;
-                xf.re64 = 0;
-                df.re = sext16(x);
-                df.im = sar(x, 16);
-                df.mag = lsr(m, 16);
-                df.re64 = __builtin_amdgcn_readlane(sc, 2);
-                df.mag64 = __builtin_amdgcn_readlane(sc, 3);
-                df.q = __builtin_amdgcn_readlane(sc, 4);
-                E::update_startup(r.u);
                 r.table_index = W::table_index_for_this_block();
+                if constexpr (kRaw) {
+                    const PipeRawSlot &slot = sh.slots[blk & 1][wave];
+                    const int fa0 = slot.fa[0][lane], fb0 = slot.fb[0][lane], fa1 = slot.fa[1][lane], fb1 = slot.fb[1][lane];
+                    const int q0 = __builtin_amdgcn_readfirstlane(slot.q[0]), q1 = __builtin_amdgcn_readfirstlane(slot.q[1]);
+                    E::spectrum(r, fa0, fb0, q0, xf);
+                    E::spectrum(r, fa1, fb1, q1, df);
+                } else {
+                    const PipeSlot &slot = sh.slots[blk & 1][wave];
+                    const int x = slot.near_x[lane], m = slot.mags[lane], sc = slot.scalars[lane];
+                    xf.mag = zext16(m);
+                    xf.mag64 = __builtin_amdgcn_readlane(sc, 0);
+                    xf.q = __builtin_amdgcn_readlane(sc, 1);
+                    xf.re = xf.im = 0;
+                    xf.re64 = 0;
+                    df.re = sext16(x);
+                    df.im = sar(x, 16);
+                    df.mag = lsr(m, 16);
+                    df.re64 = __builtin_amdgcn_readlane(sc, 2);
+                    df.mag64 = __builtin_amdgcn_readlane(sc, 3);
+                    df.q = __builtin_amdgcn_readlane(sc, 4);
+                }
+                E::update_startup(r.u);
                 if constexpr (kTail != 0) {
                     const typename E::TailInput t = E::middle_block(r, hist, xf, df, df);
                     PipeTailSlot &ts = sh.tails[blk & 1][wave];
@@ -416,13 +443,13 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             }
             if (kMode != 0 && kFrontBehind != AECM_PIPE_FRONT_PRIO && (blk & kPipeGroupMask) == 1 && blk > kPipeGroupMask) {
                 level = __builtin_amdgcn_readfirstlane(sh.level);
-                if (AECM_PIPE_FRONT_SECOND_BOOST == 0) SetPrioDynamic(level);
+                if (kBoost == 0) SetPrioDynamic(level);
             }
             if (blk < n_blocks) {
 #pragma unroll
                 for (int k = 0; k < kPipeStreamsPerFront; ++k) {
                     if (!live[k]) continue;
-                    if (AECM_PIPE_FRONT_SECOND_BOOST != 0) SetPrioDynamic(level + (k == 0 ? 0 : AECM_PIPE_FRONT_SECOND_BOOST));      // folds to immediates without balance
+                    if (kBoost != 0) SetPrioDynamic(level + (k == 0 ? 0 : kBoost));      // folds to immediates without balance
                     const int far_cur = far_next[k], near_cur = near_next[k];
                     if (blk + 1 < n_blocks) {
                         typename EF::StridedIo sio{io, (first + k0 + k) * io.stream_stride};
@@ -430,21 +457,30 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                         near_next[k] = sio.near(r, blk + 1);
                     }
                     r.table_index = Gfx950Wave<true, false>::table_index_for_this_block();
-                    typename EF::Spectrum xf, df, cf;
-                    EF::front_block(r, x_old[k], far_cur, d_old[k], near_cur, 0, 0, xf, df, cf);
+                    const int lane = W::lane_id();
+                    if constexpr (kRaw) {
+                        int fa[2], fb[2], q[2];
+                        EF::front_transforms(r, x_old[k], far_cur, d_old[k], near_cur, fa, fb, q);
+                        PipeRawSlot &slot = sh.slots[blk & 1][k0 + k];
+                        slot.fa[0][lane] = fa[0]; slot.fb[0][lane] = fb[0];
+                        slot.fa[1][lane] = fa[1]; slot.fb[1][lane] = fb[1];
+                        if (lane == 0) { slot.q[0] = q[0]; slot.q[1] = q[1]; }
+                    } else {
+                        typename EF::Spectrum xf, df, cf;
+                        EF::front_block(r, x_old[k], far_cur, d_old[k], near_cur, 0, 0, xf, df, cf);
+                        PipeSlot &slot = sh.slots[blk & 1][k0 + k];
+                        slot.near_x[lane] = (df.re & 0xffff) | (int)((unsigned)df.im << 16);
+                        slot.mags[lane] = xf.mag | (int)((unsigned)df.mag << 16);
+                        int sc = 0;
+                        sc = W::writelane(sc, xf.mag64, 0);
+                        sc = W::writelane(sc, xf.q, 1);
+                        sc = W::writelane(sc, df.re64, 2);
+                        sc = W::writelane(sc, df.mag64, 3);
+                        sc = W::writelane(sc, df.q, 4);
+                        slot.scalars[lane] = sc;
+                    }
                     x_old[k] = far_cur;
                     d_old[k] = near_cur;
-                    PipeSlot &slot = sh.slots[blk & 1][k0 + k];
-                    const int lane = W::lane_id();
-                    slot.near_x[lane] = (df.re & 0xffff) | (int)((unsigned)df.im << 16);
-                    slot.mags[lane] = xf.mag | (int)((unsigned)df.mag << 16);
-                    int sc = 0;
-                    sc = W::writelane(sc, xf.mag64, 0);
-                    sc = W::writelane(sc, xf.q, 1);
-                    sc = W::writelane(sc, df.re64, 2);
-                    sc = W::writelane(sc, df.mag64, 3);
-                    sc = W::writelane(sc, df.q, 4);
-                    slot.scalars[lane] = sc;
                 }
             }
             if (monitor) {
@@ -527,14 +563,65 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #undef AECM_PIPE_BARRIER
 
 // Streams a pipelined launch keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
-template <int kTail>
+template <int kTail, int kFront = 2>
 constexpr int PipeWorkgroupsPerCu() {
-    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / PipeWaves(kTail), by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + sizeof(PipeShared<kTail>)));
+    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / PipeWaves(kTail, kFront), by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + sizeof(PipeShared<kTail, true>)));
     return by_waves < by_lds ? by_waves : by_lds;
 }
-int PipelinedStreamLimit(int compute_units, int tail_waves) {
-    const int per_cu = tail_waves == 0 ? PipeWorkgroupsPerCu<0>() : PipeWorkgroupsPerCu<2>();
+// Streams a pipelined launch of this shape keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
+int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves) {
+    const int per_cu = tail_waves == 0 ? PipeWorkgroupsPerCu<0>() : front_waves == 4 ? PipeWorkgroupsPerCu<2, 4>() : PipeWorkgroupsPerCu<2>();
     return (compute_units > 0 ? compute_units : 256) * per_cu * kPipeStreams;
+}
+
+// The shape of a pipelined launch by its size (measured: profiles/r05_experiments.md section 1.4; M frames/s, 2 048 blocks):
+//   up to one workgroup per CU    (1 024 streams on 256 CUs)  two tail waves                                  372 -> 421
+//   up to two per CU              (2 048)                     two tail waves, FOUR front waves, raw hand-over  600 -> 740
+//   up to three per CU            (3 072)                     two tail waves, raw hand-over                    735 -> 795
+//   more (four per CU: 4 096)                                 balance + raw hand-over (launches of >= 128 blocks)  816 -> 863
+// tail_waves / front_waves / raw < 0: by this table; otherwise the caller's wish where the shape exists and fits (experiments).
+PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves, int front_waves, int raw) {
+    const int cus = compute_units > 0 ? compute_units : 256;
+    const int n_wg = (n_streams + kPipeStreams - 1) / kPipeStreams;
+    PipeShape sh{0, 2, false, false};
+    const int want_tail = tail_waves < 0 ? 2 : tail_waves;
+    if (want_tail >= 2 && n_streams <= PipelinedStreamLimit(cus, 2, 2)) sh.tail_waves = 2;
+    const int want_front = front_waves < 0 ? (n_wg > cus ? 4 : 2) : front_waves;
+    if (want_front >= 4 && sh.tail_waves == 2 && n_streams <= PipelinedStreamLimit(cus, 2, 4)) sh.front_waves = 4;
+    sh.balance = sh.tail_waves == 0 && AECM_PIPE_BALANCE != 0 && n_blocks >= (8 << kPipeGroupLog2) && n_wg <= 128 * kPipeMonitorLoads && n_wg > 3 * cus;
+    const bool want_raw = (raw < 0 ? (AECM_PIPE_RAW_HANDOVER != 0 && (sh.balance || (sh.tail_waves == 2 && n_wg > cus))) : raw != 0);
+    // the raw form exists for: the balanced shape, and the two-tail shapes
+    sh.raw = want_raw && (sh.balance || sh.tail_waves == 2);
+    if (sh.balance && !want_raw) sh.balance = false;          // (no balanced instantiation without the raw hand-over)
+    return sh;
+}
+
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, const PipeShape &shape, uint32_t *progress,
+                                        hipStream_t stream) {
+    if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
+    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * PipeWaves(shape.tail_waves, shape.front_waves));
+    if (shape.balance) {
+        if (!progress) return hipErrorInvalidValue;
+        const hipError_t e = hipMemsetAsync(progress, 0, PipelinedControlBytes(n_streams), stream);
+        if (e != hipSuccess) return e;
+    }
+#if !defined(AECM_PIPE_TRACE)
+    if (!shape.balance) progress = nullptr;
+#endif
+#define AECM_LAUNCH_PIPE(T, B, R, F) hipLaunchKernelGGL((aecm_process_pipelined_kernel<T, B, R, F>), grid, block, sizeof(LdsTables) + sizeof(PipeShared<T, R>), \
+                                                        stream, st, io, n_streams, n_blocks, progress, (int)grid.x)
+    // The instantiations the library carries (PipelinedShapeFor only ever asks for these).  One tail wave for four streams (kTail = 1,
+    // seven-wave workgroups) measured slower than its neighbours at every size and is not built.
+    const int key = shape.tail_waves * 100 + shape.front_waves * 10 + (shape.raw ? 1 : 0);
+    if (shape.balance) { if (key != 21) return hipErrorInvalidValue; AECM_LAUNCH_PIPE(0, true, true, 2); }
+    else if (key == 20) AECM_LAUNCH_PIPE(0, false, false, 2);
+    else if (key == 220) AECM_LAUNCH_PIPE(2, false, false, 2);
+    else if (key == 221) AECM_LAUNCH_PIPE(2, false, true, 2);
+    else if (key == 241) AECM_LAUNCH_PIPE(2, false, true, 4);
+    else if (key == 240) AECM_LAUNCH_PIPE(2, false, false, 4);
+    else return hipErrorInvalidValue;
+#undef AECM_LAUNCH_PIPE
+    return hipGetLastError();
 }
 
 // The progress words of a pipelined launch: 16 bits per workgroup (cleared by the launch).
@@ -549,37 +636,6 @@ size_t PipelinedControlBytes(int n_streams) {
 size_t PipelinedTraceOffsetBytes(int n_streams) {
     const size_t n_wg = (size_t)(n_streams + kPipeStreams - 1) / kPipeStreams;
     return 4 * ((n_wg + 3) / 4) * sizeof(uint32_t);
-}
-
-// Balance pays where a CU holds four workgroups (measured: +3 % at 3 584 streams, +3.5 % at 4 096, -2 % at 3 072 and below, where
-// the monitor costs more than the two or three workgroups of a CU drift apart): from 3 workgroups per CU on average upwards.
-bool PipelinedBalanceApplies(int n_streams, int n_blocks, int compute_units) {
-    const int n_wg = (n_streams + kPipeStreams - 1) / kPipeStreams;
-    return AECM_PIPE_BALANCE != 0 && n_blocks >= (8 << kPipeGroupLog2) && n_wg <= 128 * kPipeMonitorLoads &&
-           n_wg > 3 * (compute_units > 0 ? compute_units : 256);
-}
-
-hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int tail_waves, uint32_t *progress,
-                                        hipStream_t stream) {
-    if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
-    if (tail_waves != 0 && tail_waves != 2) return hipErrorInvalidValue;
-    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * PipeWaves(tail_waves));
-    // progress: null = no balance (the engine asks PipelinedBalanceApplies)
-    if (progress) {
-        const hipError_t e = hipMemsetAsync(progress, 0, PipelinedControlBytes(n_streams), stream);
-        if (e != hipSuccess) return e;
-    }
-#define AECM_LAUNCH_PIPE(T, B) hipLaunchKernelGGL((aecm_process_pipelined_kernel<T, B>), grid, block, sizeof(LdsTables) + sizeof(PipeShared<T>), stream, st, \
-                                                  io, n_streams, n_blocks, progress, (int)grid.x)
-    // The instantiations the library carries: no tail waves with and without balance (launches of four / fewer workgroups per CU),
-    // two tail waves without (eight-wave workgroups come three to a CU).  One tail wave for four streams (kTail = 1, seven-wave
-    // workgroups) measured slower than either at every size (profiles/r05_experiments.md) and is not built.
-    const bool balance = progress != nullptr && AECM_PIPE_BALANCE != 0;
-    if (tail_waves == 2) { if (balance) return hipErrorInvalidValue; AECM_LAUNCH_PIPE(2, false); }
-    else if (balance) AECM_LAUNCH_PIPE(0, true);
-    else AECM_LAUNCH_PIPE(0, false);
-#undef AECM_LAUNCH_PIPE
-    return hipGetLastError();
 }
 
 size_t QueueControlBytes(int n_streams) { return ((size_t)kQueueCtlWords + (size_t)n_streams) * sizeof(uint32_t); }

@@ -37,7 +37,10 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::min(std::max(0, atoi(env)), kMaxQueueChunk);   // the C API's bound
     if (const char *env = getenv("AECM_QUEUE_MIN_STREAMS")) e->queue_min_streams_ = atoi(env);      // experiments: the queue form above this many streams
     e->pipe_max_streams_ = PipelinedStreamLimit(cus, 0);            // = that of one tail wave (seven waves per workgroup fill the SIMDs' 28 slots)
-    if (const char *env = getenv("AECM_PIPE_TAIL")) e->pipe_tail_ = atoi(env);      // experiments: 0 / 2 tail waves per workgroup; default: 2 where they fit
+    // experiments: the shape of pipelined launches (aecm_kernels.h: PipelinedShapeFor); default: by the launch's size
+    if (const char *env = getenv("AECM_PIPE_FRONT")) e->pipe_front_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_TAIL")) e->pipe_tail_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_RAW")) e->pipe_raw_ = atoi(env);
     if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
@@ -211,13 +214,13 @@ bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count,
     if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
 #endif
     {
-        const int tail = PipelinedTailWaves(count);
-        bool balance = tail == 0 && PipelinedBalanceApplies(count, num_blocks, compute_units_);
+        const PipeShape shape = PipelinedShapeFor(count, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_);
+        bool need_ctl = shape.balance;
 #if defined(AECM_PIPE_TRACE)
-        balance = true;                       // (the diagnostics build keeps the buffer: its per-wave records live behind the progress words)
+        need_ctl = true;                      // (the diagnostics build keeps the buffer: its per-wave records live behind the progress words)
 #endif
-        if (balance && !EnsureLaunchControl(PipelinedControlBytes(count))) return false;
-        return AECM_HIP_OK(LaunchProcessBlocksPipelined(st, io, count, num_blocks, tail, balance ? queue_ctl_ : nullptr, stream_));
+        if (need_ctl && !EnsureLaunchControl(PipelinedControlBytes(count))) return false;
+        return AECM_HIP_OK(LaunchProcessBlocksPipelined(st, io, count, num_blocks, shape, need_ctl ? queue_ctl_ : nullptr, stream_));
     }
     return AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, rotation_limit_, stream_, blocks_per_stream_dev));
 }
@@ -226,13 +229,6 @@ bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count,
 // stream the same number of blocks.
 bool BatchEngine::PipelinedLaunchApplies(int count, bool clean, bool ragged) const {
     return variant_ == kVariantFast && !clean && !ragged && count >= pipe_min_streams_ && count <= pipe_max_streams_;
-}
-
-// How many tail waves a pipelined launch of `count` streams gets (aecm_block_kernels.hip): the most that still keeps every
-// workgroup of the launch resident at once.
-int BatchEngine::PipelinedTailWaves(int count) const {
-    const int want = pipe_tail_ >= 0 ? pipe_tail_ : kDefaultPipeTail;
-    return want >= 2 && count <= PipelinedStreamLimit(compute_units_, 2) ? 2 : 0;
 }
 
 // The chunk queue takes every launch of more streams than the pipelined form does (or than min_streams, when set): above the
@@ -254,9 +250,10 @@ int BatchEngine::DescribeLaunch(int num_blocks, bool has_clean, int *chunk_block
     }
     if (chunk_blocks) *chunk_blocks = 0;
     if (PipelinedLaunchApplies(num_streams_, has_clean, false)) {
-        // (for this form: the tail waves per workgroup, + 0x100 when the launch balances its workgroups' progress)
-        const int tail = PipelinedTailWaves(num_streams_);
-        if (chunk_blocks) *chunk_blocks = tail | (tail == 0 && PipelinedBalanceApplies(num_streams_, num_blocks, compute_units_) ? 0x100 : 0);
+        // (for this form: the tail waves per workgroup, + 0x100 when the launch balances its workgroups' progress, + 0x200 with
+        // four front waves, + 0x400 with the raw hand-over: the kernel's template arguments)
+        const PipeShape sh = PipelinedShapeFor(num_streams_, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_);
+        if (chunk_blocks) *chunk_blocks = sh.tail_waves | (sh.balance ? 0x100 : 0) | (sh.front_waves == 4 ? 0x200 : 0) | (sh.raw ? 0x400 : 0);
         return 3;
     }
     return variant_ == kVariantFast && num_streams_ > rotation_limit_ ? 1 : 0;

@@ -38,16 +38,24 @@ hipError_t LaunchProcessBlocksQueued(const StatePtrs &st, const IoView &io, int 
                                      int resident_waves, uint32_t *ctl, uint32_t *err, hipStream_t stream);
 int ResidentWaves(int compute_units);
 
-// The pipelined form of a launch the chip holds at once (aecm_block_kernels.hip): six (+ tail_waves) waves per four streams, the
-// state-independent transforms of a block in waves of their own, one block ahead; with tail_waves = 1 / 2 the inverse transform
-// and synthesis too, one block behind.  Fast variant, no clean input, every stream the same number of blocks.
-// progress: PipelinedControlBytes(n_streams) of device memory owned by the engine (cleared by the launch): one word per
-// workgroup, by which the workgroups balance their progress; null = no balance (PipelinedBalanceApplies says when it pays).
-int PipelinedStreamLimit(int compute_units, int tail_waves);
+// The pipelined form of a launch the chip holds at once (aecm_block_kernels.hip): a workgroup serves four streams with one
+// "back" wave per stream and, in waves of their own, the state-independent forward transforms one block ahead (front waves)
+// and -- in some shapes -- the inverse transforms one block behind (tail waves).  Fast variant, no clean input, every stream
+// the same number of blocks.
+struct PipeShape {
+    int tail_waves;      // 0 or 2 per workgroup
+    int front_waves;     // 2 (two streams each) or 4 (one each; with tail waves only)
+    bool raw;            // the front waves hand over the transforms' outputs, the back waves form the spectra
+    bool balance;        // progress feedback on the front waves' issue priority (needs `progress`)
+};
+// The shape a launch of this size takes; tail_waves / front_waves / raw < 0 = by size, else the caller's wish where it exists and fits.
+PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves = -1, int front_waves = -1, int raw = -1);
+int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves = 2);
+// progress: PipelinedControlBytes(n_streams) of device memory owned by the engine (cleared by the launch): 16 bits per
+// workgroup, by which the workgroups of a balanced launch keep in step.
 size_t PipelinedControlBytes(int n_streams);
-bool PipelinedBalanceApplies(int n_streams, int n_blocks, int compute_units);
 size_t PipelinedTraceOffsetBytes(int n_streams);     // diagnostics builds (-DAECM_PIPE_TRACE): where the per-wave records follow the progress words
-hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, int tail_waves, uint32_t *progress,
+hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, const PipeShape &shape, uint32_t *progress,
                                         hipStream_t stream);
 
 // Replicate one stream image (vec: kNumVec*64 words, scal: 64 words, both on the device) into

@@ -1199,6 +1199,18 @@ struct BlockEngine {
         AECM_PHASE_MARK(2, df.mag, df.re);
     }
 
+    // front_block without the spectra (and without a clean input): the forward transforms' outputs of the far-end (index 0) and
+    // the near-end signal and their dynamic Q; spectrum() of each is then somebody else's work (the pipelined kernel's balanced
+    // form hands these over instead of the spectra, so that the magnitudes are computed by the waves that have time to spare).
+    static AECM_HD void front_transforms(const Regs &r, vi x_old, vi far_new, vi d_old, vi near_new, vi (&fa)[2], vi (&fb)[2], int (&q)[2]) {
+        int max_abs[2];
+        W::reduce_max2(abs_max(x_old, far_new), abs_max(d_old, near_new), max_abs[0], max_abs[1]);
+        q[0] = window(r, x_old, far_new, max_abs[0], fa[0], fb[0]);
+        q[1] = window(r, d_old, near_new, max_abs[1], fa[1], fb[1]);
+        for (int n = 0; n < 2; ++n) fft_stage0_windowed(fa[n], fb[n]);
+        fft128<false, true, 2, 1>(fa, fb, r.k_p);
+    }
+
     static AECM_HD vi process_block(Regs &r, uint16_t *hist, vi far_new, vi near_new, vi clean_new) {
         update_startup(r.u);
         if (W::kLaneConstsInTable) r.table_index = W::table_index_for_this_block();
@@ -1225,6 +1237,24 @@ struct BlockEngine {
         return tail_block(r, t.a, t.b, t.clean_q);
     }
 
+    // The delay estimator of a block (delay_estimator_wrapper.cc:92-125, 233-263, 447-476; delay_estimator.cc:369-382, 521-664):
+    // both binary spectra, the far word into its history, the 100 means, the delay.  It reads the two magnitude spectra and the Q
+    // domains of the block and touches nothing but its own state (r.mean, r.bh0, r.bh1, r.m01, far_init / near_init / min_prob /
+    // last_prob / last_delay).  (Round 5 tried it in the pipelined kernel's front waves, one block ahead of everything else: slower at
+    // every size -- profiles/r05_experiments.md section 1.5.)  Returns last_delay (-2 until the first valid estimate).
+    static AECM_HD int delay_block(Regs &r, const Spectrum &xf, const Spectrum &df) {
+        int near_word;
+        {
+            int word = binary_spectra(r, xf.mag, xf.q, df.mag, df.q, near_word);
+            int carry = W::readlane(r.bh0, 63);
+            r.bh0 = W::shift_up1(r.bh0, word);
+            r.bh1 = W::shift_up1(r.bh1, carry);
+        }
+        AECM_PHASE_MARK(3, r.bh0, r.mean);
+        W::template phase_priority<4>(r.u.prio_drop);
+        // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
+        return process_binary(r, near_word);
+    }
     static AECM_HD TailInput middle_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, const Spectrum &cf) {
         Uniform &u = r.u;
         W::template phase_priority<3>(r.u.prio_drop);
@@ -1249,19 +1279,8 @@ struct BlockEngine {
             else r.hq1 = W::writelane(r.hq1, side, u.hist_pos - 64);
         }
 
-        // far and near binary spectra (delay_estimator_wrapper.cc:92-125); the far word -> history (:233-263,
-        // delay_estimator.cc:369-382)
-        int near_word;
-        {
-            int word = binary_spectra(r, xf.mag, xf.q, df.mag, df.q, near_word);
-            int carry = W::readlane(r.bh0, 63);
-            r.bh0 = W::shift_up1(r.bh0, word);
-            r.bh1 = W::shift_up1(r.bh1, carry);
-        }
-        AECM_PHASE_MARK(3, r.bh0, r.mean);
-        W::template phase_priority<4>(r.u.prio_drop);
-        // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
-        int delay = process_binary(r, near_word);
+        // far and near binary spectra, the far word -> history, near binary spectrum -> delay
+        int delay = delay_block(r, xf, df);
         if (delay == -2) delay = 0;                                                   // :479-483
         if (W::per_block(u.fixed_delay) >= 0) delay = u.fixed_delay;                  // :485-488
 

@@ -130,25 +130,27 @@ BLOCK_KERNELS = {
     (1, True): ("aecm_process_kernelILb1ELb1ELb1", "aecm_process_kernel<fast,clean>"),
     (2, False): ("aecm_process_queue_kernelILb0E", "aecm_process_queue_kernel<noclean>"),
     (2, True): ("aecm_process_queue_kernelILb1E", "aecm_process_queue_kernel<clean>"),
-    (3, False): ("aecm_process_pipelined_kernelILi0ELb1E", "aecm_process_pipelined_kernel<tail=0,balance>"),
+    (3, False): ("aecm_process_pipelined_kernelILi0ELb1ELb1ELi2E", "aecm_process_pipelined_kernel<tail=0,front=2,raw,balance>"),
 }
 
 
 def block_kernel(form: int, clean: bool, detail: int = 0):
     """(mangled-name fragment, printed name) of the kernel a launch takes; detail = DescribeLaunch's second value (for the
-    pipelined form: the tail waves per workgroup + 0x100 for the balanced instantiation, the kernel's template arguments)."""
+    pipelined form: the tail waves per workgroup + 0x100 balanced + 0x200 four front waves + 0x400 raw hand-over, the
+    kernel's template arguments).  The fragment is a regular expression."""
     if form == 3:
-        tail, bal = detail & 0xff, (detail >> 8) & 1
-        return f"aecm_process_pipelined_kernelILi{tail}ELb{bal}E", f"aecm_process_pipelined_kernel<tail={tail}{',balance' if bal else ''}>"
+        tail, bal, front, raw = detail & 0xff, (detail >> 8) & 1, 4 if detail & 0x200 else 2, (detail >> 10) & 1
+        return (f"aecm_process_pipelined_kernelILi{tail}ELb{bal}ELb{raw}ELi{front}E",
+                f"aecm_process_pipelined_kernel<tail={tail},front={front}{',raw' if raw else ''}{',balance' if bal else ''}>")
     return BLOCK_KERNELS[(form, clean)]
 HEADLINE_KERNEL = BLOCK_KERNELS[(2, False)][0]       # bench.py's default workload (65 536 streams: larger than the chip)
 
 
 def census(lib_path, kernel_substr: str = HEADLINE_KERNEL):
-    """Census of the first kernel whose mangled name contains kernel_substr (default: the headline block kernel)."""
+    """Census of the first kernel whose mangled name matches kernel_substr (a regular expression; default: the headline block kernel)."""
     all_k = census_of_text(disassemble(lib_path))
     for name, c in all_k.items():
-        if kernel_substr in name:
+        if re.search(kernel_substr, name):
             return dict(kernel=name, **c)
     raise KeyError(kernel_substr)
 
