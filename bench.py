@@ -34,7 +34,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_FRAME = 384            # 128 far in + 128 near in + 128 out
 HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_SUMMARY = ROOT / "profiles" / "r04_rocprof_summary.json"
+# rocprofv3 records of this round's kernels (tools/gpu_round5_final.sh): the headline (chunk-queue kernel) and the configs[1] kernel (pipelined, balanced)
+PROFILE_SUMMARIES = [ROOT / "profiles" / "r05_rocprof_summary.json", ROOT / "profiles" / "r05_pipelined_rocprof_summary.json"]
 
 
 PROFILES = {
@@ -225,7 +226,7 @@ def workload_name(S, T, fs, world, clean):
 
 def load_profile_record(lib_path, workload_key, kernel_substr):
     """Issue-port figures and HBM traffic of the dominant kernel come from separate rocprofv3 PMC passes
-    (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/r04_rocprof_summary.json), which cannot run
+    (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/r05_*rocprof_summary.json), which cannot run
     inside this process.  They are only valid for the binary they were measured on: the summary stores the
     instruction-stream fingerprint of the profiled kernel (webrtc_aecm_amd/isa_census.py) and is quoted only
     when the library timed here has the same fingerprint and the same workload; otherwise it is reported as stale."""
@@ -236,13 +237,18 @@ def load_profile_record(lib_path, workload_key, kernel_substr):
         return None, {"available": False, "reason": f"could not disassemble {lib_path}: {e}"}
     static = {"kernel_symbol": now["kernel"], "kernel_fingerprint": now["fingerprint"], "static_counts": now["counts"],
               "static_valu_fast_class": now["valu_fast_class"], "static_valu_8cycle_class": now["valu_8cycle_class"]}
-    if not PROFILE_SUMMARY.exists():
-        return None, dict(static, available=False, reason=f"{PROFILE_SUMMARY.name} not recorded yet")
-    rec = json.loads(PROFILE_SUMMARY.read_text())
-    if rec.get("kernel_fingerprint") != now["fingerprint"]:
-        return None, dict(static, available=False, stale=True,
-                          reason=f"profiles were measured on kernel fingerprint {rec.get('kernel_fingerprint')} "
-                                 f"(commit {rec.get('measured_at_commit')}), this library is {now['fingerprint']}: re-profile")
+    recs = [(p, json.loads(p.read_text())) for p in PROFILE_SUMMARIES if p.exists()]
+    if not recs:
+        return None, dict(static, available=False, reason=f"{PROFILE_SUMMARIES[0].name} not recorded yet")
+    same_kernel = [(p, r) for p, r in recs if r.get("kernel_symbol") == now["kernel"]]
+    match = [(p, r) for p, r in same_kernel if r.get("kernel_fingerprint") == now["fingerprint"]]
+    if not match:
+        p, r = (same_kernel or recs)[0]
+        return None, dict(static, available=False, stale=bool(same_kernel),
+                          reason=(f"profiles/{p.name} was measured on kernel fingerprint {r.get('kernel_fingerprint')} (commit {r.get('measured_at_commit')}), "
+                                  f"this library is {now['fingerprint']}: re-profile") if same_kernel else
+                                 f"no rocprofv3 record of {now['kernel'][:60]} under profiles/ (recorded: the headline and the configs[1] kernel)")
+    PROFILE_SUMMARY, rec = match[0]
     d = rec.get("derived", {})
     note = dict(static, available=True, measured_at_commit=rec.get("measured_at_commit"),
                 valu_insts_per_frame=d.get("valu_insts_per_frame"), salu_insts_per_frame=d.get("salu_insts_per_frame"),

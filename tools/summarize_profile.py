@@ -15,6 +15,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "gpurun_out"
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+P = sys.argv[2] if len(sys.argv) > 2 else "prof"         # source directories gpurun_out/<P>_* (tools/profile_gpu.sh: PREFIX)
 N_SIMD = 256 * 4
 
 
@@ -35,13 +36,13 @@ def bench_line(log):
     raise SystemExit(f"no bench JSON line in {log}")
 
 
-meta = json.loads((SRC / "prof_meta.json").read_text())
-bl = bench_line(SRC / "prof_stats.log")
+meta = json.loads((SRC / f"{P}_meta.json").read_text())
+bl = bench_line(SRC / f"{P}_stats.log")
 S, T, FS = bl["config"]["streams_per_gpu"], bl["config"]["blocks_per_step"], bl["config"]["fs"]
 frames = S * T
 state_bytes = meta["state_size_bytes"] - 32 - 100 * 64 * 2           # vec + scal of one stream (header and history excluded)
 
-rows = list(csv.reader(open(SRC / "prof_stats" / "bench_kernel_stats.csv")))
+rows = list(csv.reader(open(SRC / f"{P}_stats" / "bench_kernel_stats.csv")))
 with open(ROOT / "profiles" / f"{tag}_kernel_stats.csv", "w", newline="") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 10 --warmup 2  (commit {meta['commit']}, "
             f"{S} streams x {T} blocks per launch)\n")
@@ -51,9 +52,9 @@ with open(ROOT / "profiles" / f"{tag}_kernel_stats.csv", "w", newline="") as f:
 kern_row = next(r for r in rows[1:] if "aecm_process" in r[0])
 kern_ns = float(kern_row[3])
 pmc = {}
-for p in ("prof_fetch", "prof_write", "prof_sq1", "prof_sq2", "prof_sq3", "prof_grbm"):
-    pmc.update(agg(SRC / p / "bench_counter_collection.csv"))
-cal = agg(SRC / "prof_fetch_cal" / "bench_counter_collection.csv")
+for p in ("fetch", "write", "sq1", "sq2", "sq3", "grbm"):
+    pmc.update(agg(SRC / f"{P}_{p}" / "bench_counter_collection.csv"))
+cal = agg(SRC / f"{P}_fetch_cal" / "bench_counter_collection.csv")
 # chunk-queue launches (bench line: config.launch_chunk_blocks) load and store a stream's state once per chunk
 import re as _re
 chunk = bl["config"].get("launch_chunk_blocks")
@@ -109,7 +110,7 @@ summary = {
     "traffic_by_workload": {workload_key: fetch + write},
 }
 # the streaming path (tools/bench_sessions.py): second roofline entry, HBM-side
-tick_stats = SRC / "prof_tick" / "tick_kernel_stats.csv"
+tick_stats = SRC / f"{P}_tick" / "tick_kernel_stats.csv"
 if tick_stats.exists():
     trows = list(csv.reader(open(tick_stats)))
     with open(ROOT / "profiles" / f"{tag}_tick_kernel_stats.csv", "w", newline="") as f:
@@ -128,8 +129,8 @@ if tick_stats.exists():
         per_tick_ns += float(r[2]) / n_ticks
     tf = {}
     for sub in ("aecm_process", "aecm_tick"):
-        for d in ("prof_tick_fetch", "prof_tick_write"):
-            for k, v in agg(SRC / d / "tick_counter_collection.csv", sub).items():
+        for d in ("tick_fetch", "tick_write"):
+            for k, v in agg(SRC / f"{P}_{d}" / "tick_counter_collection.csv", sub).items():
                 tf[f"{sub}:{k}"] = v
     tick["pmc_avg_per_launch"] = tf
     # the kernel that runs the tick's blocks
@@ -142,14 +143,14 @@ if tick_stats.exists():
                                     "hbm_GBps": (rd + wr) / (avg_ns / 1e9) / 1e9, "hbm_frac_of_8TBps": (rd + wr) / (avg_ns / 1e9) / 8e12,
                                     "bytes_per_session_tick": (rd + wr) / 65536}
             break
-    sq = agg(SRC / "prof_tick_sq" / "tick_counter_collection.csv", "aecm_tick")
+    sq = agg(SRC / f"{P}_tick_sq" / "tick_counter_collection.csv", "aecm_tick")
     if sq:
         # instruction issue of the tick kernel per session-tick (2.5 blocks per 16 kHz tick): what a tick costs on top of
         # its blocks (state unpack / pack, table fill, ring appends, output assembly)
         tick["insts_per_session_tick"] = {k: v / 65536 for k, v in sq.items()}
     tick["gpu_ms_per_tick_sum_of_kernels"] = per_tick_ns / 1e6
     try:
-        tick["bench_sessions_line"] = json.loads([ln for ln in (SRC / "prof_tick.log").read_text().splitlines() if ln.startswith("{")][-1])
+        tick["bench_sessions_line"] = json.loads([ln for ln in (SRC / f"{P}_tick.log").read_text().splitlines() if ln.startswith("{")][-1])
     except Exception:
         pass
     summary["streaming_tick"] = tick
