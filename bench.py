@@ -416,9 +416,11 @@ def main():
                          "kernel": kernel_name,
                          "launch_form": {0: "one wavefront per stream (launch resident at once)", 1: "one wavefront per stream",
                                          2: f"chunk queue: items of {chunk} blocks claimed in order by resident wavefronts",
-                                         3: f"pipelined: {4 + (4 if chunk & 0x200 else 2) + (chunk & 0xff)} wavefronts per four streams, the forward transforms one block "
+                                         3: f"pipelined: {4 + (4 if chunk & 0x200 else 2) + (chunk & 0xff) + ((2 if chunk & 0x1000 else 4) if chunk & 0x800 else 0) + (4 if chunk & 0x1000 else 0)} wavefronts per four streams, the forward transforms one block "
                                             f"ahead in {4 if chunk & 0x200 else 2} wavefronts of their own"
                                             + (f", the inverse transforms one block behind in {chunk & 0xff} more" if chunk & 0xff else "")
+                                            + (f", the delay estimator one block ahead in {2 if chunk & 0x1000 else 4} more" if chunk & 0x800 else "")
+                                            + (", the gain half of the block one block behind the channel half in 4 more" if chunk & 0x1000 else "")
                                             + (", spectra formed by the back wavefronts" if chunk & 0x400 else "")
                                             + (", front-wave priorities balanced by progress feedback" if chunk & 0x100 else "")}[form],
                          "kernel_avg_ms": kern_avg_s * 1e3, "algorithmic_bytes_per_frame": algo_bytes,

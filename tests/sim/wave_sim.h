@@ -63,6 +63,7 @@ SIM_BIN(pk_lshr_b16, pk_lshr_b16(x, y))
 SIM_BIN(pk_ashr_i16, pk_ashr_i16(x, y))
 SIM_BIN(pk_min_u16, pk_min_u16(x, y))
 SIM_BIN(pk_add_u16, pk_add_u16(x, y))
+SIM_BIN(pk_add_sat_i16, pk_add_sat_i16(x, y))
 SIM_BIN(pk_max_u16, pk_max_u16(x, y))
 SIM_BIN(pk_sub_sat_u16, pk_sub_sat_u16(x, y))
 SIM_BIN(dot2_i16_c0, dot2_i16_c0(x, y))
@@ -299,6 +300,7 @@ struct SimWave {
 
     static vi load_u32(const uint32_t *p, const vi &idx) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = (int)p[idx.v[i]]; return r; }
     static void store_u32(uint32_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) p[idx.v[i]] = (uint32_t)val.v[i]; }
+    static void store_u32_if(const VecB &m, uint32_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) if (m.v[i]) p[idx.v[i]] = (uint32_t)val.v[i]; }
     static vi load_i16(const int16_t *p, const vi &idx) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = p[idx.v[i]]; return r; }
     static vi load_u16(const uint16_t *p, const vi &idx) { vi r; for (int i = 0; i < 64; ++i) r.v[i] = p[idx.v[i]]; return r; }
     static void store_i16(int16_t *p, const vi &idx, const vi &val) { for (int i = 0; i < 64; ++i) p[idx.v[i]] = (int16_t)val.v[i]; }

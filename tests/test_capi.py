@@ -101,13 +101,14 @@ def test_block_kernel_register_budget(tmp_path):
         assert not re.search(r"buffer_(wbl2|inv)", body), "an agent-scope fence crept into the chunk-queue kernel"
     # The pipelined kernel (launches the chip holds at once; 24 of its waves per CU): the same budget, no scratch; its two
     # roles meet at workgroup barriers only (no polling loops: no s_sleep).
-    for tail_waves, balance, raw, front in ((0, 0, 0, 2), (0, 1, 1, 2), (2, 0, 0, 2), (2, 0, 1, 2), (2, 0, 1, 4)):       # instantiations the launcher uses (template arguments)
-        m = re.search(r"^_ZN4aecm29aecm_process_pipelined_kernelILi%dELb%dELb%dELi%dEEE\w*:.*\n" % (tail_waves, balance, raw, front), text, re.M)
+    for tail_waves, balance, raw, front, delay, gain in ((0, 0, 0, 2, 0, 0), (0, 1, 1, 2, 0, 0), (2, 0, 0, 2, 0, 0), (2, 0, 1, 2, 0, 0), (2, 0, 1, 4, 0, 0),
+                                                         (2, 0, 0, 2, 4, 0), (2, 0, 0, 4, 2, 4)):       # instantiations the launcher uses (template arguments)
+        m = re.search(r"^_ZN4aecm29aecm_process_pipelined_kernelILi%dELb%dELb%dELi%dELi%dELi%dEEE\w*:.*\n" % (tail_waves, balance, raw, front, delay, gain), text, re.M)
         assert m, "pipelined kernel not found in the device assembly"
         body = text[m.end():]
         body = body[:body.index(".end_amdhsa_kernel")]
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
-        assert vgprs <= 72 and not re.search(r"^\s*scratch_(load|store)", body, re.M), (tail_waves, balance, raw, front, vgprs)
+        assert vgprs <= 72 and not re.search(r"^\s*scratch_(load|store)", body, re.M), (tail_waves, balance, raw, front, delay, gain, vgprs)
         assert len(re.findall(r"^\s*s_barrier", body, re.M)) >= 4 and not re.search(r"^\s*s_sleep", body, re.M)
     # The tick kernel: the engine's 64 scalar state words must arrive through scalar loads.  A conditional fence, or a
     # store wider than the rings' int16 (vector types alias everything), ahead of load_state silently turns them into

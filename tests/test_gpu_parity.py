@@ -720,6 +720,46 @@ def test_pipelined_launch_sizes_and_lengths(fs):
         b.close()
 
 
+@pytest.mark.parametrize("wish,shape", [({}, 0x1a02),                                            # by size: sixteen waves (delay + gain waves)
+                                        ({"AECM_PIPE_GAIN": "0"}, 0x802),                       # twelve: delay waves, one per stream
+                                        ({"AECM_PIPE_DELAY": "0"}, 0x2),                        # eight: two tail waves
+                                        ({"AECM_PIPE_DELAY": "0", "AECM_PIPE_RAW": "1"}, 0x402),
+                                        ({"AECM_PIPE_DELAY": "0", "AECM_PIPE_RAW": "1", "AECM_PIPE_FRONT": "4"}, 0x602),
+                                        ({"AECM_PIPE_TAIL": "0"}, 0x0)])                        # six: the two-role form
+def test_pipelined_shapes_by_wish(monkeypatch, wish, shape):
+    """Every instantiation of the pipelined kernel a small launch can be given (the engine reads the AECM_PIPE_* wishes when it is
+    created): 11 streams (the last workgroup has three of its four, a two-stream wave one of its two) through launches of 1, 2,
+    3, 4, 5 and 150 blocks -- each role's idle steps in front of and behind its block loop, the slot rings of two, three and four
+    steps, the fixed-delay configuration (the delay waves' AlignedFarend then never uses the estimate) -- outputs and complete
+    state against the oracle."""
+    for k, v in wish.items():
+        monkeypatch.setenv(k, v)
+    fs, S, T_parts = 16000, 11, (1, 2, 3, 4, 5, 150)
+    T = sum(T_parts)
+    seeds = list(range(7700, 7700 + S))
+    far, near = synth_streams(seeds, T, fs)
+    b = aecm.AecmBatch(S, fs)
+    exp = []
+    for k in range(S):
+        o = pyoracle.OracleStream(fs, *stream_config(k))
+        b.set_config(*stream_config(k), k, 1)
+        if k in (2, 5, 6):                                   # a fixed delay of 0 / 1 / 7 blocks, the last with the NLP off
+            fixed, nlp = {2: (0, 1), 5: (1, 1), 6: (7, 0)}[k]
+            o.control(fixed, nlp)
+            b.control(fixed, nlp, k, 1)
+        exp.append((o.process(far[k], near[k]), o.digest()))
+    outs, pos = [], 0
+    for t in T_parts:
+        assert b.describe_launch(t) == (3, shape)
+        outs.append(b.process_host(far[:, pos * 64:(pos + t) * 64], near[:, pos * 64:(pos + t) * 64]))
+        pos += t
+    out = np.concatenate(outs, axis=1)
+    for k in range(S):
+        assert np.array_equal(out[k], exp[k][0]), (wish, k)
+        assert np.array_equal(b.digest(k), exp[k][1]), (wish, k, describe_digest_diff(b.digest(k), exp[k][1]))
+    b.close()
+
+
 def test_chunk_queue_launch_the_chip_holds_at_once():
     """5 003 streams (between the pipelined form's 4 096 and the chip's 7 168 resident waves): every wave is resident from the
     start and the launch still takes the chunk queue (items of 32 blocks), because the waves dispatched first pull ahead and
@@ -781,14 +821,17 @@ def test_chunk_queue_half_a_million_hand_overs():
 def test_launch_form_by_size():
     """Which kernel a launch takes (WebRtcAecmBatch_DescribeLaunch; INTEGRATION.md has the table): one stream -> one wavefront
     per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant; with two tail waves per
-    workgroup up to 3 x 4 x CUs streams, above that without them and -- in launches long enough -- balanced); more -> chunk queue if
+    workgroup up to 3 x 4 x CUs streams -- and delay and gain waves up to 4 x CUs --, above that without them and -- in launches long enough --
+    balanced); more -> chunk queue if
     the launch is at least two chunks long (chunks of 32 blocks up to the chip's resident waves, of 128 above), else one
     wavefront per stream."""
     cus = aecm.device_info(0)[1]
     pipe_max, resident, rotation = cus * 16, cus * 28, cus * 24
     tail_max = cus * 12                       # eight-wave workgroups (two tail waves) come three to a CU
-    # pipelined launches: the second value is the shape (tail waves | 0x100 balanced | 0x200 four front waves | 0x400 raw hand-over)
-    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 2), (cus * 4, 300, False, 3, 2), (cus * 8, 300, False, 3, 0x602),
+    # pipelined launches: the second value is the shape (tail waves | 0x100 balanced | 0x200 four front waves | 0x400 raw hand-over | 0x800 delay
+    # waves | 0x1000 gain waves)
+    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 0x1a02), (cus * 4, 300, False, 3, 0x1a02), (cus * 4 + 1, 300, False, 3, 0x602),
+                                          (cus * 8, 300, False, 3, 0x602),
                                           (tail_max, 300, False, 3, 0x402), (tail_max + 1, 300, False, 3, 0x500),
                                           (pipe_max, 3, False, 3, 0), (pipe_max, 300, False, 3, 0x500), (pipe_max, 300, True, 0, 0),
                                           (pipe_max + 1, 300, False, 2, 32), (pipe_max + 1, 63, False, 0, 0), (rotation + 1, 63, False, 1, 0),

@@ -47,6 +47,8 @@ def main():
                     help="-DAECM_CENSUS_HOTPATH: steady-state-unreachable branches compiled out, so the block loop is the straight-line "
                          "hot path and its static count approximates the dynamic mix; also prints the fast-class share per phase")
     ap.add_argument("--json", help="write the per-phase counts here")
+    ap.add_argument("--runs", action="store_true", help="also print how the fast-class instructions of the block loop are distributed "
+                    "over uninterrupted runs (a run ends at any other instruction of the wave: slower VALU, SALU, LDS, memory, wait)")
     a = ap.parse_args()
     sys.path.insert(0, str(ROOT))
     from webrtc_aecm_amd import build as B
@@ -75,6 +77,8 @@ def main():
     counts = collections.OrderedDict()
     seen_first = False
     cur = None
+    runs = collections.Counter()          # length of a run of fast-class instructions -> how many such runs (phases 1..13)
+    run = 0
     for i, l in enumerate(lines):
         s = l.strip()
         if "AECM_MARK" in s:
@@ -93,6 +97,11 @@ def main():
         srcs = [x.strip() for x in operands.split(",")[1:]]
         if base in FAST_CLASS and not op.endswith(("_dpp", "_sdwa")) and not any(x.startswith(("s", "vcc", "exec", "m0", "ttmp")) for x in srcs):
             counts[cur]["VALU_fast"] += 1
+            run += 1 if cur <= 13 else 0
+        else:
+            if run:
+                runs[run] += 1
+            run = 0
         if base in SLOW8:
             counts[cur]["VALU_8cyc"] += 1
     tot = collections.Counter()
@@ -103,6 +112,11 @@ def main():
             for k in ("VALU", "VALU_fast", "VALU_8cyc", "SALU", "SCTL", "LDS", "VMEM"):
                 tot[k] += c[k]
     print(f"{'block loop (phases 1..13)':44s} {tot['VALU']:6d} {tot['VALU_fast']:5d} {tot['VALU_8cyc']:5d} {tot['SALU']:6d} {tot['SCTL']:5d} {tot['LDS']:5d} {tot['VMEM']:5d}")
+    if a.runs:
+        n = sum(k * v for k, v in runs.items())
+        print("fast-class instructions by length of their uninterrupted run: " +
+              ", ".join(f"{k}: {v} runs" for k, v in sorted(runs.items())) +
+              f"; in runs of >= 4: {sum(k * v for k, v in runs.items() if k >= 4)} of {n}, >= 7: {sum(k * v for k, v in runs.items() if k >= 7)}")
     if a.json:
         import json
         Path(a.json).write_text(json.dumps({"hot": a.hot, "kernel": a.kernel, "loop_total": dict(tot),

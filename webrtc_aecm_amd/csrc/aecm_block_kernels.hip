@@ -188,7 +188,8 @@ void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blo
 // part, and a SIMD holds 6 waves instead of 4 -- two of them nearly pure vector work that overlaps the others' scalar
 // stretches by construction.  4 workgroups per CU (24 waves, 4 x 27 KB of LDS) = 4 096 streams on 256 CUs, all resident.
 #ifndef AECM_PIPE_FRONT_PRIO
-#define AECM_PIPE_FRONT_PRIO 0        // the front waves' issue priority (the back waves': by phase, 1..3)
+#define AECM_PIPE_FRONT_PRIO 0        // the front waves' issue priority (the back waves': by phase, 1..3).  Also in the sixteen-wave shape,
+                                      // where the front waves are the longest link: 1 / 2 / 3 there cost 10-13 % (1 024 streams 613 -> 549 / 549 / 531)
 #endif
 constexpr int kPipeStreams = 4;
 // kFront front waves per workgroup: 2 (two streams each; the form for launches that fill the chip) or 4 (one stream each: ten-wave
@@ -200,7 +201,18 @@ constexpr int kPipeStreams = 4;
 // waves per workgroup = 28 per CU with four workgroups, every wave slot of the SIMDs taken; kTail = 2: two waves of two
 // streams, eight waves per workgroup, three workgroups per CU (launches of up to 3 072 streams).  The stream's sequential part
 // shrinks once more (what a small launch is bound by) and a SIMD gets one more wave of dense vector work to fill its port with.
-constexpr int PipeWaves(int tail_waves, int front_waves = 2) { return kPipeStreams + front_waves + tail_waves; }
+// A fourth role (round 5, small launches): delay_block -- both binary spectra, the bit histories, the 100 means; a chain of
+// reductions and scalar decisions on state of its own, a sixth of the middle wave's instructions -- in kDelay "delay" waves, one
+// stream each, one block AHEAD of the middle waves (between them and the front waves): the spectra then live for three steps
+// (three slots per stream) and the delay reaches the middle wave through LDS.
+// A fifth (smallest launches: at most one workgroup per CU): the back wave's remaining work in its two halves, channel_block
+// (far history ... channel update: what the next block's echo estimate waits for) and gain_block (suppression gain ... comfort
+// noise: fed by the channel half, otherwise state of its own), the second in kGain "gain" waves one block behind the first.
+// Sixteen waves per four streams then: 4 channel, 4 front, 2 tail, 2 delay (two streams each), 4 gain -- the longest link of the
+// chain is half of what it was.
+constexpr int PipeWaves(int tail_waves, int front_waves = 2, int delay_waves = 0, int gain_waves = 0) {
+    return kPipeStreams + front_waves + tail_waves + delay_waves + gain_waves;
+}
 struct PipeSlot {           // the spectra of one block of one stream on their way from the front to the back wave
     int near_x[kLanes];     // near-end spectrum, bins 0..63: re | im << 16 (im conjugated as the block path uses it)
     int mags[kLanes];       // far-end magnitude | near-end magnitude << 16 (both <= 46 340)
@@ -214,15 +226,49 @@ struct PipeTailSlot {       // the residual spectrum of one block of one stream 
     int a[kLanes], b[kLanes];   // BlockEngine::TailInput
     int clean_q, pad[3];
 };
-template <int kTail, bool kRaw = false>
+struct PipeGainSlot {       // BlockEngine::GainInput on its way from the channel to the gain wave
+    int echo_est[kLanes];
+    int echo_est64, far_q, cur_vad, near0, stored0, pad[3];
+};
+struct PipeGainState {      // the gain wave's part of the stream state on its way to the channel wave, which stores the state (end of the launch)
+    int echo_filt[kLanes], near_filt_ctrs[kLanes], noise_est[kLanes];      // (near_filt | low_ctr << 16 | high_ctr << 19: the V_NEARFILT layout)
+    int scal[16];
+};
+template <int kTail, bool kRaw = false, int kDelay = 0, int kGain = 0>
 struct PipeShared {
-    typename std::conditional<kRaw, PipeRawSlot, PipeSlot>::type slots[2][kPipeStreams];      // [block parity][stream of the workgroup]
+    // [block modulo the ring: 2, + 1 with delay waves, + 1 with gain waves][stream of the workgroup]
+    typename std::conditional<kRaw, PipeRawSlot, PipeSlot>::type slots[2 + (kDelay ? 1 : 0) + (kGain ? 1 : 0)][kPipeStreams];
     PipeTailSlot tails[kTail ? 2 : 1][kTail ? kPipeStreams : 1];
+    int delays[2][kPipeStreams];          // delay_block's result on its way from the delay to the middle wave ...
+    int far_rows[kDelay ? 2 : 1][kDelay ? kPipeStreams : 1][kLanes];      // ... and the far-history row that goes with it (AlignedFarend)
+    PipeGainSlot gains[kGain ? 2 : 1][kGain ? kPipeStreams : 1];
+    PipeGainState gain_state[kGain ? kPipeStreams : 1];
     int ahead;                            // this workgroup leads the launch's slowest one by more than the allowed lead (balance, below)
     int level;                            // the front waves' base priority for the current group of blocks (balance modes 2, 3)
 };
 #ifndef AECM_PIPE_TAIL_PRIO
 #define AECM_PIPE_TAIL_PRIO 1         // the tail waves' issue priority
+#endif
+// Which launches get delay waves when the caller does not say (workgroups of the launch, CUs of the device): those of at most one
+// workgroup per CU (measured: 1 024 streams 403 -> 492 M frames/s, 256 streams 105 -> 124; 1 536 streams 552 -> 370)
+#ifndef AECM_PIPE_DELAY_DEFAULT
+#define AECM_PIPE_DELAY_DEFAULT(n_wg, cus) ((n_wg) <= (cus) ? kPipeStreams : 0)
+#endif
+// Workgroups of the sixteen-wave shape a CU takes (experiments: two of them are 32 waves, eight per SIMD -- the kernel's 61 VGPRs allow it)
+#ifndef AECM_PIPE_GAIN_WGS_PER_CU
+#define AECM_PIPE_GAIN_WGS_PER_CU (PipeWorkgroupsPerCu<2, 4, 2, 4>())
+#endif
+// Which launches get gain waves when the caller does not say: those that get delay waves (at most one workgroup per CU; measured:
+// 1 024 streams 492 -> 612 M frames/s, 256 streams 124 -> 155, 64 streams 31 -> 39; two such workgroups per CU -- 32 waves -- lose
+// against the ten-wave shape: 2 048 streams 620 vs 740)
+#ifndef AECM_PIPE_GAIN_DEFAULT
+#define AECM_PIPE_GAIN_DEFAULT(n_wg, cus) ((n_wg) <= (cus) ? kPipeStreams : 0)
+#endif
+#ifndef AECM_PIPE_GAIN_PRIO
+#define AECM_PIPE_GAIN_PRIO 3         // the gain waves' issue priority (1 / 2 / 3: 1 024 streams 594 / 607 / 613 M frames/s)
+#endif
+#ifndef AECM_PIPE_DELAY_PRIO
+#define AECM_PIPE_DELAY_PRIO 1        // the delay waves' issue priority
 #endif
 
 // Balance.  Every workgroup of a pipelined launch is resident from the start and has the same amount of work, but the SIMD's
@@ -282,9 +328,11 @@ __device__ __forceinline__ void SetPrioDynamic(int p) {      // s_setprio takes 
     else __builtin_amdgcn_s_setprio(3);
 }
 constexpr int kPipeGroupLog2 = AECM_PIPE_BALANCE_GROUP_LOG2, kPipeGroupMask = (1 << kPipeGroupLog2) - 1;
-constexpr int kPipeTraceWaves = 8;        // per-wave records per workgroup in the diagnostics build (the largest workgroup)
+constexpr int kPipeTraceWaves = 16;       // per-wave records per workgroup in the diagnostics build (the largest workgroup has 14)
 constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of up to 1 024 workgroups (4 096 streams) are balanced, larger ones run as before
 
+// (With delay waves everything behind the front waves is one step later: the delay waves work on block s - 1, the middle
+// waves on block s - 2 out of slots[(s - 2) % 3], the tail waves on block s - 3; n_blocks + 3 barriers.)
 // Synchronisation: ONE workgroup barrier per step.  In step s the front waves write the spectra of block s into slots[s & 1],
 // the middle (back) waves work on block s - 1 out of slots[(s - 1) & 1] and, with tail waves, leave its residual spectrum in
 // tails[(s - 1) & 1], which the tail waves turn into output samples in step s + 1.  Every wave of the workgroup executes
@@ -309,8 +357,8 @@ constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of 
 #ifndef AECM_PIPE_RAW_HANDOVER
 #define AECM_PIPE_RAW_HANDOVER 1
 #endif
-template <int kTail, bool kBalance, bool kRaw = false, int kFront = 2>
-__global__ __launch_bounds__(64 * PipeWaves(kTail, kFront))
+template <int kTail, bool kBalance, bool kRaw = false, int kFront = 2, int kDelay = 0, int kGain = 0>
+__global__ __launch_bounds__(64 * PipeWaves(kTail, kFront, kDelay, kGain))
 __attribute__((amdgpu_waves_per_eu(kTail == 1 ? AECM_PIPE_TAIL1_WAVES_PER_EU : AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, uint32_t *progress, int n_workgroups) {
     constexpr int kMode = kBalance ? AECM_PIPE_BALANCE : 0;               // AECM_PIPE_BALANCE's meaning, per instantiation
@@ -324,8 +372,12 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #else
 #define AECM_PIPE_BARRIER() __syncthreads()
 #endif
-    constexpr int kWaves = PipeWaves(kTail, kFront), kPipeFrontWaves = kFront, kPipeStreamsPerFront = kPipeStreams / kFront;
-    PipeShared<kTail, kRaw> &sh = *reinterpret_cast<PipeShared<kTail, kRaw> *>(&g_lds[1]);        // behind the tables
+    static_assert(kDelay == 0 || ((kDelay == kPipeStreams || kDelay == 2) && kTail != 0 && !kRaw && !kBalance), "delay waves: in the two-tail shapes with formed spectra");
+    static_assert(kGain == 0 || (kGain == kPipeStreams && kDelay != 0), "gain waves: one per stream, with delay waves");
+    constexpr int kWaves = PipeWaves(kTail, kFront, kDelay, kGain), kPipeFrontWaves = kFront, kPipeStreamsPerFront = kPipeStreams / kFront;
+    constexpr int kLagD = kDelay ? 1 : 0, kLagG = kGain ? 1 : 0;           // steps the delay / gain waves put between the front waves and the rest
+    constexpr int kSlots = 2 + kLagD + kLagG;
+    PipeShared<kTail, kRaw, kDelay, kGain> &sh = *reinterpret_cast<PipeShared<kTail, kRaw, kDelay, kGain> *>(&g_lds[1]);        // behind the tables
     if (kMode != 0 && threadIdx.x == 0) { sh.ahead = 0; sh.level = kFrontBehind; }
     FillLdsTables<64 * kWaves>(st.consts);                              // ends in a barrier
     using W = Gfx950Wave<true, true, false, false, kMode == 1>;
@@ -347,7 +399,9 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
         r.u.prio_drop = 0;
         W::begin_stream();
         AECM_PIPE_BARRIER();                                              // step 0: the spectra of block 0 are in slots[0]
-        for (int blk = 0; blk < n_blocks; ++blk) {                        // step blk + 1
+        if (kDelay != 0) AECM_PIPE_BARRIER();                             // step 1: the delay waves' first
+        int slot_idx = 0;                                                 // blk mod kSlots
+        for (int blk = 0; blk < n_blocks; ++blk) {                        // step blk + 1 (+ 1 with delay waves)
             // Balance, mode 1 (see above): the monitor wrote the flag at the end of its step blk, which ran next to this wave's
             // block blk - 1 and ended in the barrier this wave has just passed.
             if (kMode == 1 && (blk & kPipeGroupMask) == 0 && blk != 0) r.u.prio_drop = __builtin_amdgcn_readfirstlane(sh.ahead);
@@ -356,13 +410,13 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 typename E::Spectrum xf, df;
                 r.table_index = W::table_index_for_this_block();
                 if constexpr (kRaw) {
-                    const PipeRawSlot &slot = sh.slots[blk & 1][wave];
+                    const PipeRawSlot &slot = sh.slots[slot_idx][wave];
                     const int fa0 = slot.fa[0][lane], fb0 = slot.fb[0][lane], fa1 = slot.fa[1][lane], fb1 = slot.fb[1][lane];
                     const int q0 = __builtin_amdgcn_readfirstlane(slot.q[0]), q1 = __builtin_amdgcn_readfirstlane(slot.q[1]);
                     E::spectrum(r, fa0, fb0, q0, xf);
                     E::spectrum(r, fa1, fb1, q1, df);
                 } else {
-                    const PipeSlot &slot = sh.slots[blk & 1][wave];
+                    const PipeSlot &slot = sh.slots[slot_idx][wave];
                     const int x = slot.near_x[lane], m = slot.mags[lane], sc = slot.scalars[lane];
                     xf.mag = zext16(m);
                     xf.mag64 = __builtin_amdgcn_readlane(sc, 0);
@@ -378,20 +432,51 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 }
                 E::update_startup(r.u);
                 if constexpr (kTail != 0) {
-                    const typename E::TailInput t = E::middle_block(r, hist, xf, df, df);
-                    PipeTailSlot &ts = sh.tails[blk & 1][wave];
-                    ts.a[lane] = t.a;
-                    ts.b[lane] = t.b;
-                    if (lane == 0) ts.clean_q = t.clean_q;
+                    int delay_given = 0, far_given = 0;
+                    if constexpr (kDelay != 0) {
+                        delay_given = __builtin_amdgcn_readfirstlane(sh.delays[blk & 1][wave]);
+                        far_given = sh.far_rows[blk & 1][wave][lane];
+                    }
+                    if constexpr (kGain != 0) {
+                        W::template phase_priority<3>(r.u.prio_drop);
+                        E::track_q(r.u, df, df);
+                        const typename E::GainInput g = E::template channel_block<true>(r, hist, xf, df, delay_given, far_given);
+                        PipeGainSlot &gs = sh.gains[blk & 1][wave];
+                        gs.echo_est[lane] = g.echo_est;
+                        if (lane == 0) { gs.echo_est64 = g.echo_est64; gs.far_q = g.far_q; gs.cur_vad = g.cur_vad; gs.near0 = g.near0; gs.stored0 = g.stored0; }
+                    } else {
+                        const typename E::TailInput t = E::template middle_block<kDelay != 0>(r, hist, xf, df, df, delay_given, far_given);
+                        PipeTailSlot &ts = sh.tails[blk & 1][wave];
+                        ts.a[lane] = t.a;
+                        ts.b[lane] = t.b;
+                        if (lane == 0) ts.clean_q = t.clean_q;
+                    }
                 } else {
                     const int out = E::back_block(r, hist, xf, df, df);
                     sio.out(r, blk, out);
                 }
             }
+            slot_idx = slot_idx + 1 == kSlots ? 0 : slot_idx + 1;
             AECM_PIPE_BARRIER();                                          // slots[blk & 1] are free again, block blk + 1 is in the others
         }
+        if (kGain != 0) AECM_PIPE_BARRIER();                              // the gain waves' last step
         if (kTail != 0) AECM_PIPE_BARRIER();                              // the tail waves' last step
-        if (live) E::template store_state<false, kTail == 0>(r, vec, scal);
+        if constexpr (kGain != 0) {
+            AECM_PIPE_BARRIER();                                          // the gain wave's part of the state is in gain_state
+            if (live) {
+                const int lane = W::lane_id();
+                const PipeGainState &g = sh.gain_state[wave];
+                const int nf = g.near_filt_ctrs[lane];
+                r.b.echo_filt = g.echo_filt[lane];
+                r.b.near_filt = sext16(nf); r.b.low_ctr = lsr(nf, 16) & 7; r.b.high_ctr = lsr(nf, 19) & 7;
+                r.b.noise_est = g.noise_est[lane];
+                Uniform &u = r.u;
+                auto S = [&](int i) { return __builtin_amdgcn_readfirstlane(g.scal[i]); };
+                u.seed = S(0); u.sup_gain = S(1); u.sup_gain_old = S(2); u.noise_ctr = S(3);
+                r.b64.echo_filt = S(4); r.b64.near_filt = S(5); r.b64.noise_est = S(6); r.b64.low_ctr = S(7); r.b64.high_ctr = S(8);
+            }
+        }
+        if (live) E::template store_state<false, kTail == 0, kDelay == 0>(r, vec, scal);
     } else if (wave < kPipeStreams + kPipeFrontWaves) {
         // ---- front wave: two streams, the transforms of the block after the one their back waves are at ----
         typename EF::Regs r;
@@ -412,6 +497,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 near_next[k] = sio.near(r, 0);
             }
         }
+        int slot_idx = 0;                                                 // blk mod kSlots
         for (int blk = 0; blk <= n_blocks; ++blk) {                      // step blk writes block blk (the last step: nothing)
             // Balance: the monitor's step at a group boundary (see above).  pv[] is only ever read under the condition it is
             // loaded under (no initialisation: a register written by a move while a load of an earlier trip may still be
@@ -461,14 +547,14 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                     if constexpr (kRaw) {
                         int fa[2], fb[2], q[2];
                         EF::front_transforms(r, x_old[k], far_cur, d_old[k], near_cur, fa, fb, q);
-                        PipeRawSlot &slot = sh.slots[blk & 1][k0 + k];
+                        PipeRawSlot &slot = sh.slots[slot_idx][k0 + k];
                         slot.fa[0][lane] = fa[0]; slot.fb[0][lane] = fb[0];
                         slot.fa[1][lane] = fa[1]; slot.fb[1][lane] = fb[1];
                         if (lane == 0) { slot.q[0] = q[0]; slot.q[1] = q[1]; }
                     } else {
                         typename EF::Spectrum xf, df, cf;
                         EF::front_block(r, x_old[k], far_cur, d_old[k], near_cur, 0, 0, xf, df, cf);
-                        PipeSlot &slot = sh.slots[blk & 1][k0 + k];
+                        PipeSlot &slot = sh.slots[slot_idx][k0 + k];
                         slot.near_x[lane] = (df.re & 0xffff) | (int)((unsigned)df.im << 16);
                         slot.mags[lane] = xf.mag | (int)((unsigned)df.mag << 16);
                         int sc = 0;
@@ -510,12 +596,16 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 else
                     sh.level = sh.ahead ? AECM_PIPE_FRONT_PRIO : kFrontBehind;
             }
+            slot_idx = slot_idx + 1 == kSlots ? 0 : slot_idx + 1;
             AECM_PIPE_BARRIER();
         }
+        if (kDelay != 0) AECM_PIPE_BARRIER();                             // the middle waves' last step
+        if (kGain != 0) AECM_PIPE_BARRIER();                              // the gain waves' last step
         if (kTail != 0) AECM_PIPE_BARRIER();                              // the tail waves' last step
+        if (kGain != 0) AECM_PIPE_BARRIER();                              // (state hand-over of the gain waves)
         for (int k = 0; k < kPipeStreamsPerFront; ++k)
             if (live[k]) EF::store_time_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
-    } else {
+    } else if (wave < kPipeStreams + kPipeFrontWaves + kTail) {
         // ---- tail wave: kPipeStreams / kTail streams, inverse transform + synthesis + output of the block BEFORE the one the middle waves are at ----
         constexpr int kPer = kTail ? kPipeStreams / kTail : 1;
         typename EF::Regs r;
@@ -531,9 +621,11 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             ovl[k] = c_old[k] = 0;
             if (live[k]) EF::load_tail_state(st.vec + stream * (int64_t)kVecWordsPerStream, r.lane, ovl[k], c_old[k]);
         }
-        AECM_PIPE_BARRIER();                                              // steps 0 and 1: nothing to do yet
+        AECM_PIPE_BARRIER();                                              // steps 0 and 1 (and 2 with delay waves): nothing to do yet
         AECM_PIPE_BARRIER();
-        for (int blk = 0; blk < n_blocks; ++blk) {                        // step blk + 2
+        if (kDelay != 0) AECM_PIPE_BARRIER();
+        if (kGain != 0) AECM_PIPE_BARRIER();
+        for (int blk = 0; blk < n_blocks; ++blk) {                        // step blk + 2 (+ 1 with delay waves, + 1 with gain waves)
 #pragma unroll
             for (int k = 0; k < kPer; ++k) {
                 if (!live[k]) continue;
@@ -550,27 +642,185 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             }
             AECM_PIPE_BARRIER();
         }
+        if (kGain != 0) AECM_PIPE_BARRIER();                              // (state hand-over of the gain waves)
         for (int k = 0; k < kPer; ++k)
             if (live[k]) EF::store_tail_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, ovl[k], c_old[k]);
+    } else if constexpr (kDelay != 0) {
+        if (wave < kPipeStreams + kPipeFrontWaves + kTail + kDelay) {
+            // ---- delay wave: kPipeStreams / kDelay streams, the delay estimator of the block AFTER the one their channel waves are at ----
+            constexpr int kPer = kPipeStreams / kDelay;
+            typename EF::Regs r;
+            EF::init_lane_constants(r, st.consts);
+            r.u.prio_drop = 0;
+            __builtin_amdgcn_s_setprio(AECM_PIPE_DELAY_PRIO);
+            const int k0 = (wave - (kPipeStreams + kPipeFrontWaves + kTail)) * kPer;
+            // the estimator's state per stream (BlockEngine::load_delay_state's fields), moved into r around each call
+            int mean[kPer], bh0[kPer], bh1[kPer], m01[kPer], far_init[kPer], near_init[kPer], min_prob[kPer], last_prob[kPer], last_delay[kPer];
+            int hist_pos[kPer], fixed_delay[kPer];                        // the channel wave's u.hist_pos, followed here
+            bool live[kPer];
+            auto swap_in = [&](int k) {
+                r.mean = mean[k]; r.bh0 = bh0[k]; r.bh1 = bh1[k]; r.m01 = m01[k];
+                r.u.far_init = far_init[k]; r.u.near_init = near_init[k]; r.u.min_prob = min_prob[k]; r.u.last_prob = last_prob[k];
+                r.u.last_delay = last_delay[k]; r.u.fixed_delay = fixed_delay[k];
+            };
+            auto swap_out = [&](int k) {
+                mean[k] = r.mean; bh0[k] = r.bh0; bh1[k] = r.bh1; m01[k] = r.m01;
+                far_init[k] = r.u.far_init; near_init[k] = r.u.near_init; min_prob[k] = r.u.min_prob; last_prob[k] = r.u.last_prob;
+                last_delay[k] = r.u.last_delay;
+            };
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int64_t stream = first + k0 + k;
+                live[k] = stream < n_streams;
+                hist_pos[k] = 0; fixed_delay[k] = -1;
+                r.mean = r.bh0 = r.bh1 = r.m01 = 0;
+                r.u.far_init = r.u.near_init = r.u.min_prob = r.u.last_prob = r.u.last_delay = 0;
+                if (live[k]) {
+                    const int32_t *scal = st.scal + stream * (int64_t)kNumScal;
+                    EF::load_delay_state(r, st.vec + stream * (int64_t)kVecWordsPerStream, scal);
+                    hist_pos[k] = __builtin_amdgcn_readfirstlane(scal[S_HISTPOS]);
+                    fixed_delay[k] = __builtin_amdgcn_readfirstlane(scal[S_FIXED_DELAY]);
+                }
+                swap_out(k);
+            }
+            AECM_PIPE_BARRIER();                                          // step 0: nothing to do yet
+            int slot_idx = 0, slot_before = kSlots - 1;
+            for (int blk = 0; blk < n_blocks; ++blk) {                    // step blk + 1
+                const int lane = W::lane_id();
+                int far[kPer];
+                bool fetch[kPer];
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    fetch[k] = false;
+                    if (!live[k]) continue;
+                    const PipeSlot &slot = sh.slots[slot_idx][k0 + k];
+                    const int m = slot.mags[lane], sc = slot.scalars[lane];
+                    typename EF::Spectrum xf, df;
+                    xf.mag = zext16(m);
+                    xf.q = __builtin_amdgcn_readlane(sc, 1);
+                    df.mag = lsr(m, 16);
+                    df.q = __builtin_amdgcn_readlane(sc, 4);
+                    r.table_index = Gfx950Wave<true, false>::table_index_for_this_block();
+                    swap_in(k);
+                    const int estimate = EF::delay_block(r, xf, df);
+                    swap_out(k);
+                    if (lane == 0) sh.delays[blk & 1][k0 + k] = estimate;
+                    // AlignedFarend for the channel wave: the history row it would fetch next step.  The row of the block before this
+                    // one is being written in this very step -- but that block's spectrum is still in its slot; older rows are in
+                    // memory (written at least one barrier ago, or by an earlier launch); a delay of 0 is the block's own spectrum,
+                    // which the channel wave has.
+                    hist_pos[k] = hist_pos[k] + 1 >= kHistory ? 0 : hist_pos[k] + 1;
+                    const int delay = EF::effective_delay(r.u, estimate);
+                    fetch[k] = delay != 0;
+                    if (delay != 0) {
+                        const uint16_t *hist = st.hist + (first + k0 + k) * (int64_t)kHistWordsPerStream;
+                        if (delay == 1 && blk > 0) far[k] = zext16(sh.slots[slot_before][k0 + k].mags[lane]);
+                        else far[k] = Gfx950Wave<true, false>::load_u16(hist + EF::aligned_slot(hist_pos[k], delay) * kLanes, lane);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kPer; ++k)                            // (the stores after every stream's fetch is under way)
+                    if (fetch[k]) sh.far_rows[blk & 1][k0 + k][lane] = far[k];
+                slot_before = slot_idx;
+                slot_idx = slot_idx + 1 == kSlots ? 0 : slot_idx + 1;
+                AECM_PIPE_BARRIER();
+            }
+            AECM_PIPE_BARRIER();                                          // the channel waves' last step
+            if (kGain != 0) AECM_PIPE_BARRIER();                          // the gain waves' last step
+            if (kTail != 0) AECM_PIPE_BARRIER();                          // the tail waves' last step
+            if (kGain != 0) AECM_PIPE_BARRIER();                          // (state hand-over of the gain waves)
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                if (!live[k]) continue;
+                swap_in(k);
+                EF::store_delay_state(r, st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, st.scal + (first + k0 + k) * (int64_t)kNumScal);
+            }
+        } else if constexpr (kGain != 0) {
+            // ---- gain wave: one stream, gain_block of the block BEFORE the one its channel wave is at ----
+            typename EF::Regs r;
+            EF::init_lane_constants(r, st.consts);
+            r.u.prio_drop = 0;
+            __builtin_amdgcn_s_setprio(AECM_PIPE_GAIN_PRIO);
+            const int k = wave - (kPipeStreams + kPipeFrontWaves + kTail + kDelay);
+            const int64_t stream = first + k;
+            const bool live = stream < n_streams;
+            if (live) EF::load_state(r, st.vec + stream * (int64_t)kVecWordsPerStream, st.scal + stream * (int64_t)kNumScal);
+            AECM_PIPE_BARRIER();                                          // steps 0, 1, 2: nothing to do yet
+            AECM_PIPE_BARRIER();
+            AECM_PIPE_BARRIER();
+            int slot_idx = 0;
+            for (int blk = 0; blk < n_blocks; ++blk) {                    // step blk + 3
+                if (live) {
+                    const int lane = W::lane_id();
+                    const PipeSlot &slot = sh.slots[slot_idx][k];
+                    const int x = slot.near_x[lane], m = slot.mags[lane], sc = slot.scalars[lane];
+                    typename EF::Spectrum df;
+                    df.re = sext16(x);
+                    df.im = sar(x, 16);
+                    df.mag = lsr(m, 16);
+                    df.re64 = __builtin_amdgcn_readlane(sc, 2);
+                    df.mag64 = __builtin_amdgcn_readlane(sc, 3);
+                    df.q = __builtin_amdgcn_readlane(sc, 4);
+                    const PipeGainSlot &gs = sh.gains[blk & 1][k];
+                    typename EF::GainInput g;
+                    g.echo_est = gs.echo_est[lane];
+                    g.echo_est64 = __builtin_amdgcn_readfirstlane(gs.echo_est64);
+                    g.far_q = __builtin_amdgcn_readfirstlane(gs.far_q);
+                    g.cur_vad = __builtin_amdgcn_readfirstlane(gs.cur_vad);
+                    g.near0 = __builtin_amdgcn_readfirstlane(gs.near0);
+                    g.stored0 = __builtin_amdgcn_readfirstlane(gs.stored0);
+                    r.table_index = Gfx950Wave<true, false>::table_index_for_this_block();
+                    EF::track_q(r.u, df, df);
+                    const typename EF::TailInput t = EF::gain_block(r, df, df, g);
+                    PipeTailSlot &ts = sh.tails[blk & 1][k];
+                    ts.a[lane] = t.a;
+                    ts.b[lane] = t.b;
+                    if (lane == 0) ts.clean_q = t.clean_q;
+                }
+                slot_idx = slot_idx + 1 == kSlots ? 0 : slot_idx + 1;
+                AECM_PIPE_BARRIER();
+            }
+            if (live) {                                                   // this wave's part of the state -> the channel wave (which stores the state)
+                const int lane = W::lane_id();
+                PipeGainState &g = sh.gain_state[k];
+                g.echo_filt[lane] = r.b.echo_filt;
+                g.near_filt_ctrs[lane] = zext16(r.b.near_filt) | shl(r.b.low_ctr & 7, 16) | shl(r.b.high_ctr & 7, 19);
+                g.noise_est[lane] = r.b.noise_est;
+                if (lane == 0) {
+                    const Uniform &u = r.u;
+                    g.scal[0] = u.seed; g.scal[1] = u.sup_gain; g.scal[2] = u.sup_gain_old; g.scal[3] = u.noise_ctr;
+                    g.scal[4] = r.b64.echo_filt; g.scal[5] = r.b64.near_filt; g.scal[6] = r.b64.noise_est; g.scal[7] = r.b64.low_ctr; g.scal[8] = r.b64.high_ctr;
+                }
+            }
+            if (kTail != 0) AECM_PIPE_BARRIER();                          // the tail waves' last step
+            AECM_PIPE_BARRIER();                                          // (state hand-over)
+        }
     }
 #if defined(AECM_PIPE_TRACE)
     if ((threadIdx.x & 63u) == 0) {
         uint64_t *tr = reinterpret_cast<uint64_t *>(progress + 2 * ((n_workgroups + 3) / 4) * 2) + ((size_t)blockIdx.x * kPipeTraceWaves + wave) * 4;
-        tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = trace_wait; tr[3] = clock64() - trace_c0;
+        // where the wave ran: HW_ID (wave slot 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13) above bit 40 of the wait count, XCC_ID above bit 40 of the total
+        const uint64_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = (trace_wait & ((1ull << 40) - 1)) | ((hw_id & 0xffffff) << 40);
+        tr[3] = ((clock64() - trace_c0) & ((1ull << 40) - 1)) | ((xcc_id & 0xf) << 40);
     }
 #endif
 }
 #undef AECM_PIPE_BARRIER
 
 // Streams a pipelined launch keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
-template <int kTail, int kFront = 2>
+template <int kTail, int kFront = 2, int kDelay = 0, int kGain = 0>
 constexpr int PipeWorkgroupsPerCu() {
-    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / PipeWaves(kTail, kFront), by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + sizeof(PipeShared<kTail, true>)));
+    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / PipeWaves(kTail, kFront, kDelay, kGain);
+    constexpr int by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + (kDelay ? sizeof(PipeShared<kTail, false, kDelay, kGain>) : sizeof(PipeShared<kTail, true>))));
     return by_waves < by_lds ? by_waves : by_lds;
 }
 // Streams a pipelined launch of this shape keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
-int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves) {
-    const int per_cu = tail_waves == 0 ? PipeWorkgroupsPerCu<0>() : front_waves == 4 ? PipeWorkgroupsPerCu<2, 4>() : PipeWorkgroupsPerCu<2>();
+int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves, int delay_waves, int gain_waves) {
+    const int per_cu = tail_waves == 0 ? PipeWorkgroupsPerCu<0>()
+                       : gain_waves != 0 ? AECM_PIPE_GAIN_WGS_PER_CU
+                       : delay_waves != 0 ? (front_waves == 4 ? PipeWorkgroupsPerCu<2, 4, 4>() : PipeWorkgroupsPerCu<2, 2, 4>())
+                       : front_waves == 4 ? PipeWorkgroupsPerCu<2, 4>() : PipeWorkgroupsPerCu<2>();
     return (compute_units > 0 ? compute_units : 256) * per_cu * kPipeStreams;
 }
 
@@ -580,10 +830,10 @@ int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves) {
 //   up to three per CU            (3 072)                     two tail waves, raw hand-over                    735 -> 795
 //   more (four per CU: 4 096)                                 balance + raw hand-over (launches of >= 128 blocks)  816 -> 863
 // tail_waves / front_waves / raw < 0: by this table; otherwise the caller's wish where the shape exists and fits (experiments).
-PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves, int front_waves, int raw) {
+PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves, int front_waves, int raw, int delay_waves, int gain_waves) {
     const int cus = compute_units > 0 ? compute_units : 256;
     const int n_wg = (n_streams + kPipeStreams - 1) / kPipeStreams;
-    PipeShape sh{0, 2, false, false};
+    PipeShape sh{0, 2, false, false, 0, 0};
     const int want_tail = tail_waves < 0 ? 2 : tail_waves;
     if (want_tail >= 2 && n_streams <= PipelinedStreamLimit(cus, 2, 2)) sh.tail_waves = 2;
     const int want_front = front_waves < 0 ? (n_wg > cus ? 4 : 2) : front_waves;
@@ -593,13 +843,27 @@ PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int 
     // the raw form exists for: the balanced shape, and the two-tail shapes
     sh.raw = want_raw && (sh.balance || sh.tail_waves == 2);
     if (sh.balance && !want_raw) sh.balance = false;          // (no balanced instantiation without the raw hand-over)
+    // delay waves: the two-tail shapes with formed spectra
+    const int want_delay = delay_waves < 0 ? AECM_PIPE_DELAY_DEFAULT(n_wg, cus) : delay_waves;
+    if (want_delay != 0 && sh.tail_waves == 2 && (raw < 0 || raw == 0) && n_streams <= PipelinedStreamLimit(cus, 2, 2, kPipeStreams)) {
+        sh.front_waves = 2;
+        sh.delay_waves = kPipeStreams;
+        sh.raw = false;
+        // gain waves: the sixteen-wave shape (four front waves, two delay waves)
+        const int want_gain = gain_waves < 0 ? AECM_PIPE_GAIN_DEFAULT(n_wg, cus) : gain_waves;
+        if (want_gain != 0 && (front_waves < 0 || front_waves == 4) && n_streams <= PipelinedStreamLimit(cus, 2, 4, 2, kPipeStreams)) {
+            sh.gain_waves = kPipeStreams;
+            sh.front_waves = 4;
+            sh.delay_waves = 2;
+        }
+    }
     return sh;
 }
 
 hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, const PipeShape &shape, uint32_t *progress,
                                         hipStream_t stream) {
     if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
-    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * PipeWaves(shape.tail_waves, shape.front_waves));
+    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * PipeWaves(shape.tail_waves, shape.front_waves, shape.delay_waves, shape.gain_waves));
     if (shape.balance) {
         if (!progress) return hipErrorInvalidValue;
         const hipError_t e = hipMemsetAsync(progress, 0, PipelinedControlBytes(n_streams), stream);
@@ -608,17 +872,18 @@ hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, i
 #if !defined(AECM_PIPE_TRACE)
     if (!shape.balance) progress = nullptr;
 #endif
-#define AECM_LAUNCH_PIPE(T, B, R, F) hipLaunchKernelGGL((aecm_process_pipelined_kernel<T, B, R, F>), grid, block, sizeof(LdsTables) + sizeof(PipeShared<T, R>), \
-                                                        stream, st, io, n_streams, n_blocks, progress, (int)grid.x)
+#define AECM_LAUNCH_PIPE(T, B, R, F, D, G) hipLaunchKernelGGL((aecm_process_pipelined_kernel<T, B, R, F, D, G>), grid, block, sizeof(LdsTables) + sizeof(PipeShared<T, R, D, G>), \
+                                                              stream, st, io, n_streams, n_blocks, progress, (int)grid.x)
     // The instantiations the library carries (PipelinedShapeFor only ever asks for these).  One tail wave for four streams (kTail = 1,
     // seven-wave workgroups) measured slower than its neighbours at every size and is not built.
-    const int key = shape.tail_waves * 100 + shape.front_waves * 10 + (shape.raw ? 1 : 0);
-    if (shape.balance) { if (key != 21) return hipErrorInvalidValue; AECM_LAUNCH_PIPE(0, true, true, 2); }
-    else if (key == 20) AECM_LAUNCH_PIPE(0, false, false, 2);
-    else if (key == 220) AECM_LAUNCH_PIPE(2, false, false, 2);
-    else if (key == 221) AECM_LAUNCH_PIPE(2, false, true, 2);
-    else if (key == 241) AECM_LAUNCH_PIPE(2, false, true, 4);
-    else if (key == 240) AECM_LAUNCH_PIPE(2, false, false, 4);
+    const int key = shape.gain_waves * 10000 + shape.delay_waves * 1000 + shape.tail_waves * 100 + shape.front_waves * 10 + (shape.raw ? 1 : 0);
+    if (shape.balance) { if (key != 21) return hipErrorInvalidValue; AECM_LAUNCH_PIPE(0, true, true, 2, 0, 0); }
+    else if (key == 20) AECM_LAUNCH_PIPE(0, false, false, 2, 0, 0);
+    else if (key == 220) AECM_LAUNCH_PIPE(2, false, false, 2, 0, 0);
+    else if (key == 221) AECM_LAUNCH_PIPE(2, false, true, 2, 0, 0);
+    else if (key == 241) AECM_LAUNCH_PIPE(2, false, true, 4, 0, 0);
+    else if (key == 4220) AECM_LAUNCH_PIPE(2, false, false, 2, 4, 0);
+    else if (key == 42240) AECM_LAUNCH_PIPE(2, false, false, 4, 2, 4);
     else return hipErrorInvalidValue;
 #undef AECM_LAUNCH_PIPE
     return hipGetLastError();

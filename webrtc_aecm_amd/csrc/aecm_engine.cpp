@@ -41,6 +41,8 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     if (const char *env = getenv("AECM_PIPE_FRONT")) e->pipe_front_ = atoi(env);
     if (const char *env = getenv("AECM_PIPE_TAIL")) e->pipe_tail_ = atoi(env);
     if (const char *env = getenv("AECM_PIPE_RAW")) e->pipe_raw_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_DELAY")) e->pipe_delay_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_GAIN")) e->pipe_gain_ = atoi(env);
     if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
@@ -214,7 +216,7 @@ bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count,
     if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
 #endif
     {
-        const PipeShape shape = PipelinedShapeFor(count, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_);
+        const PipeShape shape = PipelinedShapeFor(count, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_, pipe_delay_, pipe_gain_);
         bool need_ctl = shape.balance;
 #if defined(AECM_PIPE_TRACE)
         need_ctl = true;                      // (the diagnostics build keeps the buffer: its per-wave records live behind the progress words)
@@ -251,9 +253,9 @@ int BatchEngine::DescribeLaunch(int num_blocks, bool has_clean, int *chunk_block
     if (chunk_blocks) *chunk_blocks = 0;
     if (PipelinedLaunchApplies(num_streams_, has_clean, false)) {
         // (for this form: the tail waves per workgroup, + 0x100 when the launch balances its workgroups' progress, + 0x200 with
-        // four front waves, + 0x400 with the raw hand-over: the kernel's template arguments)
-        const PipeShape sh = PipelinedShapeFor(num_streams_, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_);
-        if (chunk_blocks) *chunk_blocks = sh.tail_waves | (sh.balance ? 0x100 : 0) | (sh.front_waves == 4 ? 0x200 : 0) | (sh.raw ? 0x400 : 0);
+        // four front waves, + 0x400 with the raw hand-over, + 0x800 with delay waves, + 0x1000 with gain waves: the kernel's template arguments)
+        const PipeShape sh = PipelinedShapeFor(num_streams_, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_, pipe_delay_, pipe_gain_);
+        if (chunk_blocks) *chunk_blocks = sh.tail_waves | (sh.balance ? 0x100 : 0) | (sh.front_waves == 4 ? 0x200 : 0) | (sh.raw ? 0x400 : 0) | (sh.delay_waves ? 0x800 : 0) | (sh.gain_waves ? 0x1000 : 0);
         return 3;
     }
     return variant_ == kVariantFast && num_streams_ > rotation_limit_ ? 1 : 0;

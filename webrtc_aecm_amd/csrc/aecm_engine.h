@@ -94,7 +94,7 @@ private:
     // The pipelined form of launches the chip holds at once: from pipe_min_streams_ (AECM_PIPELINED; SetLaunchPipelining)
     // up to PipelinedStreamLimit of the device.
     int pipe_min_streams_ = kDefaultPipelinedMinStreams, pipe_max_streams_ = 0;
-    int pipe_tail_ = -1, pipe_front_ = -1, pipe_raw_ = -1;      // shape overrides (AECM_PIPE_TAIL / _FRONT / _RAW); < 0: by size
+    int pipe_tail_ = -1, pipe_front_ = -1, pipe_raw_ = -1, pipe_delay_ = -1, pipe_gain_ = -1;      // shape overrides (AECM_PIPE_TAIL / _FRONT / _RAW / _DELAY / _GAIN); < 0: by size
     bool PipelinedLaunchApplies(int count, bool clean, bool ragged) const;
     bool LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev);
     int QueueMinStreams() const;

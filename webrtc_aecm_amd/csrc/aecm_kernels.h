@@ -47,10 +47,13 @@ struct PipeShape {
     int front_waves;     // 2 (two streams each) or 4 (one each; with tail waves only)
     bool raw;            // the front waves hand over the transforms' outputs, the back waves form the spectra
     bool balance;        // progress feedback on the front waves' issue priority (needs `progress`)
+    int delay_waves;     // 0, 4 or (with gain waves) 2 per workgroup: the delay estimator in waves of its own, one block ahead of the back waves (with tail waves, not raw)
+    int gain_waves;      // 0 or 4 per workgroup: the gain half of the back waves' work in waves of its own, one block behind the channel half (with delay waves)
 };
 // The shape a launch of this size takes; tail_waves / front_waves / raw < 0 = by size, else the caller's wish where it exists and fits.
-PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves = -1, int front_waves = -1, int raw = -1);
-int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves = 2);
+PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves = -1, int front_waves = -1, int raw = -1, int delay_waves = -1,
+                            int gain_waves = -1);
+int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves = 2, int delay_waves = 0, int gain_waves = 0);
 // progress: PipelinedControlBytes(n_streams) of device memory owned by the engine (cleared by the launch): 16 bits per
 // workgroup, by which the workgroups of a balanced launch keep in step.
 size_t PipelinedControlBytes(int n_streams);

@@ -536,6 +536,15 @@ __global__ __launch_bounds__(256) void aecm_selftest_kernel(uint64_t *fails, int
                 if (mad16_lo_uc(x, y, uc) != add(mul(sext16(x), sext16(y)), uc)) bump(4);
                 if (mad16_hi_uc(x, y, uc) != add(mul(sar(x, 16), sext16(y)), uc)) bump(4);
                 if (mad16_lo((int)0x80008000, -32768, 1) != 0x40000001 || mad16_hi((int)0x7fff0000, -32768, -32770) != (int)0xbffffffe) bump(4);
+                {   // per-half saturating add (v_pk_add_i16 clamp): random words and words that saturate either way
+                    const int xs[3] = {x, (int)0x7fff8000, (int)0x80017ffe}, ys[3] = {y, (int)0x0001ffff, (int)0xfffe0003};
+                    for (int k = 0; k < 3; ++k) {
+                        int lo = sext16(xs[k]) + sext16(ys[k]), hi = sar(xs[k], 16) + sar(ys[k], 16);
+                        lo = lo > 32767 ? 32767 : lo < -32768 ? -32768 : lo;
+                        hi = hi > 32767 ? 32767 : hi < -32768 ? -32768 : hi;
+                        if (pk_add_sat_i16(xs[k], ys[k]) != ((lo & 0xffff) | (int)((unsigned)hi << 16))) bump(4);
+                    }
+                }
                 const int ml = imax(sext16(x), sext16(y)), mh = imax(sar(x, 16), sar(y, 16));
                 if (pk_max_i16(x, y) != ((ml & 0xffff) | (int)((unsigned)mh << 16))) bump(4);
                 // per half "non-zero" (v_pk_min_u16 with an inline constant, as assembly); random words and words with an empty half

@@ -290,6 +290,18 @@ AECM_HD int pk_sub_sat_u16(int a, int b) {
     return (int)((al > bl ? al - bl : 0u) | ((ah > bh ? ah - bh : 0u) << 16));
 #endif
 }
+// per half, signed: a + b saturating at +-2^15                                -> v_pk_add_i16 clamp
+AECM_HD int pk_add_sat_i16(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short aecm_short2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(aecm_short2, a), __builtin_bit_cast(aecm_short2, b)));
+#else
+    int lo = sext16(a) + sext16(b), hi = sar(a, 16) + sar(b, 16);
+    lo = lo > 32767 ? 32767 : lo < -32768 ? -32768 : lo;
+    hi = hi > 32767 ? 32767 : hi < -32768 ? -32768 : hi;
+    return (lo & 0xffff) | (int)((unsigned)hi << 16);
+#endif
+}
 // max(sext(lo), sext(hi))
 AECM_HD int max_halves_i16(int a) { return imax(sext16(a), sar(a, 16)); }
 

@@ -845,13 +845,12 @@ struct BlockEngine {
         }
     }
 
-    static AECM_HD int calc_suppression_gain(Regs &r) {                               // :1000-1052
-        Uniform &u = r.u;
+    // cur_vad and the newest entries of the near-end and stored-channel log-energy histories: what channel_block leaves for it
+    static AECM_HD int calc_suppression_gain(Uniform &u, int cur_vad, int near0, int stored0) {      // :1000-1052
         int sup;
-        if (AECM_STEADY_NEVER(!u.cur_vad)) {
+        if (AECM_STEADY_NEVER(!cur_vad)) {
             sup = 0;
         } else {
-            int near0 = W::readlane(r.near_log, u.log_pos), stored0 = W::readlane(r.stored_log, u.log_pos);
             int dE = sext16(iabs(sext16(near0 - stored0)));
             if (dE < kEnergyDevTol) {
                 if (dE < kSupgainEpcDt) {
@@ -960,7 +959,7 @@ struct BlockEngine {
     }
 
     // ------------------------------------------------------------------------------------------
-    // Comfort noise of one bin (reference aecm/aecm_core_c.cc:52-164); returns (uReal, uImag)
+    // Comfort noise of one bin (reference aecm/aecm_core_c.cc:52-164); returns (uReal, uImag) as the UPPER HALVES of p_re, p_im
     // ------------------------------------------------------------------------------------------
     // kTracking: the caller has established that every noise estimate of the block is >= 2^11 (the usual state once the
     // estimator has found a noise floor: 2^11 in its Q15-like domain is 1/16 of an LSB of the spectrum).  Then neither
@@ -969,7 +968,7 @@ struct BlockEngine {
     // kSilent: the caller has established that the gain of every bin is ONE_Q14: the noise amplitude (ONE_Q14 - hnl) * est is 0
     // whatever the estimate (:142-147), so only the estimator moves and u_re, u_im are left alone.
     template <class I, bool kTracking = false, bool kSilent = false>
-    static AECM_HD void noise_bin(BinState<I> &s, I dfa, I hnl, I rnd, I gate, int shift_n, int min_track, I &u_re, I &u_im) {
+    static AECM_HD void noise_bin(BinState<I> &s, I dfa, I hnl, I rnd, I gate, int shift_n, int min_track, I &p_re, I &p_im) {
         I in = shl(dfa, shift_n);                                                             // :81-127
         auto lt = in < s.noise_est;
         I ne;
@@ -1005,14 +1004,17 @@ struct BlockEngine {
         I n16 = as_i16(sar(mul24(as_i16(I(kOneQ14) - hnl), as_i16(t32)), 14));               // 0 <= hnl <= 2^14, 0 <= t32 <= 32767
         n16 = n16 & gate;                                                                     // bin 0 gets no comfort noise (:146-147): one mask instead of two selects
         I idx = as_i16(sar(mul24(I(359), rnd), 15));                                            // :150
-        u_re = as_i16(sar(mul24(n16, W::cos360(idx)), 13));     /* |cos|, |sin| <= 2^13 */                                     // :153-156
-        u_im = as_i16(sar(mul24(opaque_v(neg(n16)), W::sin360(idx)), 13));   // opaque: a plain negation, not one redone in 24 bits
+        // :153-156  uReal = (noise * cos) >> 13, uImag = (-noise * sin) >> 13 (|cos|, |sin| <= 2^13): with the amplitude times 8
+        // (< 2^18) they are the upper halves of the two products, where a packed add takes them from (comfort_noise)
+        const I n8 = shl(n16, 3);
+        p_re = mul24(n8, W::cos360(idx));
+        p_im = mul24(opaque_v(neg(n8)), W::sin360(idx));                  // opaque: a plain negation, not one redone in 24 bits
     }
 
-    // ComfortNoise of the block (:52-164, called at :702-705) added to the suppressed spectrum (e_re, e_im | e_re64, e_im64).
-    // kSilent: every gain is ONE_Q14, see noise_bin.
+    // ComfortNoise of the block (:52-164, called at :702-705) added to the suppressed spectrum (e = re | im << 16 of bins 0..63;
+    // e_re64, e_im64).  kSilent: every gain is ONE_Q14, see noise_bin.
     template <bool kSilent>
-    static AECM_HD void comfort_noise(Regs &r, const Spectrum &clean, vi hnl, int hnl64, vi &e_re, vi &e_im, int &e_re64, int &e_im64) {
+    static AECM_HD void comfort_noise(Regs &r, const Spectrum &clean, vi hnl, int hnl64, vi &e, int &e_re64, int &e_im64) {
         Uniform &u = r.u;
         int shift_n = sext16(15 - u.dfa_clean_q);
         int min_track = 9;
@@ -1026,24 +1028,23 @@ struct BlockEngine {
         }
         int rnd64 = sext16(lsr(s64, 16));
         u.seed = s64;
-        vi u_re = vi(0), u_im = vi(0);
-        int u_re64 = 0, u_im64 = 0;
+        vi p_re = vi(0), p_im = vi(0);
+        int p_re64 = 0, p_im64 = 0;
         // every estimate at or above 2^11: the short form of the update (see noise_bin)
         const vi gate = lane_const<LC_NOT_BIN0>(r);                                    // 0 in lane 0, all ones elsewhere
         const bool tracking = kNoiseTrackingFastPath && (W::ballot(r.b.noise_est > vi(2047)) == ~0ull) & (r.b64.noise_est > 2047);
         if (AECM_STEADY_ALWAYS(AECM_LIKELY(tracking))) {
-            noise_bin<vi, true, kSilent>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
-            noise_bin<int, true, kSilent>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
+            noise_bin<vi, true, kSilent>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, p_re, p_im);
+            noise_bin<int, true, kSilent>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, p_re64, p_im64);
         } else {
-            noise_bin<vi, false, kSilent>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, u_re, u_im);
-            noise_bin<int, false, kSilent>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, u_re64, u_im64);
+            noise_bin<vi, false, kSilent>(r.b, clean.mag, hnl, rnd, gate, shift_n, min_track, p_re, p_im);
+            noise_bin<int, false, kSilent>(r.b64, clean.mag64, hnl64, rnd64, -1, shift_n, min_track, p_re64, p_im64);
         }
         if constexpr (kSilent) return;
-        u_im64 = 0;                                                                   // :158
-        e_re = sat16(e_re + u_re);                                                    // :160-163
-        e_im = sat16(e_im + u_im);
-        e_re64 = sat16(e_re64 + u_re64);
-        e_im64 = sat16(e_im64 + u_im64);
+        // :160-163  efw = AddSatW16(efw, u), real and imaginary part in one packed saturating add; bin 64: uImag = 0 (:158)
+        e = pk_add_sat_i16(e, pack_hi16(p_re, p_im));
+        e_re64 = sat16(e_re64 + sar(p_re64, 16));
+        e_im64 = sat16(e_im64);
     }
 
     // ------------------------------------------------------------------------------------------
@@ -1117,9 +1118,36 @@ struct BlockEngine {
         W::store_u32(vec + V_OUTBUF * kLanes, lane, pack(out_ovl, c_old));
     }
 
+    // The delay estimator's state: all delay_block touches (the thresholds, the bit histories of the far end, the 100 means, five
+    // scalars).  V_BH1 carries the second bit-history word in lanes 0..35 only (lanes 36..55 belong to two log-energy histories).
+    static AECM_HD void load_delay_state(Regs &r, const uint32_t *vec, const int32_t *scal) {
+        auto V = [&](int f) { return W::load_u32(vec + f * kLanes, r.lane); };
+        r.mean = V(V_MEAN);
+        r.bh0 = V(V_BH0);
+        r.bh1 = sel(r.lane < kSecondPass, V(V_BH1), vi(0));
+        r.m01 = V(V_M01);
+        const auto row = W::load_scalar_row(scal);
+        Uniform &u = r.u;
+        u.far_init = row.get(S_FAR_INIT); u.near_init = row.get(S_NEAR_INIT); u.min_prob = row.get(S_MIN_PROB);
+        u.last_prob = row.get(S_LAST_PROB); u.last_delay = row.get(S_LAST_DELAY);
+    }
+    static AECM_HD void store_delay_state(const Regs &r, uint32_t *vec, int32_t *scal) {
+        auto V = [&](int f, vi w) { W::store_u32(vec + f * kLanes, r.lane, w); };
+        V(V_MEAN, r.mean);
+        V(V_BH0, r.bh0);
+        W::store_u32_if(r.lane < kSecondPass, vec + V_BH1 * kLanes, r.lane, r.bh1);
+        V(V_M01, r.m01);
+        if (W::is_first_lane()) {
+            const Uniform &u = r.u;
+            W::store_scalar(scal, S_FAR_INIT, u.far_init); W::store_scalar(scal, S_NEAR_INIT, u.near_init); W::store_scalar(scal, S_MIN_PROB, u.min_prob);
+            W::store_scalar(scal, S_LAST_PROB, u.last_prob); W::store_scalar(scal, S_LAST_DELAY, u.last_delay);
+        }
+    }
+
     // kTimeState = false: without V_XD_OLD (a wave that only ran back_block does not have it: store_time_state);
-    // kTailState = false: without V_OUTBUF (a wave that only ran middle_block: store_tail_state)
-    template <bool kTimeState = true, bool kTailState = true>
+    // kTailState = false: without V_OUTBUF (a wave that only ran middle_block: store_tail_state);
+    // kDelayState = false: without the delay estimator's state (a wave that was handed the delays: store_delay_state)
+    template <bool kTimeState = true, bool kTailState = true, bool kDelayState = true>
     static AECM_HD void store_state(const Regs &r, uint32_t *vec, int32_t *scal) {
         auto V = [&](int f, vi w) { W::store_u32(vec + f * kLanes, r.lane, w); };
         const vb second = r.lane < kSecondPass;                  // live lanes of the second-pass words
@@ -1135,10 +1163,14 @@ struct BlockEngine {
         V(V_NEARFILT, zext16(r.b.near_filt) | shl(r.b.low_ctr & 7, 16) | shl(r.b.high_ctr & 7, 19) | shl(lsr(r.hq0, 16) & 31, 22) |
                           sel(second, shl(lsr(r.hq1, 16), 27), vi(0)));
         V(V_NOISE, r.b.noise_est);
-        V(V_MEAN, r.mean);
-        V(V_BH0, r.bh0);
-        V(V_BH1, sel(second, r.bh1, sel(logs, W::bpermute(pack(r.near_log, r.adapt_log), down36), vi(0))));
-        V(V_M01, r.m01);
+        if constexpr (kDelayState) {
+            V(V_MEAN, r.mean);
+            V(V_BH0, r.bh0);
+            V(V_BH1, sel(second, r.bh1, sel(logs, W::bpermute(pack(r.near_log, r.adapt_log), down36), vi(0))));
+            V(V_M01, r.m01);
+        } else {
+            W::store_u32_if(!second, vec + V_BH1 * kLanes, r.lane, sel(logs, W::bpermute(pack(r.near_log, r.adapt_log), down36), vi(0)));
+        }
         V(V_HQ, zext16(r.hq0) | shl(sel(second, r.hq1, sel(logs, W::bpermute(r.stored_log, down36), vi(0))), 16));
         if (W::is_first_lane()) {
             const Uniform &u = r.u;
@@ -1150,8 +1182,10 @@ struct BlockEngine {
             W::store_scalar(scal, S_FIRSTVAD, u.first_vad); W::store_scalar(scal, S_MSECNT, u.mse_cnt); W::store_scalar(scal, S_MSE_ADAPT_OLD, u.mse_adapt_old);
             W::store_scalar(scal, S_MSE_STORED_OLD, u.mse_stored_old); W::store_scalar(scal, S_MSE_THRESH, u.mse_thresh);
             W::store_scalar(scal, S_SUPGAIN, u.sup_gain); W::store_scalar(scal, S_SUPGAIN_OLD, u.sup_gain_old); W::store_scalar(scal, S_NOISECTR, u.noise_ctr);
-            W::store_scalar(scal, S_FAR_INIT, u.far_init); W::store_scalar(scal, S_NEAR_INIT, u.near_init); W::store_scalar(scal, S_MIN_PROB, u.min_prob);
-            W::store_scalar(scal, S_LAST_PROB, u.last_prob); W::store_scalar(scal, S_LAST_DELAY, u.last_delay);
+            if constexpr (kDelayState) {
+                W::store_scalar(scal, S_FAR_INIT, u.far_init); W::store_scalar(scal, S_NEAR_INIT, u.near_init); W::store_scalar(scal, S_MIN_PROB, u.min_prob);
+                W::store_scalar(scal, S_LAST_PROB, u.last_prob); W::store_scalar(scal, S_LAST_DELAY, u.last_delay);
+            }
             const BinState<int> &e = r.b64;
             W::store_scalar(scal, S_B64_CHSTORED, e.ch_stored); W::store_scalar(scal, S_B64_CHADAPT16, e.ch_adapt16); W::store_scalar(scal, S_B64_CHADAPT32, e.ch_adapt32);
             W::store_scalar(scal, S_B64_ECHOFILT, e.echo_filt); W::store_scalar(scal, S_B64_NEARFILT, e.near_filt); W::store_scalar(scal, S_B64_NOISE, e.noise_est);
@@ -1255,9 +1289,30 @@ struct BlockEngine {
         // near binary spectrum -> delay (delay_estimator_wrapper.cc:447-476)
         return process_binary(r, near_word);
     }
-    static AECM_HD TailInput middle_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, const Spectrum &cf) {
-        Uniform &u = r.u;
-        W::template phase_priority<3>(r.u.prio_drop);
+    // The delay a block works with (:479-488) and the far-history slot it then fetches (AlignedFarend, aecm_core.cc:157-172), for
+    // a block whose UpdateFarHistory left the write position at hist_pos.
+    static AECM_HD int effective_delay(const Uniform &u, int last_delay) {
+        int delay = last_delay;
+        if (delay == -2) delay = 0;                                                   // :479-483
+        if (W::per_block(u.fixed_delay) >= 0) delay = u.fixed_delay;                  // :485-488
+        return delay;
+    }
+    static AECM_HD int aligned_slot(int hist_pos, int delay) {
+        const int pos = hist_pos - delay;
+        return pos < 0 ? pos + kHistory : pos;
+    }
+
+    // middle_block is two halves again.  channel_block: far history, (delay estimator,) aligned far end, energies / VAD, step
+    // size, channel update (:466-511) -- the part the NEXT block's echo estimate waits for.  gain_block: suppression gain, Wiener
+    // gains, NLP, gain product, comfort noise (:514-705), which depend on the channel half through GainInput alone and otherwise
+    // only on state of their own (echo / near filters, noise estimate, counters, supGain, the seed): the pipelined kernel's
+    // smallest shapes run them in different waves, one block apart.  Both halves work with the block's Q domains: track_q first.
+    struct GainInput {
+        vi echo_est;          // bins 0..63 (after a possible StoreAdaptiveChannel)
+        int echo_est64, far_q;
+        int cur_vad, near0, stored0;      // calc_suppression_gain's inputs
+    };
+    static AECM_HD void track_q(Uniform &u, const Spectrum &df, const Spectrum &cf) {
         u.dfa_noisy_q_old = u.dfa_noisy_q;
         u.dfa_noisy_q = df.q;
         if (kHasClean) {                                                              // :449-464
@@ -1267,7 +1322,21 @@ struct BlockEngine {
             u.dfa_clean_q_old = u.dfa_noisy_q_old;
             u.dfa_clean_q = u.dfa_noisy_q;
         }
-        const Spectrum &clean = kHasClean ? cf : df;   // "dfw"/"ptrDfaClean" of the reference (T30)
+    }
+    // kDelayGiven: the block's delay estimate (delay_block's result) comes from the caller -- the pipelined kernel's delay waves --
+    // and with it, for a delay other than 0, the far-end magnitudes of the aligned block (far_given: what the history row holds).
+    template <bool kDelayGiven = false>
+    static AECM_HD TailInput middle_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, const Spectrum &cf, int delay_given = 0,
+                                          vi far_given = vi(0)) {
+        W::template phase_priority<3>(r.u.prio_drop);
+        track_q(r.u, df, cf);
+        const GainInput g = channel_block<kDelayGiven>(r, hist, xf, df, delay_given, far_given);
+        return gain_block(r, df, cf, g);
+    }
+    // Of xf only mag / mag64 / q are read, of df mag / mag64 (and, without delay_given, q).
+    template <bool kDelayGiven = false>
+    static AECM_HD GainInput channel_block(Regs &r, uint16_t *hist, const Spectrum &xf, const Spectrum &df, int delay_given = 0, vi far_given = vi(0)) {
+        Uniform &u = r.u;
 
         // UpdateFarHistory (aecm_core.cc:125-138)
         u.hist_pos = u.hist_pos + 1;
@@ -1280,20 +1349,19 @@ struct BlockEngine {
         }
 
         // far and near binary spectra, the far word -> history, near binary spectrum -> delay
-        int delay = delay_block(r, xf, df);
-        if (delay == -2) delay = 0;                                                   // :479-483
-        if (W::per_block(u.fixed_delay) >= 0) delay = u.fixed_delay;                  // :485-488
+        int delay = delay_given;
+        if constexpr (!kDelayGiven) delay = delay_block(r, xf, df);
+        delay = effective_delay(u, delay);
 
         AECM_PHASE_MARK(4, r.m01, r.mean);
         W::template phase_priority<5>(r.u.prio_drop);
         // AlignedFarend (aecm_core.cc:157-172)
-        int pos = u.hist_pos - delay;
-        if (pos < 0) pos += kHistory;
+        const int pos = aligned_slot(u.hist_pos, delay);
         int side = pos < 64 ? W::readlane(r.hq0, pos) : W::readlane(r.hq1, pos - 64);
         const int far_q = sar(side, 16);
         const int far64 = zext16(side);
         vi far = xf.mag;
-        if (AECM_STEADY_ALWAYS(delay != 0)) far = W::load_u16(hist + pos * kLanes, r.lane);
+        if (AECM_STEADY_ALWAYS(delay != 0)) far = kDelayGiven ? far_given : W::load_u16(hist + pos * kLanes, r.lane);
 
         vi echo_est;
         int echo_est64;
@@ -1305,11 +1373,24 @@ struct BlockEngine {
         AECM_PHASE_MARK(6, echo_est, r.near_log);
         W::template phase_priority<7>(r.u.prio_drop);
         update_channel(r, far, far64, far_q, df.mag, df.mag64, mu, echo_est, echo_est64);   // :511
-        AECM_PHASE_MARK(7, r.b.ch_adapt32, echo_est);
+        GainInput g;
+        g.echo_est = echo_est; g.echo_est64 = echo_est64; g.far_q = far_q;
+        g.cur_vad = u.cur_vad;
+        g.near0 = W::readlane(r.near_log, u.log_pos);
+        g.stored0 = W::readlane(r.stored_log, u.log_pos);
+        AECM_PHASE_MARK(7, r.b.ch_adapt32, g.echo_est);
+        return g;
+    }
+    // r: the Q domains (track_q), echo_filt / near_filt / noise_est / the two counters of every bin, sup_gain(_old), noise_ctr, seed.
+    static AECM_HD TailInput gain_block(Regs &r, const Spectrum &df, const Spectrum &cf, const GainInput &g) {
+        Uniform &u = r.u;
+        const Spectrum &clean = kHasClean ? cf : df;   // "dfw"/"ptrDfaClean" of the reference (T30)
+        const vi echo_est = g.echo_est;
+        const int echo_est64 = g.echo_est64, far_q = g.far_q;
         W::template phase_priority<8>(r.u.prio_drop);
-        const int sup_gain = calc_suppression_gain(r);                                // :514
+        const int sup_gain = calc_suppression_gain(u, g.cur_vad, g.near0, g.stored0);  // :514
 
-        vi e_re, e_im;
+        vi e;                            // the suppressed spectrum of bins 0..63, packed re | im << 16
         int e_re64, e_im64 = 0;
         const bool q_steady = kNearFiltSteadyPath && u.dfa_clean_q <= u.dfa_clean_q_old;     // see near_filt_update
         if (AECM_STEADY_NEVER(kGainZeroPath && sup_gain == 0)) {
@@ -1325,9 +1406,9 @@ struct BlockEngine {
                 wiener_bin<vi, false, false, true>(r.b, echo_est, clean.mag, 0, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
                 wiener_bin<int, true, false, true>(r.b64, echo_est64, clean.mag64, 0, u.dfa_clean_q, u.dfa_clean_q_old, far_q);
             }
-            e_re = clean.re; e_im = clean.im; e_re64 = clean.re64;
+            e = pack(clean.re, clean.im); e_re64 = clean.re64;
             if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1))
-                comfort_noise<true>(r, clean, vi(kOneQ14), kOneQ14, e_re, e_im, e_re64, e_im64);
+                comfort_noise<true>(r, clean, vi(kOneQ14), kOneQ14, e, e_re64, e_im64);
         } else {
         vi hnl;
         int hnl64;
@@ -1361,22 +1442,27 @@ struct BlockEngine {
         // (the gain as a value the optimiser cannot see through: knowing that the 24-bit multiplies below only look at its
         // low 24 bits, it otherwise carries the gain shifted left by 8 through the NLP's selects and shifts it back per use)
         hnl = opaque_v(hnl);
-        e_re = as_i16(sar(mul24(clean.re, hnl) + 8192, 14));      // |re| <= 2^15, 0 <= hnl <= 2^14                         // :680-685
-        e_im = as_i16(sar(mul24(clean.im, hnl) + 8192, 14));
+        // :680-685  efw = (dfw * hnl + 8192) >> 14 (|dfw| <= 2^15, 0 <= hnl <= 2^14: an int16).  With the gain times 4 the wanted 16 bits
+        // are the upper half of dfw * (hnl << 2) + 32768 (|.| <= 2^31, exact in 32 bits), and one byte permute packs both parts
+        {
+            const vi hnl4 = shl(hnl, 2);
+            e = pack_hi16(add(mul24(clean.re, hnl4), 32768), add(mul24(clean.im, hnl4), 32768));
+        }
         e_re64 = sext16(sar(mul(clean.re64, hnl64) + 8192, 14));
 
-        AECM_PHASE_MARK(9, e_re, e_im);
+        AECM_PHASE_MARK(9, e, hnl);
         W::template phase_priority<10>(r.u.prio_drop);
         if (AECM_STEADY_ALWAYS(W::per_block(u.cng) == 1))                             // :702-705
-            comfort_noise<false>(r, clean, hnl, hnl64, e_re, e_im, e_re64, e_im64);
+            comfort_noise<false>(r, clean, hnl, hnl64, e, e_re64, e_im64);
         }
 
-        AECM_PHASE_MARK(10, e_re, e_im);
+        AECM_PHASE_MARK(10, e, r.b.noise_est);
         W::template phase_priority<11>(r.u.prio_drop);
         // InverseFFTAndWindow (:193-246) + RealInverseFFT (real_fft.c:74-102):
-        // Y[c] = (re[c], -im[c]) for c <= 64, conj-symmetric extension for c > 64 (T7).
-        vi y = pack(e_re, sext16(neg(e_im)));
-        vi mirrored = W::bpermute(pack(e_re, e_im), (vi(64) - r.lane) & 63);           // lane t <- bin 64-t
+        // Y[c] = (re[c], -im[c]) for c <= 64, conj-symmetric extension for c > 64 (T7).  The negated imaginary part (int16 wrap)
+        // is the upper half times 0xffff modulo 2^16
+        vi y = pk_mul_lo_u16(e, vi((int)0xffff0001));
+        vi mirrored = W::bpermute(e, (vi(64) - r.lane) & 63);                          // lane t <- bin 64-t
         int y64 = zext16(e_re64) | shl(sext16(neg(e_im64)), 16);
         TailInput t;
         t.a = y;

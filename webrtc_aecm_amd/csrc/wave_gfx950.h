@@ -475,6 +475,9 @@ struct Gfx950Wave {
         if constexpr (kCoherent) __hip_atomic_store(p + idx, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else p[idx] = (uint32_t)v;
     }
+    static __device__ __forceinline__ void store_u32_if(bool lane_takes_part, uint32_t *p, int idx, int v) {
+        if (lane_takes_part) store_u32(p, idx, v);
+    }
     static __device__ __forceinline__ int load_i16(const int16_t *p, int idx) { return p[idx]; }
     static __device__ __forceinline__ int load_u16(const uint16_t *p, int idx) {
         if constexpr (kCoherent) return __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -136,12 +136,15 @@ BLOCK_KERNELS = {
 
 def block_kernel(form: int, clean: bool, detail: int = 0):
     """(mangled-name fragment, printed name) of the kernel a launch takes; detail = DescribeLaunch's second value (for the
-    pipelined form: the tail waves per workgroup + 0x100 balanced + 0x200 four front waves + 0x400 raw hand-over, the
-    kernel's template arguments).  The fragment is a regular expression."""
+    pipelined form: the tail waves per workgroup + 0x100 balanced + 0x200 four front waves + 0x400 raw hand-over + 0x800 delay
+    waves + 0x1000 gain waves, the kernel's template arguments).  The fragment is a regular expression."""
     if form == 3:
         tail, bal, front, raw = detail & 0xff, (detail >> 8) & 1, 4 if detail & 0x200 else 2, (detail >> 10) & 1
-        return (f"aecm_process_pipelined_kernelILi{tail}ELb{bal}ELb{raw}ELi{front}E",
-                f"aecm_process_pipelined_kernel<tail={tail},front={front}{',raw' if raw else ''}{',balance' if bal else ''}>")
+        gain = 4 if detail & 0x1000 else 0
+        delay = (2 if gain else 4) if detail & 0x800 else 0
+        return (f"aecm_process_pipelined_kernelILi{tail}ELb{bal}ELb{raw}ELi{front}ELi{delay}ELi{gain}E",
+                f"aecm_process_pipelined_kernel<tail={tail},front={front}{f',delay={delay}' if delay else ''}{f',gain={gain}' if gain else ''}"
+                f"{',raw' if raw else ''}{',balance' if bal else ''}>")
     return BLOCK_KERNELS[(form, clean)]
 HEADLINE_KERNEL = BLOCK_KERNELS[(2, False)][0]       # bench.py's default workload (65 536 streams: larger than the chip)
 
