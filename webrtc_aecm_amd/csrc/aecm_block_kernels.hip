@@ -359,7 +359,7 @@ constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of 
 #endif
 template <int kTail, bool kBalance, bool kRaw = false, int kFront = 2, int kDelay = 0, int kGain = 0>
 __global__ __launch_bounds__(64 * PipeWaves(kTail, kFront, kDelay, kGain))
-__attribute__((amdgpu_waves_per_eu(kTail == 1 ? AECM_PIPE_TAIL1_WAVES_PER_EU : AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
+__attribute__((amdgpu_waves_per_eu(PipeWaves(kTail, kFront, kDelay, kGain) == 7 ? AECM_PIPE_TAIL1_WAVES_PER_EU : AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
 void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, uint32_t *progress, int n_workgroups) {
     constexpr int kMode = kBalance ? AECM_PIPE_BALANCE : 0;               // AECM_PIPE_BALANCE's meaning, per instantiation
     constexpr int kFrontBehind = kBalance ? AECM_PIPE_FRONT_PRIO_BEHIND : AECM_PIPE_FRONT_PRIO;
@@ -372,7 +372,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #else
 #define AECM_PIPE_BARRIER() __syncthreads()
 #endif
-    static_assert(kDelay == 0 || ((kDelay == kPipeStreams || kDelay == 2) && kTail != 0 && !kRaw && !kBalance), "delay waves: in the two-tail shapes with formed spectra");
+    static_assert(kDelay == 0 || (kPipeStreams % kDelay == 0 && !kRaw), "delay waves: in the shapes with formed spectra");
     static_assert(kGain == 0 || (kGain == kPipeStreams && kDelay != 0), "gain waves: one per stream, with delay waves");
     constexpr int kWaves = PipeWaves(kTail, kFront, kDelay, kGain), kPipeFrontWaves = kFront, kPipeStreamsPerFront = kPipeStreams / kFront;
     constexpr int kLagD = kDelay ? 1 : 0, kLagG = kGain ? 1 : 0;           // steps the delay / gain waves put between the front waves and the rest
@@ -431,12 +431,12 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                     df.q = __builtin_amdgcn_readlane(sc, 4);
                 }
                 E::update_startup(r.u);
+                int delay_given = 0, far_given = 0;
+                if constexpr (kDelay != 0) {
+                    delay_given = __builtin_amdgcn_readfirstlane(sh.delays[blk & 1][wave]);
+                    far_given = sh.far_rows[blk & 1][wave][lane];
+                }
                 if constexpr (kTail != 0) {
-                    int delay_given = 0, far_given = 0;
-                    if constexpr (kDelay != 0) {
-                        delay_given = __builtin_amdgcn_readfirstlane(sh.delays[blk & 1][wave]);
-                        far_given = sh.far_rows[blk & 1][wave][lane];
-                    }
                     if constexpr (kGain != 0) {
                         W::template phase_priority<3>(r.u.prio_drop);
                         E::track_q(r.u, df, df);
@@ -452,7 +452,8 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                         if (lane == 0) ts.clean_q = t.clean_q;
                     }
                 } else {
-                    const int out = E::back_block(r, hist, xf, df, df);
+                    const typename E::TailInput t = E::template middle_block<kDelay != 0>(r, hist, xf, df, df, delay_given, far_given);
+                    const int out = E::tail_block(r, t.a, t.b, t.clean_q);        // (= back_block)
                     sio.out(r, blk, out);
                 }
             }
@@ -845,6 +846,9 @@ PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int 
     if (sh.balance && !want_raw) sh.balance = false;          // (no balanced instantiation without the raw hand-over)
     // delay waves: the two-tail shapes with formed spectra
     const int want_delay = delay_waves < 0 ? AECM_PIPE_DELAY_DEFAULT(n_wg, cus) : delay_waves;
+    // (Delay waves where the CU is short of issue slots rather than of independent work -- two delay waves next to four front waves
+    // at two workgroups per CU, one for the workgroup's four streams at three and four per CU -- measured slower than the shapes
+    // above: 2 048 streams 712 vs 740 M frames/s, 3 072 555 vs 796, 4 096 796 vs 859.  Not instantiated.)
     if (want_delay != 0 && sh.tail_waves == 2 && (raw < 0 || raw == 0) && n_streams <= PipelinedStreamLimit(cus, 2, 2, kPipeStreams)) {
         sh.front_waves = 2;
         sh.delay_waves = kPipeStreams;
