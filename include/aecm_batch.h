@@ -244,11 +244,13 @@ int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, in
 /* Launches the chip holds at once (<= 4 streams x 4 workgroups per compute unit = 4 096 streams on an MI355X; fast
  * variant, no clean near-end input) run pipelined: six wavefronts serve four streams, the state-independent transforms
  * of a block in wavefronts of their own, one block ahead of the rest; up to 3 072 streams two more wavefronts per
- * workgroup run the inverse transforms and the synthesis one block behind (1 025 .. 2 048 streams: four front wavefronts),
+ * workgroup run the inverse transforms and the synthesis one block behind (1 025 .. 2 048 streams: four front wavefronts;
+ * up to 1 024 streams -- one workgroup per compute unit -- sixteen wavefronts per four streams: the delay estimator one block
+ * ahead and the gain half of the block one block behind its channel half in wavefronts of their own as well),
  * above that the workgroups keep in step through progress feedback on their front wavefronts' issue priority.
  * min_streams: the smallest batch that takes this form (default 2; <= 0: never).  Results do not depend on it.
- * Environment: AECM_PIPELINED (0 = never, n = from n); AECM_PIPE_TAIL / AECM_PIPE_FRONT / AECM_PIPE_RAW override the shape
- * (experiments). */
+ * Environment: AECM_PIPELINED (0 = never, n = from n); AECM_PIPE_TAIL / AECM_PIPE_FRONT / AECM_PIPE_RAW / AECM_PIPE_DELAY /
+ * AECM_PIPE_GAIN override the shape (experiments). */
 int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
 /* Which form a ProcessBlocks launch of num_blocks blocks over the whole batch takes, with (has_clean_input != 0) or
  * without a clean near-end input (for measurement tools that must name
@@ -256,7 +258,7 @@ int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
  * wavefront per stream, issue priority by phase; 2 = the chunk queue (*chunk_blocks, if not NULL, receives the chunk);
  * 3 = pipelined (*chunk_blocks then receives the shape: the "tail" wavefronts per workgroup, 0 or 2, + 0x100 when the
  * launch balances its workgroups' progress, + 0x200 with four front wavefronts instead of two, + 0x400 when the back
- * wavefronts form the spectra). */
+ * wavefronts form the spectra, + 0x800 with delay wavefronts, + 0x1000 with gain wavefronts). */
 #define AECM_LAUNCH_RESIDENT 0
 #define AECM_LAUNCH_PER_STREAM 1
 #define AECM_LAUNCH_CHUNK_QUEUE 2
