@@ -62,6 +62,7 @@ def lib():
         l.sim_get_echo_path.argtypes = [C.c_void_p, _i16p]
         l.sim_process.argtypes = [C.c_void_p, _i16p, _i16p, C.c_void_p, _i16p, C.c_int]
         l.sim_digest.argtypes = [C.c_void_p, _u32p]
+        l.sim_process_roles.argtypes = [C.c_void_p, _i16p, _i16p, _i16p, C.c_int, C.c_int]
         l.sim_fft128.argtypes = [_i16p, _i16p, C.c_int]
         l.sim_constants.argtypes = [_u32p, _u32p, _u32p]
         l.sim_recordings.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -109,6 +110,14 @@ class SimStream:
             clean = np.ascontiguousarray(clean, dtype=np.int16)
             cptr = clean.ctypes.data_as(C.c_void_p)
         self.lib.sim_process(self.h, far, near, cptr, out, far.size // 64)
+        return out
+
+    def process_roles(self, far, near, order=0):
+        """The same blocks through the pipelined kernel's role decomposition (tests/sim/sim_lib.cpp: sim_process_roles)."""
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        out = np.empty_like(near)
+        self.lib.sim_process_roles(self.h, far, near, out, far.size // 64, order)
         return out
 
     def digest(self):

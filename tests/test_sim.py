@@ -26,6 +26,33 @@ def test_wave_dsp_equals_oracle(fs):
             assert np.array_equal(o.digest(), s.digest()), (seed, c, describe_digest_diff(o.digest(), s.digest()))
 
 
+@pytest.mark.parametrize("order", [0, 1])
+def test_role_decomposition_of_the_pipelined_kernel_equals_oracle(order):
+    """The pipelined kernel's deepest shape splits a block over five roles with registers and state of their own -- front,
+    delay, channel, gain, tail -- one step apart (aecm_block_kernels.hip).  The same split on the lane simulator
+    (sim_process_roles: the same BlockEngine functions, state ownership, slot rings and far-history rules), launches of 1 .. 5 and
+    several hundred blocks, alternating with the plain engine, fixed delays included: outputs and the complete state against the
+    oracle after every launch.  order 0 / 1: consumers first / producers first inside a step -- a role reading what the same step
+    writes would make the two differ."""
+    for seed, (fixed, nlp) in enumerate([(None, 1), (0, 1), (1, 1), (7, 0), (None, 1), (99, 1)]):
+        fs = 8000 if seed == 4 else 16000
+        far, near = synth_pair(40 + seed, 1200, fs)
+        cng, em = (0 if seed == 3 else 1), seed % 5
+        o, s = pyoracle.OracleStream(fs, cng, em), simlib.SimStream(fs, cng, em)
+        if fixed is not None:
+            o.control(fixed, nlp)
+            s.control(fixed, nlp)
+        pos = 0
+        for i, t in enumerate((1, 2, 3, 4, 5, 300, 120, 6, 559, 200)):
+            f, n = far[pos * 64:(pos + t) * 64], near[pos * 64:(pos + t) * 64]
+            a = o.process(f, n)
+            b = s.process(f, n) if i in (6, 9) else s.process_roles(f, n, order)
+            assert np.array_equal(a, b), (seed, i, order)
+            assert np.array_equal(o.digest(), s.digest()), (seed, i, order, describe_digest_diff(o.digest(), s.digest()))
+            pos += t
+        assert pos == 1200
+
+
 def test_wave_fft128_equals_oracle_fft_on_arbitrary_complex_data():
     """The kernel's fft128 (every per-stage scaling path of the inverse transform, the real-input
     forward specialisation and the generic complex forward) against the oracle's transform, which
