@@ -1,11 +1,11 @@
 #!/bin/bash
-# Run ON THE GPU BOX: the headline (and BASELINE configs[1]) on each content profile of bench.py --profile, every run with its own
+# Run ON THE GPU BOX: the headline (and BASELINE configs[1], and a 1 024-stream launch) on each content profile of bench.py --profile, every run with its own
 # 18-stream parity check against the CPU checker (the unmodified reference when oracle/_ref travelled) and the shares of the
 # blocks that took the data-dependent paths (counted by the restatement's branch counters over the timed passes).
 #   gpurun -- 'bash tools/content_sweep.sh > gpurun_out/content_sweep.txt'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R"
-for args in "" "--streams 4096 --blocks 2048"; do
+for args in "" "--streams 4096 --blocks 2048" ${CONTENT_SWEEP_EXTRA:+"$CONTENT_SWEEP_EXTRA"} "--streams 1024 --blocks 2048"; do
   for p in recipe always_active double_talk full_scale silent; do
     timeout 600 python bench.py --no-cpu-baseline --profile $p $args 2>&1 | tail -1 | python -c "
 import sys, json
