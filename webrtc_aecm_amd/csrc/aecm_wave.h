@@ -1499,10 +1499,15 @@ struct BlockEngine {
     static AECM_HD void run_stream_io(const StatePtrs &st, Io &io, int64_t stream, int n_blocks) {
         Regs r;
         init_lane_constants(r, st.consts);
+        load_state(r, st.vec + stream * (int64_t)kVecWordsPerStream, st.scal + stream * (int64_t)kNumScal);
+        run_stream_loaded(r, st, io, stream, n_blocks);
+    }
+    // The same with the state loads already issued by the caller (init_lane_constants + load_state into r).
+    template <class Io>
+    static AECM_HD void run_stream_loaded(Regs &r, const StatePtrs &st, Io &io, int64_t stream, int n_blocks) {
         uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
         int32_t *scal = st.scal + stream * (int64_t)kNumScal;
         uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
-        load_state(r, vec, scal);
         io.ready();
         vi far_next = io.far(r, 0);
         vi near_next = io.near(r, 0);
