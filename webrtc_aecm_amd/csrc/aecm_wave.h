@@ -1499,10 +1499,46 @@ struct BlockEngine {
     static AECM_HD void run_stream_io(const StatePtrs &st, Io &io, int64_t stream, int n_blocks) {
         Regs r;
         init_lane_constants(r, st.consts);
-        load_state(r, st.vec + stream * (int64_t)kVecWordsPerStream, st.scal + stream * (int64_t)kNumScal);
-        run_stream_loaded(r, st, io, stream, n_blocks);
+        uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
+        int32_t *scal = st.scal + stream * (int64_t)kNumScal;
+        uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
+        load_state(r, vec, scal);
+        io.ready();
+        vi far_next = io.far(r, 0);
+        vi near_next = io.near(r, 0);
+        vi clean_next = kHasClean ? io.clean(r, 0) : vi(0);
+        W::begin_stream();
+        auto step = [&](int blk) __attribute__((always_inline)) {
+            vi far_cur = far_next, near_cur = near_next, clean_cur = clean_next;
+            if (blk + 1 < n_blocks) {             // prefetch the next block's 3 x 128 bytes
+                far_next = io.far(r, blk + 1);
+                near_next = io.near(r, blk + 1);
+                if (kHasClean) clean_next = io.clean(r, blk + 1);
+            }
+            W::begin_block(blk, n_blocks);
+            vi out = process_block(r, hist, far_cur, near_cur, clean_cur);
+            io.out(r, blk, out);
+            AECM_PHASE_MARK(13, r.out_ovl, r.x_old);
+        };
+#if defined(AECM_BLOCK_LOOP_UNROLL2)
+        // two blocks per trip: the values a block hands to the next one (prefetched samples, the lane vectors a DPP shift
+        // rebuilds in a fresh register) change registers instead of being copied back at the loop's end
+        int blk = 0;
+        for (; blk + 1 < n_blocks; blk += 2) {
+            step(blk);
+            step(blk + 1);
+        }
+        if (blk < n_blocks) step(blk);
+#else
+        for (int blk = 0; blk < n_blocks; ++blk) step(blk);
+#endif
+        AECM_PHASE_MARK(14, r.out_ovl, r.x_old);
+        store_state(r, vec, scal);
     }
-    // The same with the state loads already issued by the caller (init_lane_constants + load_state into r).
+
+    // The same with the state loads already issued by the caller (init_lane_constants + load_state into r: the tick kernel issues
+    // them ahead of its table fill).  A copy of the text above rather than a call from it: the block kernels' code is kept
+    // instruction for instruction what the round's profiles were taken on.
     template <class Io>
     static AECM_HD void run_stream_loaded(Regs &r, const StatePtrs &st, Io &io, int64_t stream, int n_blocks) {
         uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
