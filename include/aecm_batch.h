@@ -249,6 +249,8 @@ int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, in
  * ahead and the gain half of the block one block behind its channel half in wavefronts of their own as well),
  * above that the workgroups keep in step through progress feedback on their front wavefronts' issue priority.
  * min_streams: the smallest batch that takes this form (default 2; <= 0: never).  Results do not depend on it.
+ * By default launches of one or two blocks keep one wavefront per stream (the pipeline's fill and drain steps cost more than
+ * they save there; environment AECM_PIPE_MIN_BLOCKS); after this call launches of any length from min_streams streams are pipelined.
  * Environment: AECM_PIPELINED (0 = never, n = from n); AECM_PIPE_TAIL / AECM_PIPE_FRONT / AECM_PIPE_RAW / AECM_PIPE_DELAY /
  * AECM_PIPE_GAIN override the shape (experiments). */
 int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);

@@ -739,6 +739,7 @@ def test_pipelined_shapes_by_wish(monkeypatch, wish, shape):
     seeds = list(range(7700, 7700 + S))
     far, near = synth_streams(seeds, T, fs)
     b = aecm.AecmBatch(S, fs)
+    b.set_launch_pipelining(2)                               # (a threshold set through the ABI: launches of any length, not only of three blocks and more)
     exp = []
     for k in range(S):
         o = pyoracle.OracleStream(fs, *stream_config(k))
@@ -821,7 +822,7 @@ def test_chunk_queue_half_a_million_hand_overs():
 def test_launch_form_by_size():
     """Which kernel a launch takes (WebRtcAecmBatch_DescribeLaunch; INTEGRATION.md has the table): one stream -> one wavefront
     per stream; 2 .. 4 x 4 x CUs streams -> pipelined (not with a clean input, not the safe variant; with two tail waves per
-    workgroup up to 3 x 4 x CUs streams -- and delay and gain waves up to 4 x CUs --, above that without them and -- in launches long enough --
+    workgroup up to 3 x 4 x CUs streams -- and delay and gain waves up to 4 x CUs --, launches of three blocks and more, above that without them and -- in launches long enough --
     balanced); more -> chunk queue if
     the launch is at least two chunks long (chunks of 32 blocks up to the chip's resident waves, of 128 above), else one
     wavefront per stream."""
@@ -833,7 +834,8 @@ def test_launch_form_by_size():
     for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 0x1a02), (cus * 4, 300, False, 3, 0x1a02), (cus * 4 + 1, 300, False, 3, 0x602),
                                           (cus * 8, 300, False, 3, 0x602),
                                           (tail_max, 300, False, 3, 0x402), (tail_max + 1, 300, False, 3, 0x500),
-                                          (pipe_max, 3, False, 3, 0), (pipe_max, 300, False, 3, 0x500), (pipe_max, 300, True, 0, 0),
+                                          (pipe_max, 3, False, 3, 0), (pipe_max, 2, False, 0, 0), (cus * 4, 2, False, 0, 0), (cus * 4, 3, False, 3, 0x1a02),
+                                          (pipe_max, 300, False, 3, 0x500), (pipe_max, 300, True, 0, 0),
                                           (pipe_max + 1, 300, False, 2, 32), (pipe_max + 1, 63, False, 0, 0), (rotation + 1, 63, False, 1, 0),
                                           (resident, 64, True, 2, 32), (resident + 1, 255, False, 1, 0), (resident + 1, 256, False, 2, 128),
                                           (resident + 1, 256, True, 2, 128)):

@@ -44,6 +44,7 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     if (const char *env = getenv("AECM_PIPE_DELAY")) e->pipe_delay_ = atoi(env);
     if (const char *env = getenv("AECM_PIPE_GAIN")) e->pipe_gain_ = atoi(env);
     if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
+    if (const char *env = getenv("AECM_PIPE_MIN_BLOCKS")) e->pipe_min_blocks_ = atoi(env) > 1 ? atoi(env) : 1;
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
               AECM_HIP_OK(hipMalloc((void **)&e->st_.vec, S * kVecWordsPerStream * sizeof(uint32_t))) &&
@@ -210,10 +211,10 @@ bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count,
         queue_unchecked_ = true;
         return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, chunk, resident_waves_, queue_ctl_, queue_err_, stream_));
     }
-    if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
+    if (PipelinedLaunchApplies(count, num_blocks, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
 #if defined(AECM_PIPE_TRACE)
         trace_streams_ = count;
-    if (PipelinedLaunchApplies(count, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
+    if (PipelinedLaunchApplies(count, num_blocks, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
 #endif
     {
         const PipeShape shape = PipelinedShapeFor(count, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_, pipe_delay_, pipe_gain_);
@@ -229,8 +230,8 @@ bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count,
 
 // Launches the chip holds at once take the pipelined kernel (aecm_block_kernels.hip): fast variant, no clean input, every
 // stream the same number of blocks.
-bool BatchEngine::PipelinedLaunchApplies(int count, bool clean, bool ragged) const {
-    return variant_ == kVariantFast && !clean && !ragged && count >= pipe_min_streams_ && count <= pipe_max_streams_;
+bool BatchEngine::PipelinedLaunchApplies(int count, int num_blocks, bool clean, bool ragged) const {
+    return variant_ == kVariantFast && !clean && !ragged && count >= pipe_min_streams_ && count <= pipe_max_streams_ && num_blocks >= pipe_min_blocks_;
 }
 
 // The chunk queue takes every launch of more streams than the pipelined form does (or than min_streams, when set): above the
@@ -251,7 +252,7 @@ int BatchEngine::DescribeLaunch(int num_blocks, bool has_clean, int *chunk_block
         return 2;
     }
     if (chunk_blocks) *chunk_blocks = 0;
-    if (PipelinedLaunchApplies(num_streams_, has_clean, false)) {
+    if (PipelinedLaunchApplies(num_streams_, num_blocks, has_clean, false)) {
         // (for this form: the tail waves per workgroup, + 0x100 when the launch balances its workgroups' progress, + 0x200 with
         // four front waves, + 0x400 with the raw hand-over, + 0x800 with delay waves, + 0x1000 with gain waves: the kernel's template arguments)
         const PipeShape sh = PipelinedShapeFor(num_streams_, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_, pipe_delay_, pipe_gain_);

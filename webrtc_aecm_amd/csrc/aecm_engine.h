@@ -12,6 +12,10 @@
 namespace aecm {
 
 constexpr int kDefaultPipelinedMinStreams = 2;    // a single stream (the drop-in ABI's 10 ms calls) keeps its one-wave launch
+// ... and so do launches of one or two blocks: the pipelined kernel's fill and drain steps (up to five with the sixteen-wave shape)
+// cost more than they save there -- 1 024 streams x 1 / 2 / 3 / 4 blocks: 10.8 / 12.4 / 14.3 / 15.9 us against 8.7 / 11.7 / 15.1 / 18.2 us
+// with one wave per stream (4 096 streams: 13.5 / 19.0 / 23.2 / 27.4 against 12.6 / 18.3 / 23.7 / 28.7)
+constexpr int kDefaultPipelinedMinBlocks = 3;
 
 class BatchEngine {
 public:
@@ -71,7 +75,8 @@ public:
     }
     static constexpr int kMaxQueueChunk = 1 << 20;
     int DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const;
-    void set_pipelined_min_streams(int n) { pipe_min_streams_ = n > 0 ? n : 0x7fffffff; }    // n <= 0: never
+    // n <= 0: never.  A threshold set through the ABI is taken as it is: launches of any length from n streams
+    void set_pipelined_min_streams(int n) { pipe_min_streams_ = n > 0 ? n : 0x7fffffff; pipe_min_blocks_ = 1; }
     int variant() const { return variant_; }
     const StatePtrs &state_ptrs() const { return st_; }      // for kernels launched by the session batch on stream()
 
@@ -94,8 +99,9 @@ private:
     // The pipelined form of launches the chip holds at once: from pipe_min_streams_ (AECM_PIPELINED; SetLaunchPipelining)
     // up to PipelinedStreamLimit of the device.
     int pipe_min_streams_ = kDefaultPipelinedMinStreams, pipe_max_streams_ = 0;
+    int pipe_min_blocks_ = kDefaultPipelinedMinBlocks;        // (AECM_PIPE_MIN_BLOCKS)
     int pipe_tail_ = -1, pipe_front_ = -1, pipe_raw_ = -1, pipe_delay_ = -1, pipe_gain_ = -1;      // shape overrides (AECM_PIPE_TAIL / _FRONT / _RAW / _DELAY / _GAIN); < 0: by size
-    bool PipelinedLaunchApplies(int count, bool clean, bool ragged) const;
+    bool PipelinedLaunchApplies(int count, int num_blocks, bool clean, bool ragged) const;
     bool LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev);
     int QueueMinStreams() const;
     int QueueChunkFor(int count) const;

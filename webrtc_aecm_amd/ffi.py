@@ -258,13 +258,14 @@ class AecmBatch:
         self._check(self.lib.WebRtcAecmBatch_SetLaunchChunking(self.h, chunk_blocks, min_streams), "SetLaunchChunking")
 
     def set_launch_pipelining(self, min_streams):
-        """Smallest batch whose launches run pipelined (six wavefronts per four streams; results never depend on it);
-        <= 0: never."""
+        """Smallest batch whose launches run pipelined (six to sixteen wavefronts per four streams; results never depend on it);
+        <= 0: never.  By default launches of one or two blocks keep one wavefront per stream; after this call launches of
+        any length do what min_streams says."""
         self._check(self.lib.WebRtcAecmBatch_SetLaunchPipelining(self.h, min_streams), "SetLaunchPipelining")
 
     def describe_launch(self, num_blocks, clean=False):
         """(form, chunk_blocks) of a ProcessBlocks launch of num_blocks blocks: form 0 / 1 = one wavefront per stream
-        (small-launch variants / issue priority by phase), 2 = chunk queue, 3 = pipelined (six wavefronts per four streams)."""
+        (small-launch variants / issue priority by phase), 2 = chunk queue, 3 = pipelined (chunk_blocks is then the shape: include/aecm_batch.h)."""
         chunk = C.c_int32(0)
         form = self.lib.WebRtcAecmBatch_DescribeLaunch(self.h, num_blocks, 1 if clean else 0, C.byref(chunk))
         if form < 0:
