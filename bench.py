@@ -37,7 +37,8 @@ HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH
 # rocprofv3 records of this round's kernels (tools/gpu_round5_final.sh): the headline (chunk-queue kernel), the configs[1] kernel (pipelined,
 # balanced) and the small launches' kernel (pipelined, sixteen waves per four streams)
 PROFILE_SUMMARIES = [ROOT / "profiles" / "r05_rocprof_summary.json", ROOT / "profiles" / "r05_pipelined_rocprof_summary.json",
-                     ROOT / "profiles" / "r05_small_rocprof_summary.json"]
+                     ROOT / "profiles" / "r05_small_rocprof_summary.json", ROOT / "profiles" / "r05_mid2048_rocprof_summary.json",
+                     ROOT / "profiles" / "r05_mid3072_rocprof_summary.json"]
 
 
 PROFILES = {
@@ -249,7 +250,7 @@ def load_profile_record(lib_path, workload_key, kernel_substr):
         return None, dict(static, available=False, stale=bool(same_kernel),
                           reason=(f"profiles/{p.name} was measured on kernel fingerprint {r.get('kernel_fingerprint')} (commit {r.get('measured_at_commit')}), "
                                   f"this library is {now['fingerprint']}: re-profile") if same_kernel else
-                                 f"no rocprofv3 record of {now['kernel'][:60]} under profiles/ (recorded: the headline, the configs[1] kernel and the small launches' kernel)")
+                                 f"no rocprofv3 record of {now['kernel'][:60]} under profiles/ (recorded: the headline and the four pipelined shapes' kernels)")
     PROFILE_SUMMARY, rec = match[0]
     d = rec.get("derived", {})
     note = dict(static, available=True, measured_at_commit=rec.get("measured_at_commit"),
