@@ -266,6 +266,10 @@ int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
 #define AECM_LAUNCH_CHUNK_QUEUE 2
 #define AECM_LAUNCH_PIPELINED 3
 int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t has_clean_input, int32_t *chunk_blocks);
+/* The same answer for a batch of num_streams streams (fast variant, default thresholds, the environment's wishes) on a device with
+ * compute_units compute units -- no device and no batch needed (capacity planning; -1 for a non-positive argument). */
+int32_t WebRtcAecmBatch_DescribeLaunchFor(int32_t num_streams, int32_t compute_units, int32_t num_blocks, int32_t has_clean_input,
+                                          int32_t *chunk_blocks);
 
 /* Device self test of the wave primitives on device_id; failures[0..7] must all be 0 afterwards
  * (see webrtc_aecm_amd/csrc/aecm_kernels.h).  exhaustive != 0 checks floor-sqrt on all of [0, 2^31). */

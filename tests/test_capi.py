@@ -49,6 +49,38 @@ def test_no_cpu_fallback_without_gpu(gpu_available):
     assert lib.WebRtcAecm_Init(None, 16000) == -1
 
 
+def test_launch_form_rules_without_a_device(monkeypatch):
+    """Which kernel a launch takes is host logic (WebRtcAecmBatch_DescribeLaunchFor: the engine's own rules for a device of that
+    many CUs; tests/test_gpu_parity.py::test_launch_form_by_size asks a live engine the same questions): one stream -> one
+    wavefront; up to 4 x 4 x CUs streams and at least three blocks -> pipelined, the shape by workgroups per CU (sixteen waves
+    per four streams up to one per CU, ten up to two, eight up to three, six -- balanced in launches of >= 128 blocks -- above);
+    more -> the chunk queue where the launch is at least two chunks long; never pipelined with a clean input."""
+    for k in ("AECM_PIPE_TAIL", "AECM_PIPE_FRONT", "AECM_PIPE_RAW", "AECM_PIPE_DELAY", "AECM_PIPE_GAIN", "AECM_PIPELINED", "AECM_PIPE_MIN_BLOCKS",
+              "AECM_QUEUE_CHUNK", "AECM_QUEUE_MIN_STREAMS"):
+        monkeypatch.delenv(k, raising=False)
+    import webrtc_aecm_amd as aecm
+    for cus in (256, 304, 64):
+        pipe_max, resident, rotation, tail_max = cus * 16, cus * 28, cus * 24, cus * 12
+        for S, T, clean, want in ((1, 300, False, (0, 0)), (2, 300, False, (3, 0x1a02)), (cus * 4, 300, False, (3, 0x1a02)), (cus * 4, 2, False, (0, 0)),
+                                  (cus * 4, 3, False, (3, 0x1a02)), (cus * 4 + 1, 300, False, (3, 0x602)), (cus * 8, 300, False, (3, 0x602)),
+                                  (cus * 8 + 1, 300, False, (3, 0x402)), (tail_max, 300, False, (3, 0x402)), (tail_max + 1, 300, False, (3, 0x500)),
+                                  (pipe_max, 100, False, (3, 0)),
+                                  (pipe_max, 300, False, (3, 0x500 if pipe_max <= 4096 else 0)),      # (the balance's monitor reads at most 1 024 workgroups' words)
+                                  (pipe_max, 300, True, (0, 0)),
+                                  (pipe_max + 1, 300, False, (2, 32)), (pipe_max + 1, 63, False, (0, 0)), (rotation + 1, 63, False, (1, 0)),
+                                  (resident, 64, True, (2, 32)), (resident + 1, 255, False, (1, 0)), (resident + 1, 256, False, (2, 128))):
+            assert aecm.describe_launch_for(S, cus, T, clean) == want, (cus, S, T, clean, aecm.describe_launch_for(S, cus, T, clean))
+    # the environment's wishes reach it like they reach an engine
+    monkeypatch.setenv("AECM_PIPE_GAIN", "0")
+    assert aecm.describe_launch_for(1024, 256, 300) == (3, 0x802)
+    monkeypatch.setenv("AECM_PIPE_DELAY", "0")
+    assert aecm.describe_launch_for(1024, 256, 300) == (3, 0x2)
+    monkeypatch.setenv("AECM_PIPELINED", "0")
+    assert aecm.describe_launch_for(1024, 256, 300) == (0, 0)
+    with pytest.raises(aecm.AecmError):
+        aecm.describe_launch_for(0, 256, 300)
+
+
 def test_product_does_not_use_the_oracle():
     """The shipped path must never import, include, link or load anything under oracle/."""
     banned = ("aecm_oracle.h", "aecm_oracle_tables.h", "pyoracle", "libaecm_oracle", "libaecm_ref", "import oracle",

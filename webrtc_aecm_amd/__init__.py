@@ -5,6 +5,6 @@ The hot path -- WebRtcAecm_ProcessBlock of cpuimage/WebRTC_AECM -- is hand-writt
 batch extension (include/*.h).  This package only builds and binds that shared library.
 """
 from .ffi import (check_counters, Aecm, AecmBatch, AecmSessions, AecmConfig, AecmError, KERNEL_FAST, KERNEL_SAFE, debug_fft128,  # noqa: F401
-                  device_info, library_path, load, register_host_buffer, self_test, unregister_host_buffer)
+                  describe_launch_for, device_info, library_path, load, register_host_buffer, self_test, unregister_host_buffer)
 
-__all__ = ["check_counters", "Aecm", "AecmBatch", "AecmSessions", "AecmConfig", "AecmError", "KERNEL_FAST", "KERNEL_SAFE", "debug_fft128", "device_info", "library_path", "load", "register_host_buffer", "self_test", "unregister_host_buffer"]
+__all__ = ["check_counters", "Aecm", "AecmBatch", "AecmSessions", "AecmConfig", "AecmError", "KERNEL_FAST", "KERNEL_SAFE", "debug_fft128", "describe_launch_for", "device_info", "library_path", "load", "register_host_buffer", "self_test", "unregister_host_buffer"]

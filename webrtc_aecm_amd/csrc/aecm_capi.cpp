@@ -300,6 +300,12 @@ int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, i
     return b->engine->DescribeLaunch(num_blocks, has_clean_input != 0, chunk_blocks);
 }
 
+int32_t WebRtcAecmBatch_DescribeLaunchFor(int32_t num_streams, int32_t compute_units, int32_t num_blocks, int32_t has_clean_input,
+                                          int32_t *chunk_blocks) {
+    if (num_streams <= 0 || compute_units <= 0 || num_blocks <= 0) return -1;
+    return aecm::BatchEngine::DescribeLaunchFor(num_streams, compute_units, num_blocks, has_clean_input != 0, chunk_blocks);
+}
+
 // ---- streaming batch of sessions ---------------------------------------------------------------------
 
 AecmSessions *WebRtcAecmSessions_Create(int32_t num_streams, int32_t device_id) {

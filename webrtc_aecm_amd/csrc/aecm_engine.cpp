@@ -27,24 +27,11 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     if (!AECM_HIP_OK(hipSetDevice(device_id))) return nullptr;
     BatchEngine *e = new BatchEngine();
     e->device_ = device_id;
+    e->owns_device_resources_ = true;
     e->num_streams_ = num_streams;
     int cus = 0;
     if (!AECM_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id))) cus = 0;
-    e->compute_units_ = cus;
-    e->rotation_limit_ = RotationStreamLimit(cus);
-    e->resident_waves_ = ResidentWaves(cus);
-    e->queue_chunk_ = kDefaultQueueChunk;
-    if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::min(std::max(0, atoi(env)), kMaxQueueChunk);   // the C API's bound
-    if (const char *env = getenv("AECM_QUEUE_MIN_STREAMS")) e->queue_min_streams_ = atoi(env);      // experiments: the queue form above this many streams
-    e->pipe_max_streams_ = PipelinedStreamLimit(cus, 0);            // = that of one tail wave (seven waves per workgroup fill the SIMDs' 28 slots)
-    // experiments: the shape of pipelined launches (aecm_kernels.h: PipelinedShapeFor); default: by the launch's size
-    if (const char *env = getenv("AECM_PIPE_FRONT")) e->pipe_front_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_TAIL")) e->pipe_tail_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_RAW")) e->pipe_raw_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_DELAY")) e->pipe_delay_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_GAIN")) e->pipe_gain_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
-    if (const char *env = getenv("AECM_PIPE_MIN_BLOCKS")) e->pipe_min_blocks_ = atoi(env) > 1 ? atoi(env) : 1;
+    e->ConfigureLaunchForms(cus);
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
               AECM_HIP_OK(hipMalloc((void **)&e->st_.vec, S * kVecWordsPerStream * sizeof(uint32_t))) &&
@@ -67,7 +54,37 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     return e;
 }
 
+// The launch-form limits of a device with `cus` compute units, and the environment's wishes.
+void BatchEngine::ConfigureLaunchForms(int cus) {
+    BatchEngine *e = this;
+    e->compute_units_ = cus;
+    e->rotation_limit_ = RotationStreamLimit(cus);
+    e->resident_waves_ = ResidentWaves(cus);
+    e->queue_chunk_ = kDefaultQueueChunk;
+    if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::min(std::max(0, atoi(env)), kMaxQueueChunk);   // the C API's bound
+    if (const char *env = getenv("AECM_QUEUE_MIN_STREAMS")) e->queue_min_streams_ = atoi(env);      // experiments: the queue form above this many streams
+    e->pipe_max_streams_ = PipelinedStreamLimit(cus, 0);            // = that of one tail wave (seven waves per workgroup fill the SIMDs' 28 slots)
+    // experiments: the shape of pipelined launches (aecm_kernels.h: PipelinedShapeFor); default: by the launch's size
+    if (const char *env = getenv("AECM_PIPE_FRONT")) e->pipe_front_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_TAIL")) e->pipe_tail_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_RAW")) e->pipe_raw_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_DELAY")) e->pipe_delay_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPE_GAIN")) e->pipe_gain_ = atoi(env);
+    if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
+    if (const char *env = getenv("AECM_PIPE_MIN_BLOCKS")) e->pipe_min_blocks_ = atoi(env) > 1 ? atoi(env) : 1;
+}
+
+// What an engine of num_streams streams on a device of compute_units CUs would answer DescribeLaunch with (no device needed: the
+// launch-form rules are host logic; the CPU-only tests walk them).
+int BatchEngine::DescribeLaunchFor(int num_streams, int compute_units, int num_blocks, bool has_clean, int *chunk_blocks) {
+    BatchEngine e;                       // (owns no device resources: its destructor touches nothing)
+    e.num_streams_ = num_streams;
+    e.ConfigureLaunchForms(compute_units);
+    return e.DescribeLaunch(num_blocks, has_clean, chunk_blocks);
+}
+
 BatchEngine::~BatchEngine() {
+    if (!owns_device_resources_) return;             // (DescribeLaunchFor's shell)
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int i = 0; i < kTimerSlots; ++i) {

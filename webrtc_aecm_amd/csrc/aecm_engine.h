@@ -75,6 +75,8 @@ public:
     }
     static constexpr int kMaxQueueChunk = 1 << 20;
     int DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const;
+    // The same for an engine of num_streams streams on a device of compute_units CUs, without one (the launch-form rules are host logic)
+    static int DescribeLaunchFor(int num_streams, int compute_units, int num_blocks, bool has_clean, int *chunk_blocks);
     // n <= 0: never.  A threshold set through the ABI is taken as it is: launches of any length from n streams
     void set_pipelined_min_streams(int n) { pipe_min_streams_ = n > 0 ? n : 0x7fffffff; pipe_min_blocks_ = 1; }
     int variant() const { return variant_; }
@@ -87,6 +89,8 @@ private:
 
     int device_ = 0;
     int compute_units_ = 0;
+    bool owns_device_resources_ = false;     // set by Create; the destructor of a shell (DescribeLaunchFor) touches no HIP call
+    void ConfigureLaunchForms(int cus);
     int rotation_limit_ = 0;             // RotationStreamLimit of device_'s CU count (launch-size switch of the block kernels)
     // The chunk-queue form of large launches (aecm_block_kernels.hip): chunk length in blocks (0 = off; AECM_QUEUE_CHUNK),
     // the chip's resident waves, the queue's control words (grown on first use) and its error word.

@@ -40,7 +40,7 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_GetTimers", "WebRtcAecmBatch_ResetTimers", "WebRtcAecmBatch_InitEchoPath",
     "WebRtcAecmBatch_GetEchoPath", "WebRtcAecmBatch_state_size_bytes", "WebRtcAecmBatch_ExportState",
     "WebRtcAecmBatch_ImportState", "WebRtcAecmBatch_ExportStates", "WebRtcAecmBatch_ImportStates", "WebRtcAecmBatch_ExportStatesDevice",
-    "WebRtcAecmBatch_ImportStatesDevice", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_SetLaunchPipelining", "WebRtcAecmBatch_DescribeLaunch",
+    "WebRtcAecmBatch_ImportStatesDevice", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_SetLaunchPipelining", "WebRtcAecmBatch_DescribeLaunch", "WebRtcAecmBatch_DescribeLaunchFor",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
     "WebRtcAecmBatch_RegisterHostBuffer", "WebRtcAecmBatch_UnregisterHostBuffer",
 ]
@@ -128,6 +128,7 @@ def load():
     lib.WebRtcAecmBatch_SetLaunchChunking.argtypes = [vp, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DescribeLaunch.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.WebRtcAecmBatch_SetLaunchPipelining.argtypes = [vp, C.c_int32]
+    lib.WebRtcAecmBatch_DescribeLaunchFor.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.WebRtcAecmSessions_Create.restype = vp
     lib.WebRtcAecmSessions_Create.argtypes = [C.c_int32, C.c_int32]
     lib.WebRtcAecmSessions_Free.argtypes = [vp]
@@ -567,6 +568,16 @@ def debug_fft128(re, im, variant: int, kernel_variant: int = KERNEL_FAST, device
     if rc != 0:
         raise AecmError(rc, "WebRtcAecmBatch_DebugFft128")
     return data[:, :128].copy(), data[:, 128:].copy(), scales
+
+
+def describe_launch_for(num_streams: int, compute_units: int, num_blocks: int, clean: bool = False):
+    """(form, chunk_blocks / shape) a default-configured batch of num_streams streams would launch num_blocks blocks with on a
+    device of compute_units CUs (AecmBatch.describe_launch without a device: the launch-form rules are host logic)."""
+    chunk = C.c_int32(0)
+    form = load().WebRtcAecmBatch_DescribeLaunchFor(num_streams, compute_units, num_blocks, 1 if clean else 0, C.byref(chunk))
+    if form < 0:
+        raise AecmError(form, "WebRtcAecmBatch_DescribeLaunchFor")
+    return form, chunk.value
 
 
 def device_info(device: int = 0):
