@@ -192,6 +192,34 @@ int32_t WebRtcAecmSessions_TickAsync(AecmSessions *s, const int16_t *far_dev, co
                                      int16_t *out_dev, int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf,
                                      const int16_t *msInSndCardBuf_host, const uint8_t *flags_host, int32_t *codes_host,
                                      void *wait_hip_event, void *done_hip_event);
+/* Far-end bursts.  The reference lets a caller make ANY number of WebRtcAecm_BufferFarend calls between two
+ * WebRtcAecm_Process calls (echo_control_mobile.h:87,135) -- what a jittery network produces: no far frame for a tick or
+ * two, then several at once.  Each call runs the delay compensation once the session is past its start-up phase and then
+ * appends to the 4 000-sample jitter buffer, which drops what does not fit (echo_control_mobile.cc:215-234, 575-594;
+ * ring_buffer.c:142-170).  WebRtcAecmSessions_BufferFarend makes, for every session s,
+ *     for (c = 0; c < (calls_host ? calls_host[s] : calls); ++c) WebRtcAecm_BufferFarend(inst_s, far[s] + c * nrOfSamples, nrOfSamples);
+ * far: [S][stream_stride] int16 with stream_stride >= calls * nrOfSamples; calls in [0, 255]; calls_host: NULL or S entries
+ * <= calls, read before the call returns.  Returns what the reference's call returns (0; AECM_NULL_POINTER_ERROR,
+ * AECM_UNINITIALIZED_ERROR, AECM_BAD_PARAMETER_ERROR for the arguments, in its order).
+ * WebRtcAecmSessions_Process is the other half: every session's WebRtcAecm_Process WITHOUT a WebRtcAecm_BufferFarend (a tick
+ * in which every session carries AECM_SESSION_NO_FAREND); msInSndCardBuf_host / codes_host as in TickPerSession, both may be
+ * NULL.  With the two, k = 0, 1, 2, ... far calls per near call and session are expressed as: BufferFarend with
+ * calls_host[s] = k_s, then Process.  The Tick* forms remain the one-launch shape of the common k = 1 (TickFlags: k in
+ * {0, 1} per session); in TickFlags / TickAsync far may be NULL when every session carries AECM_SESSION_NO_FAREND.
+ * BufferFarend (device pointers) and BufferFarendAsync are enqueued on the object's stream like ticks; BufferFarend and
+ * BufferFarendHost wait for it, BufferFarendAsync does not (events as in TickAsync; the far rows must stay untouched
+ * until the launch has run). */
+int32_t WebRtcAecmSessions_BufferFarend(AecmSessions *s, const int16_t *far_dev, int64_t stream_stride, size_t nrOfSamples, int32_t calls,
+                                        const uint8_t *calls_host);
+int32_t WebRtcAecmSessions_BufferFarendHost(AecmSessions *s, const int16_t *far_host, int64_t stream_stride, size_t nrOfSamples, int32_t calls,
+                                            const uint8_t *calls_host);
+int32_t WebRtcAecmSessions_BufferFarendAsync(AecmSessions *s, const int16_t *far_dev, int64_t stream_stride, size_t nrOfSamples, int32_t calls,
+                                             const uint8_t *calls_host, void *wait_hip_event, void *done_hip_event);
+int32_t WebRtcAecmSessions_Process(AecmSessions *s, const int16_t *near_dev, const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                   size_t nrOfSamples, int16_t msInSndCardBuf, const int16_t *msInSndCardBuf_host, int32_t *codes_host);
+int32_t WebRtcAecmSessions_ProcessHost(AecmSessions *s, const int16_t *near_host, const int16_t *near_clean_host, int16_t *out_host,
+                                       int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf, const int16_t *msInSndCardBuf_host,
+                                       int32_t *codes_host);
 int32_t WebRtcAecmSessions_Synchronize(AecmSessions *s);
 /* AECM_KERNEL_FAST (default) / AECM_KERNEL_SAFE for the object's block engine.  The tick kernel is built on the fast
  * primitives only: with the safe variant selected, ticks return AECM_UNSUPPORTED_FUNCTION_ERROR (and change nothing). */

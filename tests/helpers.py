@@ -104,33 +104,94 @@ def adversarial_cases(n_cases=24, n_blocks=1000, seed=7):
                    echo_mode=int(rs.randint(0, 5)), path=path)
 
 
-def call_pattern(seed, n_calls):
+def call_pattern(seed, n_calls, bursts=False):
     """A hostile but deterministic call pattern for session tests: msInSndCardBuf jitters around 40 ms with
     occasional out-of-range / large excursions, and now and then a call comes without a WebRtcAecm_BufferFarend
-    (far-end underrun).  Returns (ms[int16 n_calls], far_present[uint8 n_calls])."""
+    (far-end underrun).  Returns (ms[int16 n_calls], far_calls[uint8 n_calls]): far_calls[i] = the number of
+    WebRtcAecm_BufferFarend calls before the i-th WebRtcAecm_Process -- 0 or 1 by default; with bursts=True what a
+    jittery network delivers: k = 0, 1, 1, 1, 2, 3 in turn (rotated by the seed), a 30-frame burst every 50 calls (the
+    jitter buffer overflows: reference ring_buffer.c:142-170) and, once, 12 calls without any far frame."""
     rs = np.random.RandomState(1000 + seed)
     ms = (40 + rs.randint(-12, 13, size=n_calls)).astype(np.int16)
-    special = np.nonzero(np.arange(n_calls) % 40 == 39)[0]
+    idx = np.arange(n_calls)
+    special = np.nonzero(idx % 40 == 39)[0]
     ms[special] = rs.choice([-3, 0, 600, 90, 250], size=special.size)
-    far_present = np.ones(n_calls, dtype=np.uint8)
-    far_present[np.arange(n_calls) % 97 == 96] = 0
-    far_present[(np.arange(n_calls) % 211 >= 205) & (np.arange(n_calls) > 100)] = 0     # a run of underruns
-    return ms, far_present
+    far_calls = np.ones(n_calls, dtype=np.uint8)
+    far_calls[idx % 97 == 96] = 0
+    far_calls[(idx % 211 >= 205) & (idx > 100)] = 0                                        # a run of underruns
+    if bursts:
+        far_calls = np.array([0, 1, 1, 1, 2, 3], dtype=np.uint8)[(idx + seed) % 6]
+        far_calls[idx % 50 == (49 - seed % 7)] = 30
+        far_calls[(idx >= 120) & (idx < 132)] = 0
+    return ms, far_calls
 
 
-def drive_session(sess, far, near, frame, ms_seq, far_present=None, clean=None):
+def reconfiguration_events(fs, n_calls):
+    """Mid-session control calls for drive_session(events=...), the same for every ABI-shaped session object:
+    WebRtcAecm_set_config (valid and refused), InitEchoPath, GetEchoPath, and WebRtcAecm_Init at the OTHER rate and back
+    (reference echo_control_mobile.cc:142-191, 410-532).  Every return code is checked against the reference's; the echo
+    paths read on the way are appended to sess.event_log for the caller to compare."""
+    other = 8000 if fs == 16000 else 16000
+    path = (np.arange(65) * 97 % 5000 + 50).astype(np.int16)
+
+    def expect(rc, want):
+        assert rc == want, (rc, want)
+
+    def read_path(sess):                       # what the session has made of the path by now: compared between the sessions by the caller
+        rc, p = sess.get_echo_path()
+        assert rc == 0
+        sess.__dict__.setdefault("event_log", []).append(p.copy())
+    return {
+        n_calls // 5: lambda sess: expect(sess.set_config(0, 4), 0),
+        n_calls // 4: lambda sess: expect(sess.set_config(1, 7), 12004),                 # refused: echoMode out of range (cngMode is committed first)
+        n_calls // 3: lambda sess: expect(sess.init_echo_path(path), 0),
+        n_calls // 3 + 1: read_path,
+        n_calls // 3 + 40: read_path,
+        n_calls - 1: read_path,
+        n_calls // 2: lambda sess: (expect(sess.init(other), 0), expect(sess.set_config(1, 2), 0)),
+        (2 * n_calls) // 3: lambda sess: expect(sess.init(12345), 12004),                # refused: the session keeps running as it was
+        (3 * n_calls) // 4: lambda sess: expect(sess.init(fs), 0),                       # back: default configuration again
+    }
+
+
+def far_frames_needed(far_calls):
+    """How many far frames a session driven with this far_calls sequence consumes."""
+    return int(np.asarray(far_calls, dtype=np.int64).sum())
+
+
+def drive_session(sess, far, near, frame, ms_seq, far_calls=None, clean=None, events=None):
     """Drive an ABI-shaped session object (webrtc_aecm_amd.Aecm, pyoracle.RefSession, simlib.SimSession) call by
-    call; returns (out, codes[n_calls])."""
+    call: before the i-th WebRtcAecm_Process, far_calls[i] WebRtcAecm_BufferFarend calls (one when far_calls is None),
+    each taking the next `frame` samples of far.  events: {call index: function(sess)} run before that call's far
+    frames (mid-session WebRtcAecm_set_config / InitEchoPath / Init ...).  Returns (out, codes[n_calls])."""
     n_calls = near.size // frame
     out = np.empty(n_calls * frame, dtype=np.int16)
     codes = np.zeros(n_calls, dtype=np.int32)
+    cursor = 0
+    # 0 / 1 patterns keep far and near aligned: the far frame of an underrun is lost, not delayed
+    aligned = far_calls is not None and int(np.asarray(far_calls).max(initial=0)) <= 1
     for i in range(n_calls):
         sl = slice(i * frame, (i + 1) * frame)
-        if far_present is None or far_present[i]:
-            rc = sess.buffer_farend(far[sl])
+        if events and i in events:
+            events[i](sess)
+        for _ in range(1 if far_calls is None else int(far_calls[i])):
+            rc = sess.buffer_farend(far[cursor:cursor + frame])
             assert rc == 0, (i, rc)
+            cursor += frame
+        if aligned and not far_calls[i]:
+            cursor += frame
         codes[i], out[sl] = sess.process(near[sl], None if clean is None else clean[sl], int(ms_seq[i]))
     return out, codes
+
+
+def run_burst_fixture(sess, g):
+    """Drive an ABI-shaped session through a sessburst_* fixture (tools/gen_golden.py); returns (out, codes, echo paths read)."""
+    fs, frame, n_calls, seed = int(g["fs"]), int(g["frame"]), int(g["n_calls"]), int(g["seed"])
+    far, _ = synth_pair(seed, far_frames_needed(g["far_calls"]) * frame // 64 + 1, fs, "mixed")
+    _, near = synth_pair(seed, n_calls * frame // 64 + 1, fs, "mixed")
+    assert sess.init(fs) == 0 and sess.set_config(1, 3) == 0
+    out, codes = drive_session(sess, far, near, frame, g["ms_seq"], g["far_calls"], events=reconfiguration_events(fs, n_calls))
+    return out, codes, np.stack(sess.event_log)
 
 
 # ---- WAV files in the sample formats the reference CLI reads (dr_wav) ----------------------------------------------------

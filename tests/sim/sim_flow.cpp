@@ -41,6 +41,29 @@ struct DeviceSide {
         FlowInit(words);
         for (int k = 0; k < kFlowFieldsUsed; ++k) regs.v[k] = words[k];
     }
+    // `calls` WebRtcAecm_BufferFarend calls of len samples without a Process, exactly as aecm_buffer_farend_kernel does them:
+    // only the fields a burst may read are visible, the spills come first, then call by call.
+    void BufferFarend(int fs, int len, int calls, const int64_t *far_in) {
+        const int64_t mask = kRingLen - 1;
+        FlowRegs r;
+        for (int k = 0; k < kFlowFieldsUsed; ++k) r.v[k] = 0x5a5a5a5a;                  // poison what the kernel does not load
+        FlowBurstReads([&](int f) { r.v[f] = regs.v[f]; });
+        FlowBurst b;
+        FlowBurstBegin(r, len, calls, b);
+        for (int i = 0; i < 2; ++i)
+            if (b.spill[i])
+                for (int j = 0; j < kFlowFrame; ++j) far_old[i * kFlowFrame + j] = far_ring[(b.spill_pos[i] + (uint32_t)j) & mask];
+        spill_ticks += b.spill[0] + b.spill[1];
+        const int mult = fs == 16000 ? 2 : 1;
+        for (int c = 0; c < calls; ++c) {
+            const uint32_t pos = (uint32_t)r.v[F_FAR_WP];
+            const int32_t accepted = FlowFarendCall(r, mult, len);
+            for (int j = 0; j < accepted; ++j) far_ring[(pos + (uint32_t)j) & mask] = far_in[c * len + j];
+            burst_dropped += len - accepted;
+        }
+        FlowBurstWrites([&](int f) { regs.v[f] = r.v[f]; });
+    }
+    int64_t burst_dropped = 0;
     // One tick exactly as the kernel does it: plan, appends, far frames, blocks, output frames.
     void Tick(int fs, int n, int ms, int flags, const int64_t *far_in, const int64_t *near_in, int64_t *out, std::vector<int64_t> *blk_far,
               std::vector<int64_t> *blk_near) {
@@ -101,7 +124,9 @@ extern "C" {
 // block input and every output sample agreed, else the first tick that differed; detail[0] = what differed (1 block
 // count, 2 far block tags, 3 near block tags, 4 output, 5 return code), detail[1] = blocks processed in total,
 // detail[2] = ticks spent past the start-up phase, detail[3] = ticks in which the jitter buffer dropped far samples,
-// detail[4] = ticks whose blocks fetched the far end from the far ring directly, detail[5] = replay frames moved to rows.
+// detail[4] = ticks whose blocks fetched the far end from the far ring directly, detail[5] = replay frames moved to rows,
+// detail[6] = far-end calls made outside ticks (bursts), detail[7] = samples of those the full jitter buffer dropped;
+// detail[0] = 100 + field: FlowStateDefect refused a state the session passed through.
 int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t start_pos, int64_t *detail) {
     Rng rng{seed * 2654435761ull + 12345};
     DeviceSide dev;
@@ -113,7 +138,7 @@ int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t
     ref.Init(fs);
     int64_t far_offered = 0, near_offered = 0, ref_blocks = 0;
     int ms_walk = 40;
-    for (int i = 0; i < 6; ++i) detail[i] = 0;
+    for (int i = 0; i < 8; ++i) detail[i] = 0;
     for (int64_t tick = 0; tick < n_ticks; ++tick) {
         int n = fs == 16000 ? 160 : 80, ms = 40, flags = 0;
         switch (scenario) {
@@ -137,9 +162,32 @@ int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t
                 n = tick < 33100 ? 80 : 160;                                    // wrapper's short counters wrap while nBlocks10ms == 0, then
                 ms = 40 + (int)(tick % 3);                                      // 160-sample calls compare them as size_t (:320,:330)
                 break;
+            case 12: case 13: case 14: break;                                   // far-end bursts, below
             default: n = rng.chance(20) ? 80 : 160; ms = rng.range(0, 200); flags = rng.range(0, 3); break;
         }
         if (n != 160) flags &= ~kFlowSplitCalls;
+        // far-end bursts: extra WebRtcAecm_BufferFarend calls (of their own size) between two ticks, on both sides
+        int extra = 0, extra_len = n;
+        switch (scenario) {
+            case 12: extra = (int)(tick % 6 == 4) + 2 * (int)(tick % 6 == 5); if (tick % 50 == 49) extra = 30;      // k = 0,1,1,1,2,3 far calls per tick
+                     if (tick % 6 == 0) flags |= kFlowNoFarend; ms = rng.range(30, 60); break;                      // + a 30-frame burst every 50 ticks
+            case 13: extra = rng.chance(30) ? rng.range(1, 4) : 0; extra_len = rng.chance(50) ? 80 : 160; if (rng.chance(35)) flags |= kFlowNoFarend;
+                     if (rng.chance(2)) extra = rng.range(20, 60); ms = rng.range(0, 300); n = rng.chance(30) ? 80 : 160; if (rng.chance(30)) flags |= kFlowSplitCalls;
+                     if (n != 160) flags &= ~kFlowSplitCalls; break;
+            case 14: { const int ph = (int)(tick % 400);                       // long silences of the far end, then everything that was held back at once:
+                     if (ph >= 100 && ph < 160) flags |= kFlowNoFarend;       // the jitter buffer overflows, replay frames are lapped in the far ring
+                     if (ph == 160) extra = 60; if (ph == 300) { extra = 255; extra_len = 160; }
+                     n = 160; if (ph >= 200 && ph < 290) flags |= kFlowSplitCalls; ms = rng.range(35, 45); break; }
+            default: break;
+        }
+        if (extra > 0) {
+            std::vector<int64_t> burst((size_t)extra * extra_len);
+            for (size_t j = 0; j < burst.size(); ++j) burst[j] = far_offered + (int64_t)j;
+            far_offered += (int64_t)burst.size();
+            dev.BufferFarend(fs, extra_len, extra, burst.data());
+            for (int c = 0; c < extra; ++c) ref.BufferFarend(burst.data() + (size_t)c * extra_len, (size_t)extra_len);
+            detail[6] += extra;
+        }
         int64_t far_in[160], near_in[160], out_dev[160], out_ref[160];
         for (int j = 0; j < n; ++j) { far_in[j] = far_offered + j; near_in[j] = (int64_t(1) << 32) + near_offered + j; }
         far_offered += n;
@@ -168,7 +216,16 @@ int64_t sim_flow_fuzz(uint64_t seed, int fs, int n_ticks, int scenario, uint32_t
         detail[1] = ref_blocks;
         detail[4] = dev.direct_ticks;
         detail[5] = dev.spill_ticks;
+        detail[7] = dev.burst_dropped;
         int what = 0;
+        {   // every state a session passes through is one WebRtcAecmSessions_ImportSession accepts
+            int32_t words[kFlowWords] = {0};
+            for (int k = 0; k < kFlowFieldsUsed; ++k) words[k] = dev.regs.v[k];
+            if (FlowStateDefect(words) != 0) {
+                detail[0] = 100 + FlowStateDefect(words);
+                return tick;
+            }
+        }
         if (dfar.size() != rfar.size()) what = 1;
         else if (dfar != rfar) what = 2;
         else if (dnear != rnear) what = 3;

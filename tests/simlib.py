@@ -85,8 +85,8 @@ def lib():
 
 def flow_fuzz(seed, fs, n_ticks, scenario, start_pos=0):
     """(first differing tick or -1, [what, blocks processed, ticks past start-up, ticks with dropped far samples,
-    ticks with direct far fetches, replay frames moved to their rows])."""
-    detail = (C.c_int64 * 6)()
+    ticks with direct far fetches, replay frames moved to their rows, far-end calls outside ticks, samples of those dropped])."""
+    detail = (C.c_int64 * 8)()
     tick = lib().sim_flow_fuzz(seed, fs, n_ticks, scenario, start_pos, detail)
     return tick, list(detail)
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import simlib
-from helpers import adversarial_cases, describe_digest_diff, golden_files
+from helpers import adversarial_cases, describe_digest_diff, golden_files, run_burst_fixture
 from oracle import pyoracle
 from webrtc_aecm_amd.synth import synth_clean, synth_pair
 
@@ -237,6 +237,31 @@ def test_session_host_logic_matches_reference_abi_odd_call_patterns():
             assert rc == rc2 and np.array_equal(ob, o2), (fs, frame, i)
 
 
+@pytest.mark.skipif(not pyoracle.have_reference(), reason="oracle/_ref/libaecm_ref.so not built")
+@pytest.mark.parametrize("fs,frame", [(16000, 160), (8000, 80), (16000, 80), (8000, 160)])
+def test_session_host_logic_far_end_bursts_and_mid_session_reconfiguration(fs, frame):
+    """What a jittery network and a live application do to ONE session, against the reference's own ABI call by call:
+    k = 0, 1, 1, 1, 2, 3 WebRtcAecm_BufferFarend calls per WebRtcAecm_Process, a 30-frame burst every 50 calls (the
+    4 000-sample jitter buffer overflows and truncates: reference ring_buffer.c:142-170, echo_control_mobile.cc:215-234),
+    a dozen calls without any far frame, and in between WebRtcAecm_set_config (valid and refused), InitEchoPath /
+    GetEchoPath and WebRtcAecm_Init at the other sampling rate and back."""
+    from helpers import call_pattern, drive_session, far_frames_needed, reconfiguration_events
+    n_calls = 3 * fs // frame if frame == 160 or fs == 8000 else 400
+    ms_seq, far_calls = call_pattern(7 + fs // 8000 + frame, n_calls, bursts=True)
+    far, _ = synth_pair(61, far_frames_needed(far_calls) * frame // 64 + 1, fs, "mixed")
+    _, near = synth_pair(61, n_calls * frame // 64 + 1, fs, "mixed")
+    events = reconfiguration_events(fs, n_calls)
+    r = pyoracle.RefSession(fs, 1, 3)
+    s = simlib.SimSession()
+    assert s.init(fs) == 0 and s.set_config(1, 3) == 0
+    exp, exp_codes = drive_session(r, far, near, frame, ms_seq, far_calls, events=events)
+    got, codes = drive_session(s, far, near, frame, ms_seq, far_calls, events=events)
+    assert np.array_equal(codes, exp_codes)
+    assert np.array_equal(got, exp), int(np.nonzero(got != exp)[0][0]) // frame
+    assert len(r.event_log) == 3 and all(np.array_equal(a, b) for a, b in zip(r.event_log, s.event_log))
+    assert (exp != near[:exp.size]).any()             # the session did leave its start-up copy
+
+
 def test_batched_recordings_schedule_matches_reference_fixtures():
     """The index-domain session schedule (aecm_schedule.cpp) + gather/scatter reproduces, for every
     stream of a batch, what an individual WebRtcAecm_* session produces."""
@@ -285,16 +310,30 @@ def test_session_jitter_goldens_on_the_host_session_logic():
         assert np.array_equal(codes, g["codes"]) and np.array_equal(out, g["out"]), f.name
 
 
+def test_session_burst_goldens_on_the_host_session_logic():
+    """sessburst_* fixtures (reference outputs for far-end bursts, jitter-buffer overflow and mid-session set_config /
+    InitEchoPath / re-Init at the other rate): the product's Session class over the simulated engine reproduces them."""
+    files = golden_files("sessburst_")
+    assert len(files) >= 2
+    for f in files:
+        g = np.load(f)
+        assert int(g["far_calls"].max()) == 30 and int(g["far_calls"].min()) == 0
+        out, codes, paths = run_burst_fixture(simlib.SimSession(), g)
+        assert np.array_equal(codes, g["codes"]) and np.array_equal(out, g["out"]) and np.array_equal(paths, g["paths"]), f.name
+
+
 @pytest.mark.parametrize("fs", [16000, 8000])
 def test_device_session_machinery_equals_the_generic_wrapper_on_sample_tags(fs):
     """aecm_flow_plan.h (the wrapper + frame adapter as position arithmetic, what aecm_tick_flow_kernel runs per session)
     against SessionFlow<T> on sample tags: every block's 64 far / near inputs and every output sample must have the
     same provenance, tick by tick -- constant, jittering, stepping and out-of-range msInSndCardBuf, far-end underruns,
     a saturated jitter buffer (16 kHz in 80-sample calls), mixed 80 / 160 / 2 x 80 call shapes, a replay frame that
-    outlives its place in the far ring, and position counters that wrap around 2^32 and 2^31 during the run."""
+    outlives its place in the far ring, far-end bursts (k = 0..3 and 30 / 60 / 255 WebRtcAecm_BufferFarend calls between
+    two WebRtcAecm_Process calls, overflowing the jitter buffer), and position counters that wrap around 2^32 and 2^31
+    during the run.  Every state passed through must also be one ImportSession's validator accepts."""
     assert simlib.lib().sim_flow_tolerance_check() == 0
-    saw_blocks = saw_drops = saw_direct = saw_framed = saw_spills = 0
-    for scenario in range(11):
+    saw_blocks = saw_drops = saw_direct = saw_framed = saw_spills = saw_bursts = saw_burst_drops = 0
+    for scenario in list(range(11)) + [12, 13, 14]:
         for seed, start in ((1, 0), (2, 0xfffff000), (3, 0x7ffff800), (4, 987654321)):
             tick, detail = simlib.flow_fuzz(seed + 10 * scenario, fs, 6000, scenario, start)
             assert tick == -1, (fs, scenario, seed, tick, detail)
@@ -303,10 +342,14 @@ def test_device_session_machinery_equals_the_generic_wrapper_on_sample_tags(fs):
             saw_direct += detail[4]
             saw_framed += detail[2] - detail[4]
             saw_spills += detail[5]
+            saw_bursts += detail[6]
+            saw_burst_drops += detail[7]
     # both far-end paths of the tick kernel (fetch from the far ring / through the framed-far ring), a saturated jitter
     # buffer and replay frames that had to move to their rows were all exercised
     assert saw_blocks > 100000 and saw_direct > 50000 and saw_framed > 50000 and saw_spills > 50
     assert fs == 8000 or saw_drops > 1000
+    # far-end bursts (WebRtcAecm_BufferFarend calls without a Process, scenarios 12-14), some of them into a full jitter buffer
+    assert saw_bursts > 20000 and saw_burst_drops > 100000
     if fs == 16000:     # counters wrapped negative during an endless 80-sample start-up, then compared as size_t (scenario 11)
         tick, detail = simlib.flow_fuzz(77, fs, 33600, 11, 12345)
         assert tick == -1 and detail[2] > 300, (tick, detail)

@@ -41,6 +41,12 @@ SESSJIT_CASES = [
     (13, 6, 8000, 80, 1, 1),
     (14, 5, 16000, 80, 0, 4),
 ]
+# Far-end bursts (k = 0..3 and 30 WebRtcAecm_BufferFarend calls per WebRtcAecm_Process) + mid-session set_config / InitEchoPath /
+# re-Init at the other rate (tests/helpers.py: call_pattern(bursts=True), reconfiguration_events): (seed, seconds, fs, frame)
+SESSBURST_CASES = [
+    (15, 3, 16000, 160),
+    (16, 3, 8000, 80),
+]
 
 
 def main():
@@ -103,6 +109,20 @@ def main():
                             ms_seq=ms_seq, far_present=far_present, out=out, codes=codes,
                             sha256=hashlib.sha256(out.tobytes()).hexdigest())
         print("sessjit", seed, fs, frame, cng, em, sorted(set(codes.tolist())), int((far_present == 0).sum()), "underruns")
+    from helpers import far_frames_needed, reconfiguration_events
+    for seed, secs, fs, frame in SESSBURST_CASES:
+        name = f"sessburst_s{seed}_fs{fs}_f{frame}"
+        if only and only not in name:
+            continue
+        n_calls = secs * fs // frame
+        ms_seq, far_calls = call_pattern(seed, n_calls, bursts=True)
+        far, _ = synth_pair(seed, far_frames_needed(far_calls) * frame // 64 + 1, fs, "mixed")
+        _, near = synth_pair(seed, n_calls * frame // 64 + 1, fs, "mixed")
+        r = pyoracle.RefSession(fs, 1, 3)
+        out, codes = drive_session(r, far, near, frame, ms_seq, far_calls, events=reconfiguration_events(fs, n_calls))
+        np.savez_compressed(GOLD / f"{name}.npz", seed=seed, n_calls=n_calls, fs=fs, frame=frame, ms_seq=ms_seq, far_calls=far_calls, out=out,
+                            codes=codes, paths=np.stack(r.event_log), sha256=hashlib.sha256(out.tobytes()).hexdigest())
+        print("sessburst", seed, fs, frame, sorted(set(codes.tolist())), int(far_calls.sum()), "far calls for", n_calls, "near calls")
     if only:
         return
     # 60 s reference-CLI-shaped run: hash only

@@ -420,6 +420,36 @@ int32_t WebRtcAecmSessions_TickAsync(AecmSessions *s, const int16_t *far_dev, co
                                msInSndCardBuf_host, flags_host, codes_host, wait_hip_event, done_hip_event);
 }
 
+int32_t WebRtcAecmSessions_BufferFarend(AecmSessions *s, const int16_t *far_dev, int64_t stream_stride, size_t nrOfSamples, int32_t calls,
+                                        const uint8_t *calls_host) {
+    return s ? s->batch->BufferFarend(far_dev, stream_stride, nrOfSamples, calls, calls_host, false, true, nullptr, nullptr) : -1;
+}
+
+int32_t WebRtcAecmSessions_BufferFarendHost(AecmSessions *s, const int16_t *far_host, int64_t stream_stride, size_t nrOfSamples, int32_t calls,
+                                            const uint8_t *calls_host) {
+    return s ? s->batch->BufferFarend(far_host, stream_stride, nrOfSamples, calls, calls_host, true, true, nullptr, nullptr) : -1;
+}
+
+int32_t WebRtcAecmSessions_BufferFarendAsync(AecmSessions *s, const int16_t *far_dev, int64_t stream_stride, size_t nrOfSamples, int32_t calls,
+                                             const uint8_t *calls_host, void *wait_hip_event, void *done_hip_event) {
+    return s ? s->batch->BufferFarend(far_dev, stream_stride, nrOfSamples, calls, calls_host, false, false, wait_hip_event, done_hip_event) : -1;
+}
+
+int32_t WebRtcAecmSessions_Process(AecmSessions *s, const int16_t *near_dev, const int16_t *near_clean_dev, int16_t *out_dev, int64_t stream_stride,
+                                   size_t nrOfSamples, int16_t msInSndCardBuf, const int16_t *msInSndCardBuf_host, int32_t *codes_host) {
+    if (!s) return -1;
+    return s->batch->Tick(nullptr, near_dev, near_clean_dev, out_dev, stream_stride, nrOfSamples, msInSndCardBuf, msInSndCardBuf_host, nullptr,
+                          codes_host, false, AECM_SESSION_NO_FAREND);
+}
+
+int32_t WebRtcAecmSessions_ProcessHost(AecmSessions *s, const int16_t *near_host, const int16_t *near_clean_host, int16_t *out_host,
+                                       int64_t stream_stride, size_t nrOfSamples, int16_t msInSndCardBuf, const int16_t *msInSndCardBuf_host,
+                                       int32_t *codes_host) {
+    if (!s) return -1;
+    return s->batch->Tick(nullptr, near_host, near_clean_host, out_host, stream_stride, nrOfSamples, msInSndCardBuf, msInSndCardBuf_host, nullptr,
+                          codes_host, true, AECM_SESSION_NO_FAREND);
+}
+
 int32_t WebRtcAecmSessions_Synchronize(AecmSessions *s) { return s ? s->batch->Synchronize() : -1; }
 
 int32_t WebRtcAecmSessions_SetKernelVariant(AecmSessions *s, int32_t variant) {

@@ -119,8 +119,10 @@ AECM_FLOW_HD void FlowInit(int32_t words[kFlowWords]) {
 
 // Is this wrapper state one FlowTick and the tick kernel may run on (WebRtcAecmSessions_ImportSession)?  Everything they
 // turn into a loop count, a lane count or a 4-bit field of the plan: the pending frame-stream samples (< one block: the block
-// loop of a frame and the plan's left_count), the jitter buffer's fill, the output ring's fill, the flags.  Positions
-// themselves are free-running counters: any value is a position.  Returns 0 or the 1-based index of the offending field.
+// loop of a frame and the plan's left_count), the jitter buffer's fill, the output ring's fill, the flags; and everything
+// that names far-ring samples a later tick will read (replay frames, pending samples of direct ticks) must name samples the
+// ring still holds.  Positions themselves are free-running counters: any value is a position.  tests/sim/sim_flow.cpp checks
+// that every state a session passes through is accepted.  Returns 0 or the 1-based index of the offending field.
 AECM_FLOW_HD int FlowStateDefect(const int32_t v[kFlowWords]) {
     for (int f : {F_EC_STARTUP, F_CHECK_BUFF_SIZE, F_DELAY_CHANGE, F_FF_VALID, F_OLD_ROW0, F_OLD_ROW1})
         if (v[f] != 0 && v[f] != 1) return f + 1;
@@ -134,6 +136,18 @@ AECM_FLOW_HD int FlowStateDefect(const int32_t v[kFlowWords]) {
     if (pending >= (uint32_t)kFlowBlock) return F_BLK_POS + 1;
     const uint32_t out_fill = (uint32_t)v[F_BLK_POS] - (uint32_t)v[F_OUT_RP];
     if (out_fill > (uint32_t)(kFlowFrame + kFlowBlock)) return F_OUT_RP + 1;                          // the output frame ring holds FRAME_LEN + PART_LEN (aecm_core.cc:204-205)
+    // A replay frame that still lives in the far ring only has not been lapped there: FlowTick / FlowBurstBegin move it to
+    // its row before the write position gets further than kFlowOldAge + one tick ahead of it.
+    for (int i = 0; i < 2; ++i)
+        if (!v[F_OLD_ROW0 + i] && (uint32_t)v[F_FAR_WP] - (uint32_t)v[F_OLD_POS0 + i] > (uint32_t)(kFlowOldAge + 2 * kFlowFrame)) return F_OLD_POS0 + i + 1;
+    // Pending samples that were left in the far ring by direct ticks (F_FF_VALID == 0) are one run of the far stream that
+    // ends before the jitter buffer's read pointer and is as young as anything the jitter buffer can still hand out
+    // (the read pointer never falls back by more than the buffer's capacity; a frame and the pending samples lie before it).
+    if (!v[F_FF_VALID]) {
+        const uint32_t behind = (uint32_t)v[F_FAR_WP] - ((uint32_t)v[F_BLK_POS] + (uint32_t)v[F_RUN_DELTA]);    // write position - far position of the first pending sample
+        if (behind < pending || behind > (uint32_t)(kFlowJitterCapacity + 2 * kFlowFrame + kFlowBlock)) return F_RUN_DELTA + 1;
+        if ((uint32_t)v[F_BLK_POS] - (uint32_t)v[F_RUN_POS] > (uint32_t)(4 * kFlowBlock)) return F_RUN_POS + 1;  // FlowTick keeps it at the last tick's first block
+    }
     for (int f = kFlowFieldsUsed; f < kFlowWords; ++f)
         if (v[f] != 0) return f + 1;
     return 0;
@@ -159,6 +173,47 @@ AECM_FLOW_HD void FlowDelayComp(FlowRegs &s, int mult) {
         FlowMoveFarReadPtr(s, -n_add);
         s.v[F_DELAY_CHANGE] = 1;
     }
+}
+
+// One WebRtcAecm_BufferFarend call of len samples (:215-234): delay compensation once the start-up phase is over, then
+// the jitter buffer takes what fits -- a full buffer drops the rest (ring_buffer.c:142-150).  Returns the number of
+// samples accepted; they land at far-stream positions [F_FAR_WP before the call, + accepted).
+AECM_FLOW_HD int32_t FlowFarendCall(FlowRegs &s, int mult, int len) {
+    if (!s.v[F_EC_STARTUP]) FlowDelayComp(s, mult);
+    const int32_t readable = (int32_t)((uint32_t)s.v[F_FAR_WP] - (uint32_t)s.v[F_FAR_RP]);
+    const int32_t accepted = FlowMin(len, kFlowJitterCapacity - readable);
+    s.v[F_FAR_WP] = (int32_t)((uint32_t)s.v[F_FAR_WP] + (uint32_t)accepted);
+    return accepted;
+}
+
+// WebRtcAecm_BufferFarend calls that come WITHOUT a WebRtcAecm_Process (a far-end burst: the network delivered several
+// frames between two ticks; WebRtcAecmSessions_BufferFarend).  Each is FlowFarendCall; the only other thing a burst has to
+// mind is the far ring of the device, which is longer than the jitter buffer but finite: a replay frame that lives in the
+// ring only (F_OLD_ROWi == 0) moves to its row before the burst's samples can lap it.  FlowBurstBegin decides that from
+// an upper bound of what `calls` calls of `len` samples can add (what is free now: delay compensation only ever makes
+// the buffer fuller), so the copy can be made before the first sample of the burst is written; a row taking over a
+// little early reads the same samples.  The wrapper fields a burst reads / writes: FlowBurstReads / FlowBurstWrites.
+struct FlowBurst {
+    int32_t spill[2];
+    uint32_t spill_pos[2];
+};
+AECM_FLOW_HD void FlowBurstBegin(FlowRegs &s, int len, int calls, FlowBurst &b) {
+    const int32_t readable = (int32_t)((uint32_t)s.v[F_FAR_WP] - (uint32_t)s.v[F_FAR_RP]);
+    const int64_t offered = (int64_t)len * calls;
+    const int32_t most = (int32_t)(offered < (int64_t)(kFlowJitterCapacity - readable) ? offered : (int64_t)(kFlowJitterCapacity - readable));
+    for (int i = 0; i < 2; ++i) {
+        b.spill_pos[i] = (uint32_t)s.v[F_OLD_POS0 + i];
+        b.spill[i] = !s.v[F_OLD_ROW0 + i] && (int32_t)((uint32_t)s.v[F_FAR_WP] + (uint32_t)most - (uint32_t)s.v[F_OLD_POS0 + i]) > kFlowOldAge;
+        if (b.spill[i]) s.v[F_OLD_ROW0 + i] = 1;
+    }
+}
+template <class Fn>
+AECM_FLOW_HD void FlowBurstReads(Fn &&fn) {
+    for (int f : {F_FAR_RP, F_FAR_WP, F_MS, F_EC_STARTUP, F_DELAY_CHANGE, F_OLD_POS0, F_OLD_POS1, F_OLD_ROW0, F_OLD_ROW1}) fn(f);
+}
+template <class Fn>
+AECM_FLOW_HD void FlowBurstWrites(Fn &&fn) {
+    for (int f : {F_FAR_RP, F_FAR_WP, F_DELAY_CHANGE, F_OLD_ROW0, F_OLD_ROW1}) fn(f);
 }
 
 // WebRtcAecm_EstBufDelay (:534-573).
@@ -266,12 +321,8 @@ AECM_FLOW_HD void FlowTick(FlowRegs &s, int fs, int n, int ms, int flags, uint32
         if (c >= n_calls) break;
         // ---- WebRtcAecm_BufferFarend (:215-234) ----
         if (!(flags & kFlowNoFarend)) {
-            if (!s.v[F_EC_STARTUP]) FlowDelayComp(s, mult);
-            const int32_t readable = (int32_t)((uint32_t)s.v[F_FAR_WP] - (uint32_t)s.v[F_FAR_RP]);
-            const int32_t accepted = FlowMin(len, kFlowJitterCapacity - readable);             // a full buffer drops the rest (ring_buffer.c:142-150)
             p.far[c].pos = (uint32_t)s.v[F_FAR_WP];
-            p.far[c].count = accepted;
-            s.v[F_FAR_WP] = (int32_t)((uint32_t)s.v[F_FAR_WP] + (uint32_t)accepted);
+            p.far[c].count = FlowFarendCall(s, mult, len);
         }
         // ---- WebRtcAecm_Process (:236-408) ----
         s.v[F_MS] = ms + 10;

@@ -122,6 +122,12 @@ struct TickFlowIo {
     int32_t ms, flags, fs;
 };
 hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowIo &fio, int n_streams, hipStream_t stream);
+// Far-end bursts: WebRtcAecm_BufferFarend calls WITHOUT a Process (reference echo_control_mobile.cc:215-234), one wavefront
+// per session.  Session s makes clamp(calls_per_session[s] - call_base, 0, max_calls) calls of io.n samples (max_calls each
+// when calls_per_session is null) on io.far_in[s][c * io.n .. + io.n): delay compensation when past the start-up phase, then
+// what fits into the jitter buffer goes to the far ring.  Of io only far_in / io_stride / n / far_ring / ring_len are used.
+hipError_t LaunchBufferFarend(const TickIo &io, const TickFlowIo &fio, const uint8_t *calls_per_session, int call_base, int max_calls, int n_streams,
+                              hipStream_t stream);
 // WebRtcAecm_Init of the wrapper side of sessions [first, first + count): wrapper state as after Init (aecm_flow_plan.h:
 // FlowFieldStartsAtOne), far / output rings, framed-far ring and replay rows reading as never written (zero).  Only the
 // ring pointers, ring_len and the state / far_frames / far_old pointers of io / fio are used.

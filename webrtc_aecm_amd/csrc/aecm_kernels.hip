@@ -411,6 +411,53 @@ hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowI
     return hipGetLastError();
 }
 
+// WebRtcAecm_BufferFarend calls without a Process (far-end bursts), one wavefront per session: the few wrapper fields a
+// burst touches (aecm_flow_plan.h: FlowBurstReads) into scalar registers, replay frames the burst could lap in the far
+// ring to their rows first, then call by call FlowFarendCall and the accepted samples into the far ring.  Session s makes
+// clamp(calls_per_session[s] - call_base, 0, max_calls) calls (everybody max_calls without the array) on the samples
+// far_in[s][c * n .. + n), c = 0, 1, ...
+__global__ __launch_bounds__(256)
+void aecm_buffer_farend_kernel(TickIo io, TickFlowIo fio, const uint8_t *calls_per_session, int call_base, int max_calls, int n_streams) {
+    const int64_t s = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (s >= n_streams) return;
+    const int lane = threadIdx.x & 63;
+    int calls = max_calls;
+    if (calls_per_session) calls = FlowMin(FlowMax((int)calls_per_session[s] - call_base, 0), max_calls);
+    calls = __builtin_amdgcn_readfirstlane(calls);
+    if (calls <= 0) return;
+    FlowRegs r;
+    FlowBurstReads([&](int f) { r.v[f] = __builtin_amdgcn_readfirstlane(fio.state[(size_t)f * n_streams + s]); });
+    const int mask = (int)io.ring_len - 1, n = io.n, mult = fio.fs == 16000 ? 2 : 1;
+    int16_t *fr = io.far_ring + s * io.ring_len, *old = fio.far_old + s * (2 * kFlowFrame);
+    const int16_t *fin = io.far_in + s * io.io_stride;
+    FlowBurst b;
+    FlowBurstBegin(r, n, calls, b);
+    if (b.spill[0] | b.spill[1]) {
+        for (int i = 0; i < 2; ++i) {
+            if (!b.spill[i]) continue;
+            int16_t *row = old + i * kFlowFrame;
+            const int16_t a0 = fr[(b.spill_pos[i] + lane) & mask], a1 = fr[(b.spill_pos[i] + 64 + (lane & 15)) & mask];
+            row[lane] = a0;
+            if (lane < kFlowFrame - 64) row[64 + lane] = a1;
+        }
+        // the rows have their samples (the stores above needed the loaded values) before the burst may overwrite them in the ring
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    for (int c = 0; c < calls; ++c) {
+        const unsigned pos = (unsigned)r.v[F_FAR_WP];
+        const int accepted = FlowFarendCall(r, mult, n);
+        for (int j = lane; j < accepted; j += 64) fr[(pos + (unsigned)j) & mask] = fin[c * n + j];
+    }
+    if (lane == 0) FlowBurstWrites([&](int f) { fio.state[(size_t)f * n_streams + s] = r.v[f]; });
+}
+
+hipError_t LaunchBufferFarend(const TickIo &io, const TickFlowIo &fio, const uint8_t *calls_per_session, int call_base, int max_calls, int n_streams,
+                              hipStream_t stream) {
+    if (n_streams <= 0 || max_calls <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aecm_buffer_farend_kernel, dim3((n_streams + 3) / 4), dim3(256), 0, stream, io, fio, calls_per_session, call_base, max_calls, n_streams);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256)
 void aecm_reset_sessions_kernel(TickIo io, TickFlowIo fio, int n_streams, int first) {
     const int64_t s = (int64_t)first + blockIdx.x;

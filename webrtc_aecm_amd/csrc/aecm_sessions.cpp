@@ -151,10 +151,90 @@ int32_t SessionBatch::Fail() {
     return AECM_UNSPECIFIED_ERROR;
 }
 
+// The caller's events are parameters: a stale or foreign handle is refused before anything is touched (a query of a
+// live event answers "done" or "not ready", never anything else), and refused without consequences for the sessions.
+bool SessionBatch::EventUsable(void *ev) const {
+    if (!ev) return true;
+    const hipError_t q = hipEventQuery(static_cast<hipEvent_t>(ev));
+    if (q == hipSuccess || q == hipErrorNotReady) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+// The next of the pinned per-session argument slots; when it is going to be written (needed), wait -- normally not at all --
+// until the launch that last read it has run.
+int SessionBatch::AcquireArgSlot(bool needed, bool *ok) {
+    const int slot = slot_;
+    slot_ = (slot_ + 1) % kArgSlots;
+    *ok = true;
+    if (needed && slot_busy_[slot]) {
+        *ok = AECM_HIP_OK(hipEventSynchronize(slot_read_[slot]));
+        slot_busy_[slot] = false;
+    }
+    return slot;
+}
+
+int32_t SessionBatch::BufferFarend(const int16_t *far, int64_t stride, size_t n_samples, int32_t calls, const uint8_t *calls_per_session,
+                                   bool host_pointers, bool wait, void *wait_event, void *done_event) {
+    if (far == nullptr) return AECM_NULL_POINTER_ERROR;                                  // the order of WebRtcAecm_GetBufferFarendError (:195-213)
+    if (fs_ == 0) return AECM_UNINITIALIZED_ERROR;
+    if (n_samples != 80 && n_samples != 160) return AECM_BAD_PARAMETER_ERROR;
+    if (calls < 0 || calls > 255 || stride < (int64_t)n_samples * calls) return AECM_BAD_PARAMETER_ERROR;
+    if (poisoned_) return AECM_UNSPECIFIED_ERROR;
+    const int S = engine_->num_streams(), n = (int)n_samples;
+    if (calls_per_session)
+        for (int s = 0; s < S; ++s)
+            if (calls_per_session[s] > calls) return AECM_BAD_PARAMETER_ERROR;
+    if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
+    if (!EventUsable(wait_event) || !EventUsable(done_event)) return AECM_BAD_PARAMETER_ERROR;
+    hipStream_t st = engine_->stream();
+    if (calls > 0) {
+        bool slot_ok;
+        const int slot = AcquireArgSlot(calls_per_session != nullptr, &slot_ok);
+        if (!slot_ok) return Fail();
+        if (calls_per_session) memcpy(flags_host_[slot], calls_per_session, (size_t)S);     // pinned + mapped: the kernel reads it in place
+        if (wait_event && !AECM_HIP_OK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(wait_event), 0))) {
+            (void)hipGetLastError();
+            return AECM_BAD_PARAMETER_ERROR;                                              // nothing has been enqueued: no poison
+        }
+        TickFlowIo fio{flow_state_, flow_plans_, far_frames_, far_old_, nullptr, nullptr, 0, 0, fs_};
+        const uint8_t *calls_dev = calls_per_session ? flags_dev_[slot] : nullptr;
+        bool ok = true;
+        if (!host_pointers) {
+            TickIo tio{far, nullptr, nullptr, nullptr, stride, n, far_ring_, nullptr, nullptr, nullptr, kRing, 0};
+            ok = AECM_HIP_OK(LaunchBufferFarend(tio, fio, calls_dev, 0, calls, S, st));
+        } else {
+            // host audio: staged through the ticks' device rows, as many calls per round as they hold
+            const int per_round = (4 * 160) / n;
+            for (int base = 0; base < calls && ok; base += per_round) {
+                const int round = std::min(per_round, calls - base);
+                const size_t width = (size_t)round * n * 2;
+                ok = AECM_HIP_OK(hipMemcpy2DAsync(io_dev_, width, far + (size_t)base * n, (size_t)stride * 2, width, S, hipMemcpyHostToDevice, st));
+                TickIo tio{io_dev_, nullptr, nullptr, nullptr, (int64_t)round * n, n, far_ring_, nullptr, nullptr, nullptr, kRing, 0};
+                ok = ok && AECM_HIP_OK(LaunchBufferFarend(tio, fio, calls_dev, base, round, S, st));
+            }
+        }
+        if (!ok) return Fail();
+        if (calls_per_session) {
+            if (!AECM_HIP_OK(hipEventRecord(slot_read_[slot], st))) return Fail();
+            slot_busy_[slot] = true;
+        }
+    }
+    if (done_event && !AECM_HIP_OK(hipEventRecord(static_cast<hipEvent_t>(done_event), st))) return Fail();
+    if ((wait || host_pointers) && !AECM_HIP_OK(hipStreamSynchronize(st))) return Fail();
+    return 0;
+}
+
 int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
                               int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
-                              bool host_pointers, void *wait_event, void *done_event) {
-    if (far == nullptr || near == nullptr || out == nullptr) return AECM_NULL_POINTER_ERROR;
+                              bool host_pointers, void *wait_event, void *done_event, int flags) {
+    if (near == nullptr || out == nullptr) return AECM_NULL_POINTER_ERROR;
+    if (far == nullptr) {                 // only a tick in which nobody makes a WebRtcAecm_BufferFarend call needs no far rows
+        bool nobody = flags_per_session ? true : (flags & kNoFarend) != 0;
+        if (flags_per_session && fs_ != 0)
+            for (int s = 0; s < engine_->num_streams() && nobody; ++s) nobody = (flags_per_session[s] & kNoFarend) != 0;
+        if (!nobody) return AECM_NULL_POINTER_ERROR;
+    }
     if (fs_ == 0) return AECM_UNINITIALIZED_ERROR;
     if (n_samples != 80 && n_samples != 160) return AECM_BAD_PARAMETER_ERROR;       // compared as size_t: 2^32 + 80 is not 80
     if (stride < (int64_t)n_samples) return AECM_BAD_PARAMETER_ERROR;
@@ -166,19 +246,11 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
     if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
     hipStream_t st = engine_->stream();
-    // The caller's events are parameters: a stale or foreign handle is refused before anything is touched (a query of a
-    // live event answers "done" or "not ready", never anything else), and refused without consequences for the sessions.
-    for (void *ev : {wait_event, done_event}) {
-        if (!ev) continue;
-        const hipError_t q = hipEventQuery(static_cast<hipEvent_t>(ev));
-        if (q != hipSuccess && q != hipErrorNotReady) {
-            (void)hipGetLastError();
-            return AECM_BAD_PARAMETER_ERROR;
-        }
-    }
-    if (flags_per_session && n != 160) {
-        uint8_t any = 0;
-        for (int s = 0; s < S; ++s) any |= flags_per_session[s];
+    if (!EventUsable(wait_event) || !EventUsable(done_event)) return AECM_BAD_PARAMETER_ERROR;
+    if (n != 160) {
+        uint8_t any = flags_per_session ? 0 : (uint8_t)flags;
+        if (flags_per_session)
+            for (int s = 0; s < S; ++s) any |= flags_per_session[s];
         if (any & kSplitCalls) return AECM_BAD_PARAMETER_ERROR;                           // two 80-sample calls need 160 samples
     }
     if (clean && !clean_ring_) {
@@ -187,13 +259,10 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
             return AECM_UNSPECIFIED_ERROR;
     }
     auto fail = [&]() -> int32_t { return Fail(); };
-    // this tick's argument slot: wait (normally not at all) until the planning kernel that last read it has run
-    const int slot = slot_;
-    slot_ = (slot_ + 1) % kArgSlots;
-    if ((ms_per_session || flags_per_session) && slot_busy_[slot]) {
-        if (!AECM_HIP_OK(hipEventSynchronize(slot_read_[slot]))) return fail();
-        slot_busy_[slot] = false;
-    }
+    // this tick's argument slot
+    bool slot_ok;
+    const int slot = AcquireArgSlot(ms_per_session || flags_per_session, &slot_ok);
+    if (!slot_ok) return fail();
     auto code_of = [](int16_t v) -> int32_t { return (v < 0 || v > 500) ? AECM_BAD_PARAMETER_WARNING : 0; };
     int32_t first_rc = 0;
     if (ms_per_session) {
@@ -220,6 +289,9 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
     if (flags_per_session) {
         memcpy(flags_host_[slot], flags_per_session, (size_t)S);
     }
+    // without far rows (nobody buffers a far frame in this tick) the kernel's far row pointer is never used for a sample that
+    // counts; it still has to be an address: the near rows
+    if (far == nullptr) far = near;
     const int16_t *dfar = far, *dnear = near, *dclean = clean;
     int16_t *dout = out;
     int64_t dstride = stride;
@@ -244,7 +316,7 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
     }
     TickIo tio{dfar, dnear, dclean, dout, dstride, n, far_ring_, near_ring_, clean_ring_, out_ring_, kRing, near_pos_};
     TickFlowIo fio{flow_state_, flow_plans_, far_frames_, far_old_, ms_per_session ? ms_dev_[slot] : nullptr,
-                   flags_per_session ? flags_dev_[slot] : nullptr, ms, 0, fs_};
+                   flags_per_session ? flags_dev_[slot] : nullptr, ms, flags & (kNoFarend | kSplitCalls), fs_};
     if (wait_event && !AECM_HIP_OK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(wait_event), 0))) {
         (void)hipGetLastError();
         return AECM_BAD_PARAMETER_ERROR;      // nothing of this tick has been enqueued (device pointers: no staging copies): no poison
@@ -263,9 +335,9 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
 
 int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride, size_t n_samples,
                            int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes,
-                           bool host_pointers) {
+                           bool host_pointers, int flags) {
     const int32_t rc = Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, host_pointers,
-                               nullptr, nullptr);
+                               nullptr, nullptr, flags);
     if (rc != 0 && rc != AECM_BAD_PARAMETER_WARNING) return rc;            // nothing was enqueued (or the object is poisoned)
     if (!AECM_HIP_OK(hipStreamSynchronize(engine_->stream()))) return Fail();
     return rc;
@@ -273,8 +345,8 @@ int32_t SessionBatch::Tick(const int16_t *far, const int16_t *near, const int16_
 
 int32_t SessionBatch::TickAsync(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stride,
                                 size_t n_samples, int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session,
-                                int32_t *codes, void *wait_event, void *done_event) {
-    return Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, false, wait_event, done_event);
+                                int32_t *codes, void *wait_event, void *done_event, int flags) {
+    return Enqueue(far, near, clean, out, stride, n_samples, ms, ms_per_session, flags_per_session, codes, false, wait_event, done_event, flags);
 }
 
 // ---- session snapshots ---------------------------------------------------------------------------------

@@ -46,15 +46,24 @@ public:
     //     bit 1 (kSplitCalls, 160-sample ticks only) = this session makes TWO BufferFarend + Process call pairs of 80
     //     samples in this tick instead of one of 160 (the reference treats the two cadences differently:
     //     echo_control_mobile.cc:282-283, 384-385).
+    //   flags: the same bits for every session when flags_per_session is null.
+    //   far may be null when no session makes a BufferFarend call in this tick (kNoFarend for everybody).
     int32_t Tick(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
-                 int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers);
+                 int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers, int flags = 0);
     // The same tick, enqueued on the object's stream without waiting for it (device pointers, or host memory the device
     // can address: see RegisterHostAudio): the two launches of tick t + 1 may be issued while tick t still runs.
     // wait_event (hipEvent_t, may be null): the tick's kernels wait for it first (the caller's producer of far / near);
     // done_event (hipEvent_t, may be null): recorded behind the tick (the caller's consumer of out waits for it).
     int32_t TickAsync(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
                       int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, void *wait_event,
-                      void *done_event);
+                      void *done_event, int flags = 0);
+    // Far-end bursts: WebRtcAecm_BufferFarend calls that come without a WebRtcAecm_Process (reference
+    // echo_control_mobile.cc:215-234) -- session s makes calls_per_session[s] (host array, S entries <= calls; null:
+    // everybody makes `calls`) consecutive calls of n samples on far[s][c * n .. + n).  Together with ticks whose sessions are
+    // flagged kNoFarend (far may then be null) any interleaving of the two reference calls can be expressed per session.
+    // Enqueued on the object's stream like a tick (device pointers; host pointers are staged and the call waits).
+    int32_t BufferFarend(const int16_t *far, int64_t stream_stride, size_t n, int32_t calls, const uint8_t *calls_per_session, bool host_pointers,
+                         bool wait, void *wait_event, void *done_event);
     int32_t Synchronize();
     static constexpr uint8_t kNoFarend = kFlowNoFarend, kSplitCalls = kFlowSplitCalls;
 
@@ -106,7 +115,9 @@ private:
     int slot_ = 0;
     int32_t Enqueue(const int16_t *far, const int16_t *near, const int16_t *clean, int16_t *out, int64_t stream_stride, size_t n,
                     int16_t ms, const int16_t *ms_per_session, const uint8_t *flags_per_session, int32_t *codes, bool host_pointers,
-                    void *wait_event, void *done_event);
+                    void *wait_event, void *done_event, int flags);
+    bool EventUsable(void *ev) const;
+    int AcquireArgSlot(bool needed, bool *ok);
     int32_t Fail();
     int device_ = 0;
 };

@@ -146,6 +146,11 @@ def load():
     lib.WebRtcAecmSessions_InitEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmSessions_GetEchoPath.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     lib.WebRtcAecmSessions_TickAsync.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16, vp, vp, vp, vp, vp]
+    lib.WebRtcAecmSessions_BufferFarend.argtypes = [vp, vp, C.c_int64, C.c_size_t, C.c_int32, vp]
+    lib.WebRtcAecmSessions_BufferFarendHost.argtypes = [vp, vp, C.c_int64, C.c_size_t, C.c_int32, vp]
+    lib.WebRtcAecmSessions_BufferFarendAsync.argtypes = [vp, vp, C.c_int64, C.c_size_t, C.c_int32, vp, vp, vp]
+    lib.WebRtcAecmSessions_Process.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16, vp, vp]
+    lib.WebRtcAecmSessions_ProcessHost.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_size_t, C.c_int16, vp, vp]
     lib.WebRtcAecmSessions_Synchronize.argtypes = [vp]
     lib.WebRtcAecmSessions_SetKernelVariant.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmBatch_RegisterHostBuffer.argtypes = [C.c_int32, vp, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -459,6 +464,59 @@ class AecmSessions:
                                                            far.shape[1], far.shape[1], ms.ctypes.data, fl.ctypes.data,
                                                            codes.ctypes.data)
         return rc, out, codes
+
+    def buffer_farend_host(self, far, n: int, calls: int, calls_per_session=None) -> int:
+        """Far-end burst (include/aecm_batch.h: WebRtcAecmSessions_BufferFarendHost): far [S, >= calls * n] int16; session s
+        makes calls_per_session[s] (or `calls`) WebRtcAecm_BufferFarend calls of n samples."""
+        far = np.ascontiguousarray(far, dtype=np.int16)
+        if far.ndim != 2 or far.shape[0] != self.num_streams:
+            raise ValueError(f"far must be [{self.num_streams}, >= calls * n] int16, got {far.shape}")
+        cp = None
+        if calls_per_session is not None:
+            calls_per_session = np.ascontiguousarray(calls_per_session, dtype=np.uint8)
+            if calls_per_session.shape != (self.num_streams,):
+                raise ValueError("calls_per_session must have one entry per session")
+            cp = calls_per_session.ctypes.data
+        return self.lib.WebRtcAecmSessions_BufferFarendHost(self.h, far.ctypes.data, far.shape[1], n, calls, cp)
+
+    def buffer_farend_device(self, far_ptr, stream_stride, n, calls, calls_per_session=None, asynchronous=False, wait_event=None, done_event=None):
+        cp = None
+        if calls_per_session is not None:
+            calls_per_session = np.ascontiguousarray(calls_per_session, dtype=np.uint8)
+            cp = calls_per_session.ctypes.data
+        if asynchronous:
+            return self.lib.WebRtcAecmSessions_BufferFarendAsync(self.h, far_ptr, stream_stride, n, calls, cp, wait_event, done_event)
+        return self.lib.WebRtcAecmSessions_BufferFarend(self.h, far_ptr, stream_stride, n, calls, cp)
+
+    def process_host(self, near, ms=40, clean=None, ms_per_session=None):
+        """Every session's WebRtcAecm_Process without a WebRtcAecm_BufferFarend (WebRtcAecmSessions_ProcessHost).
+        Returns (code, out, codes[S])."""
+        near = np.ascontiguousarray(near, dtype=np.int16)
+        if near.ndim != 2 or near.shape[0] != self.num_streams:
+            raise ValueError(f"near must be [{self.num_streams}, n] int16, got {near.shape}")
+        cptr = msp = None
+        if clean is not None:
+            clean = np.ascontiguousarray(clean, dtype=np.int16)
+            if clean.shape != near.shape:
+                raise ValueError("clean must have the shape of near")
+            cptr = clean.ctypes.data
+        if ms_per_session is not None:
+            ms_per_session = np.ascontiguousarray(ms_per_session, dtype=np.int16)
+            if ms_per_session.shape != (self.num_streams,):
+                raise ValueError("ms_per_session must have one entry per session")
+            msp = ms_per_session.ctypes.data
+        out = np.empty_like(near)
+        codes = np.zeros(self.num_streams, dtype=np.int32)
+        rc = self.lib.WebRtcAecmSessions_ProcessHost(self.h, near.ctypes.data, cptr, out.ctypes.data, near.shape[1], near.shape[1], ms, msp,
+                                                     codes.ctypes.data)
+        return rc, out, codes
+
+    def process_device(self, near_ptr, out_ptr, stream_stride, n, ms=40, clean_ptr=None, ms_per_session=None):
+        msp = None
+        if ms_per_session is not None:
+            ms_per_session = np.ascontiguousarray(ms_per_session, dtype=np.int16)
+            msp = ms_per_session.ctypes.data
+        return self.lib.WebRtcAecmSessions_Process(self.h, near_ptr, clean_ptr, out_ptr, stream_stride, n, ms, msp, None)
 
     def init_session(self, session: int) -> int:
         return self.lib.WebRtcAecmSessions_InitSession(self.h, session)
