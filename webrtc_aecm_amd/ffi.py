@@ -51,7 +51,8 @@ SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_InitSession", "WebRtcAecmSessions_set_config_session", "WebRtcAecmSessions_InitEchoPath",
     "WebRtcAecmSessions_GetEchoPath", "WebRtcAecmSessions_TickAsync", "WebRtcAecmSessions_Synchronize",
     "WebRtcAecmSessions_SetKernelVariant", "WebRtcAecmSessions_session_size_bytes", "WebRtcAecmSessions_ExportSession",
-    "WebRtcAecmSessions_ImportSession",
+    "WebRtcAecmSessions_ImportSession", "WebRtcAecmSessions_BufferFarend", "WebRtcAecmSessions_BufferFarendHost",
+    "WebRtcAecmSessions_BufferFarendAsync", "WebRtcAecmSessions_Process", "WebRtcAecmSessions_ProcessHost",
 ]
 SESSION_NO_FAREND = 1
 SESSION_SPLIT_CALLS = 2
