@@ -299,6 +299,51 @@ int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, i
 int32_t WebRtcAecmBatch_DescribeLaunchFor(int32_t num_streams, int32_t compute_units, int32_t num_blocks, int32_t has_clean_input,
                                           int32_t *chunk_blocks);
 
+/* The launch policy: every threshold and wish that decides how a ProcessBlocks launch is scheduled, as ONE value.  The library derives
+ * it from the device's compute units (WebRtcAecmBatch_DefaultLaunchPolicy does the same without a device) and from what its kernels are
+ * built for; a caller may read it, change fields and set it back (per batch).  Results never depend on it.  The shipped library reads
+ * no environment variable: experiments set a policy, or use a build with -DAECM_EXPERIMENTS (tools/ab_build.py) whose default policy
+ * takes the AECM_* wishes of the environment.
+ *   struct_size            sizeof(AecmLaunchPolicy) of the caller's header (the calls refuse another size)
+ *   compute_units          of the device (Set refuses a policy made for another count)
+ *   queue_chunk_blocks     chunk queue: blocks per item (128); 0 = never the queue: one wavefront keeps one stream for the whole launch
+ *   queue_chunk_explicit   0: the default length, quartered (to at least 8) while every stream's wavefront is resident at once; 1: as given
+ *   queue_min_streams      the queue above this many streams; -1: above pipelined_max_streams
+ *   pipelined_min_streams  the smallest batch whose launches run pipelined (2); larger than the batch: never
+ *   pipelined_min_blocks   the shortest launch that does (3: the pipeline's fill and drain steps cost more than they save below)
+ *   pipelined_max_streams  the largest batch that does (16 per compute unit: what the chip holds of the widest shape)
+ *   resident_waves         wavefronts of the one-wavefront-per-stream kernels the chip holds (28 per compute unit)
+ *   rotation_stream_limit  launches of at most this many streams take the kernel variants built for full residency
+ *   pipe_*                 wishes for the pipelined form's shape, -1 = by size (tests, experiments): tail wavefronts 0 / 2, front wavefronts
+ *                          2 / 4, raw hand-over 0 / 1, delay wavefronts 0 / 2 / 4, gain wavefronts 0 / 4; pipe_spread 1 = every compute
+ *                          unit gets the shape's full count of workgroups, of fewer than four streams each where the launch is short of
+ *                          streams (0: workgroups of four); pipe_wgs_per_cu > 0 = workgroups of the shape a compute unit takes;
+ *                          pipe_rot >= 0 = the slot rotations (csrc/aecm_kernels.h: PipeShape::rot) */
+typedef struct AecmLaunchPolicy {
+    int32_t struct_size;
+    int32_t compute_units;
+    int32_t queue_chunk_blocks, queue_chunk_explicit, queue_min_streams;
+    int32_t pipelined_min_streams, pipelined_min_blocks, pipelined_max_streams;
+    int32_t resident_waves, rotation_stream_limit;
+    int32_t pipe_tail_waves, pipe_front_waves, pipe_raw, pipe_delay_waves, pipe_gain_waves, pipe_spread, pipe_wgs_per_cu, pipe_rot;
+} AecmLaunchPolicy;
+int32_t WebRtcAecmBatch_DefaultLaunchPolicy(int32_t compute_units, AecmLaunchPolicy *policy);
+int32_t WebRtcAecmBatch_GetLaunchPolicy(const AecmBatch *b, AecmLaunchPolicy *policy);
+int32_t WebRtcAecmBatch_SetLaunchPolicy(AecmBatch *b, const AecmLaunchPolicy *policy);
+/* What a launch looks like on the device, for capacity planning (no device needed): the form and its detail as DescribeLaunch gives
+ * them, the grid, and how the grid quantises on the chip -- rounds_x1000 = 1000 x workgroups / (compute units x workgroups a compute
+ * unit holds at once): 1000 = the chip exactly full once; 9140 = nine full rounds and a last one 14 % full (65 536 sessions' tick).
+ * policy == NULL: the default policy of compute_units.  WebRtcAecmSessions_DescribeTick: the same for one tick of num_sessions sessions. */
+typedef struct AecmLaunchDescription {
+    int32_t form, chunk_blocks, shape;
+    int32_t workgroups, waves_per_workgroup, workgroups_per_cu, rounds_x1000;
+} AecmLaunchDescription;
+int32_t WebRtcAecmBatch_DescribeLaunchDetail(const AecmLaunchPolicy *policy, int32_t compute_units, int32_t num_streams, int32_t num_blocks,
+                                             int32_t has_clean_input, AecmLaunchDescription *out);
+int32_t WebRtcAecmSessions_DescribeTick(int32_t num_sessions, int32_t compute_units, AecmLaunchDescription *out);
+/* The HIP device WebRtcAecm_Create (which has no device argument) puts its sessions on from now on; process-wide, default 0. */
+int32_t WebRtcAecm_SetDefaultDevice(int32_t device_id);
+
 /* Device self test of the wave primitives on device_id; failures[0..7] must all be 0 afterwards
  * (see webrtc_aecm_amd/csrc/aecm_kernels.h).  exhaustive != 0 checks floor-sqrt on all of [0, 2^31). */
 int32_t WebRtcAecmBatch_SelfTest(int32_t device_id, int32_t exhaustive, uint64_t failures[8]);

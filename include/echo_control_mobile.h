@@ -36,8 +36,8 @@ typedef struct {                                  /* reference echo_control_mobi
 extern "C" {
 #endif
 
-/* reference :46   Allocates an instance (device state for one stream on HIP device
- *                 $AECM_DEVICE, default 0).  NULL on failure (including "no usable GPU"). */
+/* reference :46   Allocates an instance (device state for one stream on HIP device 0, or the one named by
+ *                 WebRtcAecm_SetDefaultDevice of aecm_batch.h).  NULL on failure (including "no usable GPU"). */
 void *WebRtcAecm_Create(void);
 
 /* reference :55   Releases the instance; NULL is a no-op. */

@@ -4,6 +4,8 @@ import ctypes
 import re
 from pathlib import Path
 
+import ctypes as C
+
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -49,36 +51,79 @@ def test_no_cpu_fallback_without_gpu(gpu_available):
     assert lib.WebRtcAecm_Init(None, 16000) == -1
 
 
-def test_launch_form_rules_without_a_device(monkeypatch):
-    """Which kernel a launch takes is host logic (WebRtcAecmBatch_DescribeLaunchFor: the engine's own rules for a device of that
-    many CUs; tests/test_gpu_parity.py::test_launch_form_by_size asks a live engine the same questions): one stream -> one
-    wavefront; up to 4 x 4 x CUs streams and at least three blocks -> pipelined, the shape by workgroups per CU (sixteen waves
-    per four streams up to one per CU, ten up to two, eight up to three, six -- balanced in launches of >= 128 blocks -- above);
-    more -> the chunk queue where the launch is at least two chunks long; never pipelined with a clean input."""
-    for k in ("AECM_PIPE_TAIL", "AECM_PIPE_FRONT", "AECM_PIPE_RAW", "AECM_PIPE_DELAY", "AECM_PIPE_GAIN", "AECM_PIPELINED", "AECM_PIPE_MIN_BLOCKS",
-              "AECM_QUEUE_CHUNK", "AECM_QUEUE_MIN_STREAMS"):
-        monkeypatch.delenv(k, raising=False)
+def test_launch_form_rules_without_a_device():
+    """Which kernel a launch takes is host logic (WebRtcAecmBatch_DescribeLaunchFor / DescribeLaunchDetail: the engine's own rules for
+    a device of that many CUs; tests/test_gpu_parity.py::test_launch_form_by_size asks a live engine the same questions): one stream ->
+    one wavefront; up to 4 x 4 x CUs streams and at least three blocks -> pipelined, the shape by streams per CU (sixteen waves per
+    workgroup up to eight streams per CU -- two such workgroups --, eight waves up to twelve, six -- balanced in launches of >= 128
+    blocks -- above); more -> the chunk queue where the launch is at least two chunks long; never pipelined with a clean input."""
     import webrtc_aecm_amd as aecm
     for cus in (256, 304, 64):
         pipe_max, resident, rotation, tail_max = cus * 16, cus * 28, cus * 24, cus * 12
         for S, T, clean, want in ((1, 300, False, (0, 0)), (2, 300, False, (3, 0x1a02)), (cus * 4, 300, False, (3, 0x1a02)), (cus * 4, 2, False, (0, 0)),
-                                  (cus * 4, 3, False, (3, 0x1a02)), (cus * 4 + 1, 300, False, (3, 0x602)), (cus * 8, 300, False, (3, 0x602)),
+                                  (cus * 4, 3, False, (3, 0x1a02)), (cus * 4 + 1, 300, False, (3, 0x1a02)), (cus * 8, 300, False, (3, 0x1a02)),
                                   (cus * 8 + 1, 300, False, (3, 0x402)), (tail_max, 300, False, (3, 0x402)), (tail_max + 1, 300, False, (3, 0x500)),
                                   (pipe_max, 100, False, (3, 0)),
-                                  (pipe_max, 300, False, (3, 0x500 if pipe_max <= 4096 else 0)),      # (the balance's monitor reads at most 1 024 workgroups' words)
+                                  (pipe_max, 300, False, (3, 0x500 if pipe_max <= 5120 else 0)),      # (the balance's monitor reads at most 1 280 workgroups' words)
                                   (pipe_max, 300, True, (0, 0)),
                                   (pipe_max + 1, 300, False, (2, 32)), (pipe_max + 1, 63, False, (0, 0)), (rotation + 1, 63, False, (1, 0)),
                                   (resident, 64, True, (2, 32)), (resident + 1, 255, False, (1, 0)), (resident + 1, 256, False, (2, 128))):
             assert aecm.describe_launch_for(S, cus, T, clean) == want, (cus, S, T, clean, aecm.describe_launch_for(S, cus, T, clean))
-    # the environment's wishes reach it like they reach an engine
-    monkeypatch.setenv("AECM_PIPE_GAIN", "0")
-    assert aecm.describe_launch_for(1024, 256, 300) == (3, 0x802)
-    monkeypatch.setenv("AECM_PIPE_DELAY", "0")
-    assert aecm.describe_launch_for(1024, 256, 300) == (3, 0x2)
-    monkeypatch.setenv("AECM_PIPELINED", "0")
-    assert aecm.describe_launch_for(1024, 256, 300) == (0, 0)
+            d = aecm.describe_launch_detail(S, T, cus, clean)
+            assert (d["form"], d["chunk_blocks"] if d["form"] == 2 else d["shape"] if d["form"] == 3 else 0) == want, (cus, S, T, d)
     with pytest.raises(aecm.AecmError):
         aecm.describe_launch_for(0, 256, 300)
+
+
+def test_launch_policy_is_one_value_and_the_library_reads_no_environment(monkeypatch):
+    """The launch policy through the C ABI (AecmLaunchPolicy): the default derives from the CU count alone, wishes set on it reach
+    the launch rules, invalid values are refused; and the shipped build consults no environment variable -- neither for the policy
+    (the AECM_* wishes of an -DAECM_EXPERIMENTS build are ignored) nor anywhere else (no getenv outside AECM_EXPERIMENTS)."""
+    import re
+    import webrtc_aecm_amd as aecm
+    from webrtc_aecm_amd import ffi
+    for k, v in (("AECM_PIPE_GAIN", "0"), ("AECM_PIPE_DELAY", "0"), ("AECM_PIPELINED", "0"), ("AECM_QUEUE_CHUNK", "7"), ("AECM_PIPE_SPREAD", "0")):
+        monkeypatch.setenv(k, v)
+    p = aecm.default_launch_policy(256)
+    assert p.as_dict() == dict(struct_size=C.sizeof(ffi.AecmLaunchPolicy), compute_units=256, queue_chunk_blocks=128, queue_chunk_explicit=0,
+                               queue_min_streams=-1, pipelined_min_streams=2, pipelined_min_blocks=3, pipelined_max_streams=4096,
+                               resident_waves=7168, rotation_stream_limit=6144, pipe_tail_waves=-1, pipe_front_waves=-1, pipe_raw=-1,
+                               pipe_delay_waves=-1, pipe_gain_waves=-1, pipe_spread=1, pipe_wgs_per_cu=0, pipe_rot=-1)
+    assert aecm.describe_launch_for(1024, 256, 300) == (3, 0x1a02)                      # the environment above changed nothing
+    # wishes on a policy
+    shape = lambda **kw: (lambda q: [setattr(q, k, v) for k, v in kw.items()] and aecm.describe_launch_detail(1024, 300, policy=q))(aecm.default_launch_policy(256))
+    assert shape(pipe_gain_waves=0)["shape"] == 0x802
+    assert shape(pipe_delay_waves=0)["shape"] == 0x2 and shape(pipe_delay_waves=0, pipe_raw=1, pipe_front_waves=4)["shape"] == 0x602
+    assert shape(pipe_tail_waves=0)["shape"] == 0x0
+    assert shape(pipelined_min_streams=0)["form"] == 0
+    assert shape(queue_min_streams=0, pipelined_min_streams=5000) == dict(form=2, chunk_blocks=32, shape=0, workgroups=256, waves_per_workgroup=4,
+                                                                           workgroups_per_cu=7, rounds_x1000=142)
+    # every CU its full count of workgroups: 1 536 streams = two sixteen-wave workgroups of three streams per CU; without the spread, 384 of four
+    d = aecm.describe_launch_detail(1536, 300, 256)
+    assert (d["workgroups"], d["waves_per_workgroup"], d["workgroups_per_cu"], d["rounds_x1000"]) == (512, 16, 2, 1000)
+    assert shape(pipe_spread=0)["workgroups"] == 256 and aecm.describe_launch_detail(2560, 300, 256)["workgroups"] == 768
+    # a tick of 65 536 sessions: 16 384 workgroups on 1 792 places (the last round 14 % full)
+    assert aecm.describe_tick(65536, 256) == dict(form=0, chunk_blocks=0, shape=0, workgroups=16384, waves_per_workgroup=4, workgroups_per_cu=7,
+                                                  rounds_x1000=9142)
+    # refused: another struct size, values outside what the kernels exist for
+    for bad in (dict(struct_size=8), dict(pipe_front_waves=3), dict(pipe_gain_waves=2), dict(queue_chunk_blocks=-1), dict(pipelined_max_streams=5000),
+                dict(pipe_rot=4096)):
+        q = aecm.default_launch_policy(256)
+        for k, v in bad.items():
+            setattr(q, k, v)
+        with pytest.raises(aecm.AecmError):
+            aecm.describe_launch_detail(1024, 300, policy=q)
+    # no getenv in the default build: every use in the sources sits between #if defined(AECM_EXPERIMENTS) / AECM_PIPE_TRACE and its #endif
+    for src in sorted((ROOT / "webrtc_aecm_amd" / "csrc").glob("*")):
+        depth_exp, stack = 0, []
+        for n, line in enumerate(src.read_text().splitlines(), 1):
+            t = line.strip()
+            if t.startswith("#if"):
+                stack.append(bool(re.search(r"AECM_EXPERIMENTS|AECM_PIPE_TRACE", t)))
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            elif "getenv" in t and not t.startswith("//"):
+                assert any(stack), f"{src.name}:{n}: getenv in the default build"
 
 
 def test_product_does_not_use_the_oracle():

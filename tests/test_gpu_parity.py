@@ -695,7 +695,12 @@ def test_pipelined_launch_sizes_and_lengths(fs):
     continue each other across forms (pipelined, one wavefront per stream, pipelined): outputs and complete state."""
     T_parts = (1, 2, 3, 130, 64)
     T = sum(T_parts)
-    for S in (1, 2, 3, 4, 5, 7, 9, 333):
+    cus = aecm.device_info(0)[1]
+    # (round 6) sizes between the shapes' full loads: every CU then gets its full count of workgroups, of one to four streams
+    # each -- 2 x cus + 88: sixteen-wave workgroups of 3 and 2; 6 x cus: ten-wave workgroups of 3 (1 536 streams on an MI355X);
+    # 10 x cus: eight-wave workgroups of 4 and 3 (2 560); 14 x cus - 3: six-wave workgroups of 4 and 3
+    sizes = (1, 2, 3, 4, 5, 7, 9, 333, 2 * cus + 88, 6 * cus, 10 * cus, 14 * cus - 3) if fs == 16000 else (1, 3, 5, 333, 5 * cus + 1)
+    for S in sizes:
         seeds = list(range(7500, 7500 + min(S, 24)))
         far, near = synth_streams(seeds, T, fs)
         exp = []
@@ -714,32 +719,44 @@ def test_pipelined_launch_sizes_and_lengths(fs):
             outs.append(b.process_host(far_s[:, pos * 64:(pos + t) * 64], near_s[:, pos * 64:(pos + t) * 64]))
             pos += t
         out = np.concatenate(outs, axis=1)
-        for s in range(S):
-            assert np.array_equal(out[s], exp[idx[s]][0]), (S, s)
+        want = np.stack([e[0] for e in exp])[idx]
+        bad = np.nonzero((out != want).any(axis=1))[0]
+        assert bad.size == 0, (S, bad[:8].tolist())
+        for s in (range(S) if S < 400 else list(range(0, S, S // 97)) + [S - 1]):
             assert np.array_equal(b.digest(s), exp[idx[s]][1]), (S, s, describe_digest_diff(b.digest(s), exp[idx[s]][1]))
         b.close()
 
 
 @pytest.mark.parametrize("wish,shape", [({}, 0x1a02),                                            # by size: sixteen waves (delay + gain waves)
-                                        ({"AECM_PIPE_GAIN": "0"}, 0x802),                       # twelve: delay waves, one per stream
-                                        ({"AECM_PIPE_DELAY": "0"}, 0x2),                        # eight: two tail waves
-                                        ({"AECM_PIPE_DELAY": "0", "AECM_PIPE_RAW": "1"}, 0x402),
-                                        ({"AECM_PIPE_DELAY": "0", "AECM_PIPE_RAW": "1", "AECM_PIPE_FRONT": "4"}, 0x602),
-                                        ({"AECM_PIPE_TAIL": "0"}, 0x0)])                        # six: the two-role form
-def test_pipelined_shapes_by_wish(monkeypatch, wish, shape):
-    """Every instantiation of the pipelined kernel a small launch can be given (the engine reads the AECM_PIPE_* wishes when it is
-    created): 11 streams (the last workgroup has three of its four, a two-stream wave one of its two) through launches of 1, 2,
+                                        ({"pipe_gain_waves": 0}, 0x802),                        # twelve: delay waves, one per stream
+                                        ({"pipe_delay_waves": 0}, 0x2),                         # eight: two tail waves
+                                        ({"pipe_delay_waves": 0, "pipe_raw": 1}, 0x402),
+                                        ({"pipe_delay_waves": 0, "pipe_raw": 1, "pipe_front_waves": 4}, 0x602),
+                                        ({"pipe_tail_waves": 0}, 0x0),                          # six: the two-role form
+                                        # workgroups of four streams, the last one partly empty (the form of rounds 4 and 5)
+                                        ({"pipe_spread": 0}, 0x1a02),
+                                        ({"pipe_spread": 0, "pipe_delay_waves": 0, "pipe_raw": 1, "pipe_front_waves": 4}, 0x602),
+                                        ({"pipe_spread": 0, "pipe_tail_waves": 0}, 0x0),
+                                        # every slot rotation at its other values (any bijection of waves to slots is correct)
+                                        ({"pipe_rot": 2 | (3 << 2) | (1 << 4) | (1 << 6) | (1 << 8)}, 0x1a02),
+                                        ({"pipe_spread": 0, "pipe_rot": 3 | (2 << 2) | (2 << 4) | (3 << 6) | (3 << 8)}, 0x1a02),
+                                        ({"pipe_spread": 0, "pipe_gain_waves": 0, "pipe_rot": 1 | (3 << 4) | (1 << 8)}, 0x802),
+                                        ({"pipe_spread": 0, "pipe_delay_waves": 0, "pipe_raw": 1, "pipe_rot": 1 | (2 << 6) | (3 << 8)}, 0x402),
+                                        ({"pipe_spread": 0, "pipe_tail_waves": 0, "pipe_rot": 3 | (1 << 6)}, 0x0)])
+def test_pipelined_shapes_by_wish(wish, shape):
+    """Every instantiation of the pipelined kernel a small launch can be given (wishes on the batch's launch policy:
+    WebRtcAecmBatch_SetLaunchPolicy): 11 streams (one per workgroup: the other slots' waves only keep the barriers; with
+    pipe_spread = 0 two workgroups of four and one of three, a two-stream wave with one of its two) through launches of 1, 2,
     3, 4, 5 and 150 blocks -- each role's idle steps in front of and behind its block loop, the slot rings of two, three and four
     steps, the fixed-delay configuration (the delay waves' AlignedFarend then never uses the estimate) -- outputs and complete
     state against the oracle."""
-    for k, v in wish.items():
-        monkeypatch.setenv(k, v)
     fs, S, T_parts = 16000, 11, (1, 2, 3, 4, 5, 150)
     T = sum(T_parts)
     seeds = list(range(7700, 7700 + S))
     far, near = synth_streams(seeds, T, fs)
     b = aecm.AecmBatch(S, fs)
     b.set_launch_pipelining(2)                               # (a threshold set through the ABI: launches of any length, not only of three blocks and more)
+    b.set_launch_policy(**wish)
     exp = []
     for k in range(S):
         o = pyoracle.OracleStream(fs, *stream_config(k))
@@ -831,8 +848,8 @@ def test_launch_form_by_size():
     tail_max = cus * 12                       # eight-wave workgroups (two tail waves) come three to a CU
     # pipelined launches: the second value is the shape (tail waves | 0x100 balanced | 0x200 four front waves | 0x400 raw hand-over | 0x800 delay
     # waves | 0x1000 gain waves)
-    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 0x1a02), (cus * 4, 300, False, 3, 0x1a02), (cus * 4 + 1, 300, False, 3, 0x602),
-                                          (cus * 8, 300, False, 3, 0x602),
+    for S, T, clean, want, want_chunk in ((1, 300, False, 0, 0), (2, 300, False, 3, 0x1a02), (cus * 4, 300, False, 3, 0x1a02), (cus * 4 + 1, 300, False, 3, 0x1a02),
+                                          (cus * 8, 300, False, 3, 0x1a02), (cus * 8 + 1, 300, False, 3, 0x402),
                                           (tail_max, 300, False, 3, 0x402), (tail_max + 1, 300, False, 3, 0x500),
                                           (pipe_max, 3, False, 3, 0), (pipe_max, 2, False, 0, 0), (cus * 4, 2, False, 0, 0), (cus * 4, 3, False, 3, 0x1a02),
                                           (pipe_max, 300, False, 3, 0x500), (pipe_max, 300, True, 0, 0),
@@ -842,6 +859,7 @@ def test_launch_form_by_size():
         b = aecm.AecmBatch(S, 16000)
         form, chunk = b.describe_launch(T, clean)
         assert (form, chunk) == (want, want_chunk), (S, T, clean, form, chunk)
+        assert b.launch_policy().as_dict() == aecm.default_launch_policy(cus).as_dict()       # derived from the device's CU count alone
         if S == pipe_max:
             b.set_variant(aecm.KERNEL_SAFE)
             assert b.describe_launch(T, clean)[0] == 0

@@ -45,8 +45,7 @@ def main():
         b.synchronize()
     ms = b.last_launch_ms()
     rec = np.fromfile(trace, dtype=np.uint64).reshape(-1, 16, 4).astype(np.int64)       # [workgroup][wave][t0, t1, wait, total]; waves a workgroup does not have read 0
-    n_wg = (S + 3) // 4
-    rec = rec[:n_wg]
+    n_wg = rec.shape[0]                      # one record set per workgroup of the launch (workgroups need not hold four streams)
     hw_id, xcc = rec[:, :, 2] >> 40, (rec[:, :, 3] >> 40) & 0xf           # placement (see the kernel's trace epilogue)
     rec[:, :, 2] &= (1 << 40) - 1
     rec[:, :, 3] &= (1 << 40) - 1
@@ -99,6 +98,13 @@ def main():
     res["simd_mixes_back/front/tail/delay/gain_count"] = dict(sorted(mixes.items(), key=lambda kv: -kv[1])[:16])
     res["first_workgroups_simd_of_each_wave"] = [simd[w].tolist() for w in range(min(n_wg, 6))]
     res["first_workgroups_cu"] = [hex(int(cu_key[w, 0])) for w in range(min(n_wg, 12))]
+    # which workgroups share a CU (by dispatch index) and where their waves sit: the CUs of workgroups 0, 1 and 9
+    res["cu_mates"] = {}
+    for w0 in (0, 1, 9):
+        if w0 < n_wg:
+            mates = [w for w in range(n_wg) if cu_key[w, 0] == cu_key[w0, 0]]
+            res["cu_mates"][str(w0)] = {str(w): simd[w].tolist() for w in mates}
+    res["workgroups_per_cu_histogram"] = {str(k): int(v) for k, v in zip(*np.unique([sum(1 for w in range(n_wg) if cu_key[w, 0] == c) for c in per], return_counts=True))}
     print(json.dumps(res))
     os.unlink(trace)
 

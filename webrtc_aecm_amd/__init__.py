@@ -4,7 +4,10 @@ The hot path -- WebRtcAecm_ProcessBlock of cpuimage/WebRTC_AECM -- is hand-writt
 (one wavefront per stream, webrtc_aecm_amd/csrc/), exposed through the reference's own C ABI plus a
 batch extension (include/*.h).  This package only builds and binds that shared library.
 """
-from .ffi import (check_counters, Aecm, AecmBatch, AecmSessions, AecmConfig, AecmError, KERNEL_FAST, KERNEL_SAFE, debug_fft128,  # noqa: F401
-                  describe_launch_for, device_info, library_path, load, register_host_buffer, self_test, unregister_host_buffer)
+from .ffi import (check_counters, Aecm, AecmBatch, AecmSessions, AecmConfig, AecmError, AecmLaunchPolicy, KERNEL_FAST, KERNEL_SAFE, debug_fft128,  # noqa: F401
+                  default_launch_policy, describe_launch_detail, describe_launch_for, describe_tick, device_info, library_path, load,
+                  register_host_buffer, self_test, set_default_device, unregister_host_buffer)
 
-__all__ = ["check_counters", "Aecm", "AecmBatch", "AecmSessions", "AecmConfig", "AecmError", "KERNEL_FAST", "KERNEL_SAFE", "debug_fft128", "describe_launch_for", "device_info", "library_path", "load", "register_host_buffer", "self_test", "unregister_host_buffer"]
+__all__ = ["check_counters", "Aecm", "AecmBatch", "AecmSessions", "AecmConfig", "AecmError", "AecmLaunchPolicy", "KERNEL_FAST", "KERNEL_SAFE", "debug_fft128",
+           "default_launch_policy", "describe_launch_detail", "describe_launch_for", "describe_tick", "device_info", "library_path", "load",
+           "register_host_buffer", "self_test", "set_default_device", "unregister_host_buffer"]

@@ -192,6 +192,10 @@ void aecm_process_queue_kernel(StatePtrs st, IoView io, int n_streams, int n_blo
                                       // where the front waves are the longest link: 1 / 2 / 3 there cost 10-13 % (1 024 streams 613 -> 549 / 549 / 531)
 #endif
 constexpr int kPipeStreams = 4;
+// Slot rotations: PipeShape::rot (the kernel's slot_of), chosen per shape in PipelinedShapeFor.  There is none per workgroup of a CU by
+// default (rot bits 6-7): the hardware does that one itself -- traced (tools/pipe_trace.py, cu_mates), the second and third workgroup
+// of a CU each start one SIMD further round the cycle 0, 2, 1, 3 than the one before; a software rotation on top brings the same
+// slots back onto the same SIMDs (1 024 streams as 2 x 2 per CU: 620 -> 493 M frames/s).
 // kFront front waves per workgroup: 2 (two streams each; the form for launches that fill the chip) or 4 (one stream each: ten-wave
 // workgroups with two tail waves, two to a CU -- launches of up to 2 048 streams, where the chip has wave slots to spare and a
 // front wave with two streams' transforms is the longest link of the chain).
@@ -249,20 +253,24 @@ struct PipeShared {
 #ifndef AECM_PIPE_TAIL_PRIO
 #define AECM_PIPE_TAIL_PRIO 1         // the tail waves' issue priority
 #endif
-// Which launches get delay waves when the caller does not say (workgroups of the launch, CUs of the device): those of at most one
-// workgroup per CU (measured: 1 024 streams 403 -> 492 M frames/s, 256 streams 105 -> 124; 1 536 streams 552 -> 370)
+// Which launches get delay waves when the caller does not say (workgroups of four streams the launch makes, CUs of the device): those the
+// sixteen-wave shape takes (below).
 #ifndef AECM_PIPE_DELAY_DEFAULT
-#define AECM_PIPE_DELAY_DEFAULT(n_wg, cus) ((n_wg) <= (cus) ? kPipeStreams : 0)
+#define AECM_PIPE_DELAY_DEFAULT(n_wg, cus) ((n_wg) <= 2 * (cus) ? kPipeStreams : 0)
 #endif
 // Workgroups of the sixteen-wave shape a CU takes (experiments: two of them are 32 waves, eight per SIMD -- the kernel's 61 VGPRs allow it)
 #ifndef AECM_PIPE_GAIN_WGS_PER_CU
 #define AECM_PIPE_GAIN_WGS_PER_CU (PipeWorkgroupsPerCu<2, 4, 2, 4>())
 #endif
-// Which launches get gain waves when the caller does not say: those that get delay waves (at most one workgroup per CU; measured:
-// 1 024 streams 492 -> 612 M frames/s, 256 streams 124 -> 155, 64 streams 31 -> 39; two such workgroups per CU -- 32 waves -- lose
-// against the ten-wave shape: 2 048 streams 620 vs 740)
+// Which launches get gain waves when the caller does not say: up to two sixteen-wave workgroups per CU (eight streams per CU).
+// Round 5 gave this shape one workgroup per CU only (1 024 streams 492 -> 612 M frames/s with the gain waves, 256 streams 124 -> 155)
+// because two of them measured 620 M at 2 048 streams against the ten-wave shape's 740: with 81 SGPRs the two never shared a CU
+// (PipeWavesPerEu above), and with every one-stream role of a slot on the same SIMD a CU of five streams ran them at 0.43 instead of
+// 0.60 M frames/s each.  Built for eight waves per SIMD and with the roles staggered over the SIMDs (the kernel's slot_of) the shape
+// carries a CU's eight streams as well as the ten-wave shape and everything below better (profiles/r06_experiments.md):
+// 1 280 streams 482 -> 650, 1 536: 571 -> 688, 1 792: 647 -> 702, 2 048: 738 / 734.
 #ifndef AECM_PIPE_GAIN_DEFAULT
-#define AECM_PIPE_GAIN_DEFAULT(n_wg, cus) ((n_wg) <= (cus) ? kPipeStreams : 0)
+#define AECM_PIPE_GAIN_DEFAULT(n_wg, cus) ((n_wg) <= 2 * (cus) ? kPipeStreams : 0)
 #endif
 #ifndef AECM_PIPE_GAIN_PRIO
 #define AECM_PIPE_GAIN_PRIO 3         // the gain waves' issue priority (1 / 2 / 3: 1 024 streams 594 / 607 / 613 M frames/s)
@@ -329,7 +337,7 @@ __device__ __forceinline__ void SetPrioDynamic(int p) {      // s_setprio takes 
 }
 constexpr int kPipeGroupLog2 = AECM_PIPE_BALANCE_GROUP_LOG2, kPipeGroupMask = (1 << kPipeGroupLog2) - 1;
 constexpr int kPipeTraceWaves = 16;       // per-wave records per workgroup in the diagnostics build (the largest workgroup has 14)
-constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of up to 1 024 workgroups (4 096 streams) are balanced, larger ones run as before
+constexpr int kPipeMonitorLoads = 10;     // x 64 lanes x 2 halves: launches of up to 1 280 workgroups are balanced, larger ones run as before
 
 // (With delay waves everything behind the front waves is one step later: the delay waves work on block s - 1, the middle
 // waves on block s - 2 out of slots[(s - 2) % 3], the tail waves on block s - 3; n_blocks + 3 barriers.)
@@ -357,10 +365,38 @@ constexpr int kPipeMonitorLoads = 8;      // x 64 lanes x 2 halves: launches of 
 #ifndef AECM_PIPE_RAW_HANDOVER
 #define AECM_PIPE_RAW_HANDOVER 1
 #endif
+// The occupancy a shape is built for.  Eight waves per SIMD need <= 64 VGPRs AND <= 80 SGPRs (MI355X_MICROARCH.md "Residency": with
+// 82-96 SGPRs the hardware admits seven, whatever the compiler's occupancy line says): the sixteen-wave shape fits both without a
+// spill, and two of its workgroups on a CU are exactly the 32 wave slots.  (Round 5 measured "two sixteen-wave workgroups per CU" as
+// 620 M at 2 048 streams -- with 81 SGPRs they never were on a CU together; they took turns.)
+#ifndef AECM_PIPE16_WAVES_PER_EU
+#define AECM_PIPE16_WAVES_PER_EU 8
+#endif
+#ifndef AECM_PIPE10_WAVES_PER_EU
+#define AECM_PIPE10_WAVES_PER_EU AECM_WAVES_PER_EU
+#endif
+#ifndef AECM_PIPE8_WAVES_PER_EU
+#define AECM_PIPE8_WAVES_PER_EU AECM_WAVES_PER_EU
+#endif
+#ifndef AECM_PIPE6_WAVES_PER_EU
+#define AECM_PIPE6_WAVES_PER_EU AECM_WAVES_PER_EU
+#endif
+constexpr int PipeWavesPerEu(int tail_waves, int front_waves, int delay_waves, int gain_waves) {
+#if defined(AECM_CHECKED)
+    return AECM_WAVES_PER_EU;
+#else
+    return PipeWaves(tail_waves, front_waves, delay_waves, gain_waves) == 7 ? AECM_PIPE_TAIL1_WAVES_PER_EU
+           : gain_waves != 0 ? AECM_PIPE16_WAVES_PER_EU
+           : delay_waves != 0 ? AECM_WAVES_PER_EU
+           : tail_waves == 0 ? AECM_PIPE6_WAVES_PER_EU
+           : front_waves == 4 ? AECM_PIPE10_WAVES_PER_EU : AECM_PIPE8_WAVES_PER_EU;
+#endif
+}
 template <int kTail, bool kBalance, bool kRaw = false, int kFront = 2, int kDelay = 0, int kGain = 0>
 __global__ __launch_bounds__(64 * PipeWaves(kTail, kFront, kDelay, kGain))
-__attribute__((amdgpu_waves_per_eu(PipeWaves(kTail, kFront, kDelay, kGain) == 7 ? AECM_PIPE_TAIL1_WAVES_PER_EU : AECM_WAVES_PER_EU, AECM_MAX_WAVES_PER_EU)))
-void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n_blocks, uint32_t *progress, int n_workgroups) {
+__attribute__((amdgpu_waves_per_eu(PipeWavesPerEu(kTail, kFront, kDelay, kGain), AECM_MAX_WAVES_PER_EU)))
+void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int streams_base, int streams_rem, int n_blocks, uint32_t *progress, int n_workgroups,
+                                    int wgs_per_round, int rot) {
     constexpr int kMode = kBalance ? AECM_PIPE_BALANCE : 0;               // AECM_PIPE_BALANCE's meaning, per instantiation
     constexpr int kFrontBehind = kBalance ? AECM_PIPE_FRONT_PRIO_BEHIND : AECM_PIPE_FRONT_PRIO;
     // the second-stream boost is for the launches without balance: on top of it, it costs (4 096 streams: 862 M frames/s without, 844 with)
@@ -384,13 +420,35 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
     using E = BlockEngine<W, false>;
     using EF = BlockEngine<Gfx950Wave<true, false>, false>;               // the front and tail waves keep one priority (no per-phase s_setprio)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t first = (int64_t)blockIdx.x * kPipeStreams;
+    // This workgroup's streams (PipeSplit, below): streams_base of them, one more in the first streams_rem workgroups -- the
+    // dispatcher deals workgroups out to the CUs in turn, so the CUs' loads differ by at most one stream.  A workgroup with fewer
+    // than kPipeStreams streams keeps them in the slots that spread them over the waves that serve two slots each (front, tail,
+    // delay waves): 1 -> slot 0; 2 -> slots 0, 2; 3 -> slots 0, 1, 2.  The waves of an empty slot only keep the barriers.
+    const int wg = (int)blockIdx.x;
+    const int64_t first = (int64_t)wg * streams_base + (wg < streams_rem ? wg : streams_rem);
+    const int live_mask = (0xf7510 >> (4 * (streams_base + (wg < streams_rem ? 1 : 0)))) & 0xf;
+    const auto slot_live = [&](int k) -> bool { return ((live_mask >> k) & 1) != 0; };
+    const auto slot_stream = [&](int k) -> int64_t { return first + __builtin_popcount((unsigned)(live_mask & ((1 << k) - 1))); };
+    // Which wave serves which slot.  The hardware deals a workgroup's waves out to the CU's four SIMDs in turn, so with the natural
+    // numbering (wave = role's first wave + slot) every one-stream-per-wave role of a slot would sit on the same SIMD: a workgroup
+    // with an empty slot leaves one SIMD idle and two workgroups with the same live slots crowd the same SIMDs -- a SIMD's vector
+    // port carries the instruction stream of one stream's waves at 0.9 M frames/s and no more (measured: one five-stream CU among
+    // four-stream CUs ran its streams at 0.43 instead of 0.60 M frames/s and held the whole launch up).  So the roles are
+    // staggered (the front wave of slot k sits one SIMD further than its back wave, the gain wave two) and the workgroups that
+    // share a CU -- workgroup i and i + wgs_per_round, ... -- each start one SIMD further.  Any bijection is correct.
+    const int wg_rot = wgs_per_round > 0 ? (wg / wgs_per_round) * ((rot >> 6) & 3) : 0;
+    const int rot_front = rot & 3, rot_gain = (rot >> 2) & 3, rot_delay = (rot >> 4) & 3, rot_tail = (rot >> 8) & 3;
+    int k0 = 0;                                                                              // the first slot of a wave that serves several
+    const auto ks = [&](int k) -> int { return (k0 + k) & (kPipeStreams - 1); };
+    const auto slot_of = [&](int j, int role_rot) -> int { return (j + role_rot + wg_rot) & (kPipeStreams - 1); };
+    static_assert((kPipeStreams & (kPipeStreams - 1)) == 0, "slot rotation");
     if (wave < kPipeStreams) {
         // ---- back (middle) wave: one stream, everything of a block after the forward transforms (and before the inverse one, with tail waves) ----
         typename E::Regs r;
         E::init_lane_constants(r, st.consts);
-        const int64_t stream = first + wave;
-        const bool live = stream < n_streams;
+        const int slot = slot_of(wave, 0);
+        const int64_t stream = slot_stream(slot);
+        const bool live = slot_live(slot);
         uint32_t *vec = st.vec + stream * (int64_t)kVecWordsPerStream;
         int32_t *scal = st.scal + stream * (int64_t)kNumScal;
         uint16_t *hist = st.hist + stream * (int64_t)kHistWordsPerStream;
@@ -410,14 +468,14 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 typename E::Spectrum xf, df;
                 r.table_index = W::table_index_for_this_block();
                 if constexpr (kRaw) {
-                    const PipeRawSlot &slot = sh.slots[slot_idx][wave];
-                    const int fa0 = slot.fa[0][lane], fb0 = slot.fb[0][lane], fa1 = slot.fa[1][lane], fb1 = slot.fb[1][lane];
-                    const int q0 = __builtin_amdgcn_readfirstlane(slot.q[0]), q1 = __builtin_amdgcn_readfirstlane(slot.q[1]);
+                    const PipeRawSlot &slot_in = sh.slots[slot_idx][slot];
+                    const int fa0 = slot_in.fa[0][lane], fb0 = slot_in.fb[0][lane], fa1 = slot_in.fa[1][lane], fb1 = slot_in.fb[1][lane];
+                    const int q0 = __builtin_amdgcn_readfirstlane(slot_in.q[0]), q1 = __builtin_amdgcn_readfirstlane(slot_in.q[1]);
                     E::spectrum(r, fa0, fb0, q0, xf);
                     E::spectrum(r, fa1, fb1, q1, df);
                 } else {
-                    const PipeSlot &slot = sh.slots[slot_idx][wave];
-                    const int x = slot.near_x[lane], m = slot.mags[lane], sc = slot.scalars[lane];
+                    const PipeSlot &slot_in = sh.slots[slot_idx][slot];
+                    const int x = slot_in.near_x[lane], m = slot_in.mags[lane], sc = slot_in.scalars[lane];
                     xf.mag = zext16(m);
                     xf.mag64 = __builtin_amdgcn_readlane(sc, 0);
                     xf.q = __builtin_amdgcn_readlane(sc, 1);
@@ -433,20 +491,20 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 E::update_startup(r.u);
                 int delay_given = 0, far_given = 0;
                 if constexpr (kDelay != 0) {
-                    delay_given = __builtin_amdgcn_readfirstlane(sh.delays[blk & 1][wave]);
-                    far_given = sh.far_rows[blk & 1][wave][lane];
+                    delay_given = __builtin_amdgcn_readfirstlane(sh.delays[blk & 1][slot]);
+                    far_given = sh.far_rows[blk & 1][slot][lane];
                 }
                 if constexpr (kTail != 0) {
                     if constexpr (kGain != 0) {
                         W::template phase_priority<3>(r.u.prio_drop);
                         E::track_q(r.u, df, df);
                         const typename E::GainInput g = E::template channel_block<true>(r, hist, xf, df, delay_given, far_given);
-                        PipeGainSlot &gs = sh.gains[blk & 1][wave];
+                        PipeGainSlot &gs = sh.gains[blk & 1][slot];
                         gs.echo_est[lane] = g.echo_est;
                         if (lane == 0) { gs.echo_est64 = g.echo_est64; gs.far_q = g.far_q; gs.cur_vad = g.cur_vad; gs.near0 = g.near0; gs.stored0 = g.stored0; }
                     } else {
                         const typename E::TailInput t = E::template middle_block<kDelay != 0>(r, hist, xf, df, df, delay_given, far_given);
-                        PipeTailSlot &ts = sh.tails[blk & 1][wave];
+                        PipeTailSlot &ts = sh.tails[blk & 1][slot];
                         ts.a[lane] = t.a;
                         ts.b[lane] = t.b;
                         if (lane == 0) ts.clean_q = t.clean_q;
@@ -466,7 +524,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             AECM_PIPE_BARRIER();                                          // the gain wave's part of the state is in gain_state
             if (live) {
                 const int lane = W::lane_id();
-                const PipeGainState &g = sh.gain_state[wave];
+                const PipeGainState &g = sh.gain_state[slot];
                 const int nf = g.near_filt_ctrs[lane];
                 r.b.echo_filt = g.echo_filt[lane];
                 r.b.near_filt = sext16(nf); r.b.low_ctr = lsr(nf, 16) & 7; r.b.high_ctr = lsr(nf, 19) & 7;
@@ -484,12 +542,12 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
         EF::init_lane_constants(r, st.consts);
         int level = kFrontBehind;                                         // this group's base priority (constant without balance)
         SetPrioDynamic(level);
-        const int k0 = (wave - kPipeStreams) * kPipeStreamsPerFront;
+        k0 = slot_of((wave - kPipeStreams) * kPipeStreamsPerFront, rot_front);        // (a wave of two slots: k0 and the one after it, round the ring)
         int x_old[kPipeStreamsPerFront], d_old[kPipeStreamsPerFront], far_next[kPipeStreamsPerFront], near_next[kPipeStreamsPerFront];
         bool live[kPipeStreamsPerFront];
         for (int k = 0; k < kPipeStreamsPerFront; ++k) {
-            const int64_t stream = first + k0 + k;
-            live[k] = stream < n_streams;
+            const int64_t stream = slot_stream(ks(k));
+            live[k] = slot_live(ks(k));
             x_old[k] = d_old[k] = far_next[k] = near_next[k] = 0;
             if (live[k]) {
                 EF::load_time_state(st.vec + stream * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
@@ -539,7 +597,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                     if (kBoost != 0) SetPrioDynamic(level + (k == 0 ? 0 : kBoost));      // folds to immediates without balance
                     const int far_cur = far_next[k], near_cur = near_next[k];
                     if (blk + 1 < n_blocks) {
-                        typename EF::StridedIo sio{io, (first + k0 + k) * io.stream_stride};
+                        typename EF::StridedIo sio{io, slot_stream(ks(k)) * io.stream_stride};
                         far_next[k] = sio.far(r, blk + 1);
                         near_next[k] = sio.near(r, blk + 1);
                     }
@@ -548,14 +606,14 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                     if constexpr (kRaw) {
                         int fa[2], fb[2], q[2];
                         EF::front_transforms(r, x_old[k], far_cur, d_old[k], near_cur, fa, fb, q);
-                        PipeRawSlot &slot = sh.slots[slot_idx][k0 + k];
+                        PipeRawSlot &slot = sh.slots[slot_idx][ks(k)];
                         slot.fa[0][lane] = fa[0]; slot.fb[0][lane] = fb[0];
                         slot.fa[1][lane] = fa[1]; slot.fb[1][lane] = fb[1];
                         if (lane == 0) { slot.q[0] = q[0]; slot.q[1] = q[1]; }
                     } else {
                         typename EF::Spectrum xf, df, cf;
                         EF::front_block(r, x_old[k], far_cur, d_old[k], near_cur, 0, 0, xf, df, cf);
-                        PipeSlot &slot = sh.slots[slot_idx][k0 + k];
+                        PipeSlot &slot = sh.slots[slot_idx][ks(k)];
                         slot.near_x[lane] = (df.re & 0xffff) | (int)((unsigned)df.im << 16);
                         slot.mags[lane] = xf.mag | (int)((unsigned)df.mag << 16);
                         int sc = 0;
@@ -605,7 +663,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
         if (kTail != 0) AECM_PIPE_BARRIER();                              // the tail waves' last step
         if (kGain != 0) AECM_PIPE_BARRIER();                              // (state hand-over of the gain waves)
         for (int k = 0; k < kPipeStreamsPerFront; ++k)
-            if (live[k]) EF::store_time_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
+            if (live[k]) EF::store_time_state(st.vec + slot_stream(ks(k)) * (int64_t)kVecWordsPerStream, r.lane, x_old[k], d_old[k]);
     } else if (wave < kPipeStreams + kPipeFrontWaves + kTail) {
         // ---- tail wave: kPipeStreams / kTail streams, inverse transform + synthesis + output of the block BEFORE the one the middle waves are at ----
         constexpr int kPer = kTail ? kPipeStreams / kTail : 1;
@@ -613,12 +671,12 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
         EF::init_lane_constants(r, st.consts);
         r.u.prio_drop = 0;
         __builtin_amdgcn_s_setprio(AECM_PIPE_TAIL_PRIO);
-        const int k0 = (wave - kPipeStreams - kPipeFrontWaves) * kPer;
+        k0 = slot_of((wave - kPipeStreams - kPipeFrontWaves) * kPer, rot_tail);
         int ovl[kPer], c_old[kPer];
         bool live[kPer];
         for (int k = 0; k < kPer; ++k) {
-            const int64_t stream = first + k0 + k;
-            live[k] = stream < n_streams;
+            const int64_t stream = slot_stream(ks(k));
+            live[k] = slot_live(ks(k));
             ovl[k] = c_old[k] = 0;
             if (live[k]) EF::load_tail_state(st.vec + stream * (int64_t)kVecWordsPerStream, r.lane, ovl[k], c_old[k]);
         }
@@ -630,7 +688,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 #pragma unroll
             for (int k = 0; k < kPer; ++k) {
                 if (!live[k]) continue;
-                const PipeTailSlot &ts = sh.tails[blk & 1][k0 + k];
+                const PipeTailSlot &ts = sh.tails[blk & 1][ks(k)];
                 const int lane = W::lane_id();
                 const int a = ts.a[lane], b = ts.b[lane];
                 const int clean_q = __builtin_amdgcn_readfirstlane(ts.clean_q);
@@ -638,14 +696,14 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 r.out_ovl = ovl[k];
                 const int out = EF::tail_block(r, a, b, clean_q);
                 ovl[k] = r.out_ovl;
-                typename EF::StridedIo sio{io, (first + k0 + k) * io.stream_stride};
+                typename EF::StridedIo sio{io, slot_stream(ks(k)) * io.stream_stride};
                 sio.out(r, blk, out);
             }
             AECM_PIPE_BARRIER();
         }
         if (kGain != 0) AECM_PIPE_BARRIER();                              // (state hand-over of the gain waves)
         for (int k = 0; k < kPer; ++k)
-            if (live[k]) EF::store_tail_state(st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, r.lane, ovl[k], c_old[k]);
+            if (live[k]) EF::store_tail_state(st.vec + slot_stream(ks(k)) * (int64_t)kVecWordsPerStream, r.lane, ovl[k], c_old[k]);
     } else if constexpr (kDelay != 0) {
         if (wave < kPipeStreams + kPipeFrontWaves + kTail + kDelay) {
             // ---- delay wave: kPipeStreams / kDelay streams, the delay estimator of the block AFTER the one their channel waves are at ----
@@ -654,7 +712,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             EF::init_lane_constants(r, st.consts);
             r.u.prio_drop = 0;
             __builtin_amdgcn_s_setprio(AECM_PIPE_DELAY_PRIO);
-            const int k0 = (wave - (kPipeStreams + kPipeFrontWaves + kTail)) * kPer;
+            k0 = slot_of((wave - (kPipeStreams + kPipeFrontWaves + kTail)) * kPer, rot_delay);
             // the estimator's state per stream (BlockEngine::load_delay_state's fields), moved into r around each call
             int mean[kPer], bh0[kPer], bh1[kPer], m01[kPer], far_init[kPer], near_init[kPer], min_prob[kPer], last_prob[kPer], last_delay[kPer];
             int hist_pos[kPer], fixed_delay[kPer];                        // the channel wave's u.hist_pos, followed here
@@ -671,8 +729,8 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             };
 #pragma unroll
             for (int k = 0; k < kPer; ++k) {
-                const int64_t stream = first + k0 + k;
-                live[k] = stream < n_streams;
+                const int64_t stream = slot_stream(ks(k));
+                live[k] = slot_live(ks(k));
                 hist_pos[k] = 0; fixed_delay[k] = -1;
                 r.mean = r.bh0 = r.bh1 = r.m01 = 0;
                 r.u.far_init = r.u.near_init = r.u.min_prob = r.u.last_prob = r.u.last_delay = 0;
@@ -694,7 +752,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                 for (int k = 0; k < kPer; ++k) {
                     fetch[k] = false;
                     if (!live[k]) continue;
-                    const PipeSlot &slot = sh.slots[slot_idx][k0 + k];
+                    const PipeSlot &slot = sh.slots[slot_idx][ks(k)];
                     const int m = slot.mags[lane], sc = slot.scalars[lane];
                     typename EF::Spectrum xf, df;
                     xf.mag = zext16(m);
@@ -705,7 +763,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                     swap_in(k);
                     const int estimate = EF::delay_block(r, xf, df);
                     swap_out(k);
-                    if (lane == 0) sh.delays[blk & 1][k0 + k] = estimate;
+                    if (lane == 0) sh.delays[blk & 1][ks(k)] = estimate;
                     // AlignedFarend for the channel wave: the history row it would fetch next step.  The row of the block before this
                     // one is being written in this very step -- but that block's spectrum is still in its slot; older rows are in
                     // memory (written at least one barrier ago, or by an earlier launch); a delay of 0 is the block's own spectrum,
@@ -714,14 +772,14 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
                     const int delay = EF::effective_delay(r.u, estimate);
                     fetch[k] = delay != 0;
                     if (delay != 0) {
-                        const uint16_t *hist = st.hist + (first + k0 + k) * (int64_t)kHistWordsPerStream;
-                        if (delay == 1 && blk > 0) far[k] = zext16(sh.slots[slot_before][k0 + k].mags[lane]);
+                        const uint16_t *hist = st.hist + slot_stream(ks(k)) * (int64_t)kHistWordsPerStream;
+                        if (delay == 1 && blk > 0) far[k] = zext16(sh.slots[slot_before][ks(k)].mags[lane]);
                         else far[k] = Gfx950Wave<true, false>::load_u16(hist + EF::aligned_slot(hist_pos[k], delay) * kLanes, lane);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < kPer; ++k)                            // (the stores after every stream's fetch is under way)
-                    if (fetch[k]) sh.far_rows[blk & 1][k0 + k][lane] = far[k];
+                    if (fetch[k]) sh.far_rows[blk & 1][ks(k)][lane] = far[k];
                 slot_before = slot_idx;
                 slot_idx = slot_idx + 1 == kSlots ? 0 : slot_idx + 1;
                 AECM_PIPE_BARRIER();
@@ -734,7 +792,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             for (int k = 0; k < kPer; ++k) {
                 if (!live[k]) continue;
                 swap_in(k);
-                EF::store_delay_state(r, st.vec + (first + k0 + k) * (int64_t)kVecWordsPerStream, st.scal + (first + k0 + k) * (int64_t)kNumScal);
+                EF::store_delay_state(r, st.vec + slot_stream(ks(k)) * (int64_t)kVecWordsPerStream, st.scal + slot_stream(ks(k)) * (int64_t)kNumScal);
             }
         } else if constexpr (kGain != 0) {
             // ---- gain wave: one stream, gain_block of the block BEFORE the one its channel wave is at ----
@@ -742,9 +800,9 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
             EF::init_lane_constants(r, st.consts);
             r.u.prio_drop = 0;
             __builtin_amdgcn_s_setprio(AECM_PIPE_GAIN_PRIO);
-            const int k = wave - (kPipeStreams + kPipeFrontWaves + kTail + kDelay);
-            const int64_t stream = first + k;
-            const bool live = stream < n_streams;
+            const int k = slot_of(wave - (kPipeStreams + kPipeFrontWaves + kTail + kDelay), rot_gain);
+            const int64_t stream = slot_stream(k);
+            const bool live = slot_live(k);
             if (live) EF::load_state(r, st.vec + stream * (int64_t)kVecWordsPerStream, st.scal + stream * (int64_t)kNumScal);
             AECM_PIPE_BARRIER();                                          // steps 0, 1, 2: nothing to do yet
             AECM_PIPE_BARRIER();
@@ -812,13 +870,14 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int n_streams, int n
 // Streams a pipelined launch keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
 template <int kTail, int kFront = 2, int kDelay = 0, int kGain = 0>
 constexpr int PipeWorkgroupsPerCu() {
-    constexpr int by_waves = 4 * AECM_WAVES_PER_EU / PipeWaves(kTail, kFront, kDelay, kGain);
+    constexpr int by_waves = 4 * PipeWavesPerEu(kTail, kFront, kDelay, kGain) / PipeWaves(kTail, kFront, kDelay, kGain);
     constexpr int by_lds = (int)((160 * 1024) / (sizeof(LdsTables) + (kDelay ? sizeof(PipeShared<kTail, false, kDelay, kGain>) : sizeof(PipeShared<kTail, true>))));
     return by_waves < by_lds ? by_waves : by_lds;
 }
 // Streams a pipelined launch of this shape keeps resident at once: workgroups per CU by wave slots (4 SIMDs x 7) and by LDS (160 KB).
-int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves, int delay_waves, int gain_waves) {
-    const int per_cu = tail_waves == 0 ? PipeWorkgroupsPerCu<0>()
+int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves, int delay_waves, int gain_waves, int wgs_per_cu) {
+    const int per_cu = wgs_per_cu > 0 ? wgs_per_cu
+                       : tail_waves == 0 ? PipeWorkgroupsPerCu<0>()
                        : gain_waves != 0 ? AECM_PIPE_GAIN_WGS_PER_CU
                        : delay_waves != 0 ? (front_waves == 4 ? PipeWorkgroupsPerCu<2, 4, 4>() : PipeWorkgroupsPerCu<2, 2, 4>())
                        : front_waves == 4 ? PipeWorkgroupsPerCu<2, 4>() : PipeWorkgroupsPerCu<2>();
@@ -831,14 +890,16 @@ int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves, int
 //   up to three per CU            (3 072)                     two tail waves, raw hand-over                    735 -> 795
 //   more (four per CU: 4 096)                                 balance + raw hand-over (launches of >= 128 blocks)  816 -> 863
 // tail_waves / front_waves / raw < 0: by this table; otherwise the caller's wish where the shape exists and fits (experiments).
-PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves, int front_waves, int raw, int delay_waves, int gain_waves) {
+PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, const PipeWishes &wishes) {
+    const int tail_waves = wishes.tail_waves, front_waves = wishes.front_waves, raw = wishes.raw, delay_waves = wishes.delay_waves, gain_waves = wishes.gain_waves;
+    const int spread = wishes.spread, wgs = wishes.wgs_per_cu;
     const int cus = compute_units > 0 ? compute_units : 256;
     const int n_wg = (n_streams + kPipeStreams - 1) / kPipeStreams;
-    PipeShape sh{0, 2, false, false, 0, 0};
+    PipeShape sh{0, 2, false, false, 0, 0, cus, 0, n_wg};
     const int want_tail = tail_waves < 0 ? 2 : tail_waves;
-    if (want_tail >= 2 && n_streams <= PipelinedStreamLimit(cus, 2, 2)) sh.tail_waves = 2;
+    if (want_tail >= 2 && n_streams <= PipelinedStreamLimit(cus, 2, 2, 0, 0, wgs)) sh.tail_waves = 2;
     const int want_front = front_waves < 0 ? (n_wg > cus ? 4 : 2) : front_waves;
-    if (want_front >= 4 && sh.tail_waves == 2 && n_streams <= PipelinedStreamLimit(cus, 2, 4)) sh.front_waves = 4;
+    if (want_front >= 4 && sh.tail_waves == 2 && n_streams <= PipelinedStreamLimit(cus, 2, 4, 0, 0, wgs)) sh.front_waves = 4;
     sh.balance = sh.tail_waves == 0 && AECM_PIPE_BALANCE != 0 && n_blocks >= (8 << kPipeGroupLog2) && n_wg <= 128 * kPipeMonitorLoads && n_wg > 3 * cus;
     const bool want_raw = (raw < 0 ? (AECM_PIPE_RAW_HANDOVER != 0 && (sh.balance || (sh.tail_waves == 2 && n_wg > cus))) : raw != 0);
     // the raw form exists for: the balanced shape, and the two-tail shapes
@@ -849,35 +910,63 @@ PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int 
     // (Delay waves where the CU is short of issue slots rather than of independent work -- two delay waves next to four front waves
     // at two workgroups per CU, one for the workgroup's four streams at three and four per CU -- measured slower than the shapes
     // above: 2 048 streams 712 vs 740 M frames/s, 3 072 555 vs 796, 4 096 796 vs 859.  Not instantiated.)
-    if (want_delay != 0 && sh.tail_waves == 2 && (raw < 0 || raw == 0) && n_streams <= PipelinedStreamLimit(cus, 2, 2, kPipeStreams)) {
+    if (want_delay != 0 && sh.tail_waves == 2 && (raw < 0 || raw == 0) && n_streams <= PipelinedStreamLimit(cus, 2, 2, kPipeStreams, 0, wgs)) {
         sh.front_waves = 2;
         sh.delay_waves = kPipeStreams;
         sh.raw = false;
         // gain waves: the sixteen-wave shape (four front waves, two delay waves)
         const int want_gain = gain_waves < 0 ? AECM_PIPE_GAIN_DEFAULT(n_wg, cus) : gain_waves;
-        if (want_gain != 0 && (front_waves < 0 || front_waves == 4) && n_streams <= PipelinedStreamLimit(cus, 2, 4, 2, kPipeStreams)) {
+        if (want_gain != 0 && (front_waves < 0 || front_waves == 4) && n_streams <= PipelinedStreamLimit(cus, 2, 4, 2, kPipeStreams, wgs)) {
             sh.gain_waves = kPipeStreams;
             sh.front_waves = 4;
             sh.delay_waves = 2;
         }
     }
+    // Even load (round 6).  The shape holds per_cu workgroups on a CU; with fewer workgroups of four streams than that on some CUs
+    // the launch ends when the fullest CU does (1 536 streams = 384 workgroups: half the CUs carried two, the launch ran slower than
+    // 1 024 streams).  Every CU gets its full count of workgroups instead, of three or four (two, one) streams each: the
+    // dispatcher deals workgroups out to the CUs in turn, the first n_streams % workgroups of them serve one stream more
+    // (the kernel's first lines), so the CUs' loads differ by at most one stream.
+    if (spread != 0) {
+        const int per_cu = PipelinedStreamLimit(cus, sh.tail_waves, sh.front_waves, sh.delay_waves, sh.gain_waves, wgs) / (cus * kPipeStreams);
+        int full = per_cu * cus < n_streams ? per_cu * cus : n_streams;
+        if (sh.balance && full > 128 * kPipeMonitorLoads) full = 128 * kPipeMonitorLoads;      // (what the monitor wave reads; n_wg fits: see balance above)
+        if (full > sh.workgroups) sh.workgroups = full;
+    }
+    // The slot rotations (the kernel's slot_of; measured over all sixteen front x gain and front x tail combinations, M frames/s):
+    //   sixteen waves, workgroups of one stream (two of them)   front + 1, gain + 2:  256 streams 186 -> 227, 512: 365 -> 441, 768: 507 -> 550
+    //   sixteen waves, workgroups of two to four streams        front + 3, gain + 1:  1 024: 626 -> 673, 1 280: 537 -> 650, 1 536: 574 -> 688, 1 792: 641 -> 702
+    //   eight waves (front and tail waves of two slots each)    front + 3, tail + 2:  2 304: 634 -> 679, 2 560: 706 -> 709, 2 816: 734 -> 753
+    //   ten and six waves                                       none (nothing moved by more than the run-to-run spread)
+    if (sh.gain_waves != 0) sh.rot = n_streams < 2 * sh.workgroups ? (1 | (2 << 2)) : (3 | (1 << 2));
+    else if (sh.tail_waves == 2 && sh.front_waves == 2 && sh.delay_waves == 0) sh.rot = 3 | (2 << 8);
+    else sh.rot = 0;
+    if (wishes.rot >= 0) sh.rot = wishes.rot;
     return sh;
+}
+
+int PipelinedWorkgroupWaves(const PipeShape &shape) { return PipeWaves(shape.tail_waves, shape.front_waves, shape.delay_waves, shape.gain_waves); }
+int PipelinedWorkgroupsPerCu(const PipeShape &shape) {
+    return PipelinedStreamLimit(1, shape.tail_waves, shape.front_waves, shape.delay_waves, shape.gain_waves) / kPipeStreams;
 }
 
 hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, const PipeShape &shape, uint32_t *progress,
                                         hipStream_t stream) {
     if (n_streams <= 0 || n_blocks <= 0) return hipSuccess;
-    const dim3 grid((n_streams + kPipeStreams - 1) / kPipeStreams), block(64 * PipeWaves(shape.tail_waves, shape.front_waves, shape.delay_waves, shape.gain_waves));
+    const int n_wg = shape.workgroups;
+    if (n_wg <= 0 || (int64_t)n_wg * kPipeStreams < n_streams || n_wg > n_streams) return hipErrorInvalidValue;
+    const dim3 grid(n_wg), block(64 * PipeWaves(shape.tail_waves, shape.front_waves, shape.delay_waves, shape.gain_waves));
+    const int streams_base = n_streams / n_wg, streams_rem = n_streams % n_wg;
     if (shape.balance) {
-        if (!progress) return hipErrorInvalidValue;
-        const hipError_t e = hipMemsetAsync(progress, 0, PipelinedControlBytes(n_streams), stream);
+        if (!progress || n_wg > 128 * kPipeMonitorLoads) return hipErrorInvalidValue;
+        const hipError_t e = hipMemsetAsync(progress, 0, PipelinedControlBytes(n_wg), stream);
         if (e != hipSuccess) return e;
     }
 #if !defined(AECM_PIPE_TRACE)
     if (!shape.balance) progress = nullptr;
 #endif
 #define AECM_LAUNCH_PIPE(T, B, R, F, D, G) hipLaunchKernelGGL((aecm_process_pipelined_kernel<T, B, R, F, D, G>), grid, block, sizeof(LdsTables) + sizeof(PipeShared<T, R, D, G>), \
-                                                              stream, st, io, n_streams, n_blocks, progress, (int)grid.x)
+                                                              stream, st, io, streams_base, streams_rem, n_blocks, progress, (int)grid.x, shape.wgs_per_round, shape.rot)
     // The instantiations the library carries (PipelinedShapeFor only ever asks for these).  One tail wave for four streams (kTail = 1,
     // seven-wave workgroups) measured slower than its neighbours at every size and is not built.
     const int key = shape.gain_waves * 10000 + shape.delay_waves * 1000 + shape.tail_waves * 100 + shape.front_waves * 10 + (shape.raw ? 1 : 0);
@@ -894,16 +983,16 @@ hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, i
 }
 
 // The progress words of a pipelined launch: 16 bits per workgroup (cleared by the launch).
-size_t PipelinedControlBytes(int n_streams) {
-    const size_t n_wg = (size_t)(n_streams + kPipeStreams - 1) / kPipeStreams;
+size_t PipelinedControlBytes(int n_workgroups) {
+    const size_t n_wg = (size_t)n_workgroups;
 #if defined(AECM_PIPE_TRACE)
     return 4 * ((n_wg + 3) / 4) * sizeof(uint32_t) + n_wg * kPipeTraceWaves * 4 * sizeof(uint64_t);      // progress halves (padded), then the trace records
 #else
     return (n_wg + 2) / 2 * sizeof(uint32_t);
 #endif
 }
-size_t PipelinedTraceOffsetBytes(int n_streams) {
-    const size_t n_wg = (size_t)(n_streams + kPipeStreams - 1) / kPipeStreams;
+size_t PipelinedTraceOffsetBytes(int n_workgroups) {
+    const size_t n_wg = (size_t)n_workgroups;
     return 4 * ((n_wg + 3) / 4) * sizeof(uint32_t);
 }
 

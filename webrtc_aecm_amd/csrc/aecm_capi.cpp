@@ -303,7 +303,93 @@ int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, i
 int32_t WebRtcAecmBatch_DescribeLaunchFor(int32_t num_streams, int32_t compute_units, int32_t num_blocks, int32_t has_clean_input,
                                           int32_t *chunk_blocks) {
     if (num_streams <= 0 || compute_units <= 0 || num_blocks <= 0) return -1;
-    return aecm::BatchEngine::DescribeLaunchFor(num_streams, compute_units, num_blocks, has_clean_input != 0, chunk_blocks);
+    const aecm::LaunchDescription d = aecm::DescribeLaunchWith(aecm::DefaultLaunchPolicy(compute_units), aecm::kVariantFast, num_streams, num_blocks,
+                                                               has_clean_input != 0);
+    if (chunk_blocks) *chunk_blocks = d.form == 2 ? d.chunk_blocks : d.form == 3 ? d.shape : 0;
+    return d.form;
+}
+
+// ---- the launch policy as one value (aecm_engine.h: LaunchPolicy) --------------------------------------
+static void PolicyToAbi(const aecm::LaunchPolicy &p, AecmLaunchPolicy *o) {
+    *o = AecmLaunchPolicy{(int32_t)sizeof(AecmLaunchPolicy), p.compute_units, p.queue_chunk_blocks, p.queue_chunk_explicit ? 1 : 0, p.queue_min_streams,
+                          p.pipelined_min_streams, p.pipelined_min_blocks, p.pipelined_max_streams, p.resident_waves, p.rotation_stream_limit,
+                          p.pipe.tail_waves, p.pipe.front_waves, p.pipe.raw, p.pipe.delay_waves, p.pipe.gain_waves, p.pipe.spread, p.pipe.wgs_per_cu, p.pipe.rot};
+}
+static aecm::LaunchPolicy PolicyFromAbi(const AecmLaunchPolicy &a) {
+    aecm::LaunchPolicy p;
+    p.compute_units = a.compute_units;
+    p.queue_chunk_blocks = a.queue_chunk_blocks;
+    p.queue_chunk_explicit = a.queue_chunk_explicit != 0;
+    p.queue_min_streams = a.queue_min_streams;
+    p.pipelined_min_streams = a.pipelined_min_streams > 0 ? a.pipelined_min_streams : 0x7fffffff;
+    p.pipelined_min_blocks = a.pipelined_min_blocks;
+    p.pipelined_max_streams = a.pipelined_max_streams;
+    p.resident_waves = a.resident_waves;
+    p.rotation_stream_limit = a.rotation_stream_limit;
+    p.pipe.tail_waves = a.pipe_tail_waves;
+    p.pipe.front_waves = a.pipe_front_waves;
+    p.pipe.raw = a.pipe_raw;
+    p.pipe.delay_waves = a.pipe_delay_waves;
+    p.pipe.gain_waves = a.pipe_gain_waves;
+    p.pipe.spread = a.pipe_spread;
+    p.pipe.wgs_per_cu = a.pipe_wgs_per_cu;
+    p.pipe.rot = a.pipe_rot;
+    return p;
+}
+
+int32_t WebRtcAecmBatch_DefaultLaunchPolicy(int32_t compute_units, AecmLaunchPolicy *policy) {
+    if (!policy) return AECM_NULL_POINTER_ERROR;
+    if (compute_units <= 0) return AECM_BAD_PARAMETER_ERROR;
+    PolicyToAbi(aecm::DefaultLaunchPolicy(compute_units), policy);
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_GetLaunchPolicy(const AecmBatch *b, AecmLaunchPolicy *policy) {
+    if (!b) return -1;
+    if (!policy) return AECM_NULL_POINTER_ERROR;
+    PolicyToAbi(b->engine->launch_policy(), policy);
+    return 0;
+}
+
+int32_t WebRtcAecmBatch_SetLaunchPolicy(AecmBatch *b, const AecmLaunchPolicy *policy) {
+    if (!b) return -1;
+    if (!policy) return AECM_NULL_POINTER_ERROR;
+    if (policy->struct_size != (int32_t)sizeof(AecmLaunchPolicy)) return AECM_BAD_PARAMETER_ERROR;
+    return b->engine->set_launch_policy(PolicyFromAbi(*policy)) ? 0 : AECM_BAD_PARAMETER_ERROR;
+}
+
+static void DescriptionToAbi(const aecm::LaunchDescription &d, AecmLaunchDescription *o) {
+    *o = AecmLaunchDescription{d.form, d.chunk_blocks, d.shape, d.workgroups, d.waves_per_workgroup, d.workgroups_per_cu, d.rounds_x1000};
+}
+
+int32_t WebRtcAecmBatch_DescribeLaunchDetail(const AecmLaunchPolicy *policy, int32_t compute_units, int32_t num_streams, int32_t num_blocks,
+                                             int32_t has_clean_input, AecmLaunchDescription *out) {
+    if (!out) return AECM_NULL_POINTER_ERROR;
+    if (num_streams <= 0 || num_blocks <= 0) return AECM_BAD_PARAMETER_ERROR;
+    aecm::LaunchPolicy p;
+    if (policy) {
+        if (policy->struct_size != (int32_t)sizeof(AecmLaunchPolicy)) return AECM_BAD_PARAMETER_ERROR;
+        p = PolicyFromAbi(*policy);
+        if (!aecm::LaunchPolicyValid(p) || p.compute_units <= 0) return AECM_BAD_PARAMETER_ERROR;
+    } else {
+        if (compute_units <= 0) return AECM_BAD_PARAMETER_ERROR;
+        p = aecm::DefaultLaunchPolicy(compute_units);
+    }
+    DescriptionToAbi(aecm::DescribeLaunchWith(p, aecm::kVariantFast, num_streams, num_blocks, has_clean_input != 0), out);
+    return 0;
+}
+
+int32_t WebRtcAecmSessions_DescribeTick(int32_t num_sessions, int32_t compute_units, AecmLaunchDescription *out) {
+    if (!out) return AECM_NULL_POINTER_ERROR;
+    if (num_sessions <= 0 || compute_units <= 0) return AECM_BAD_PARAMETER_ERROR;
+    DescriptionToAbi(aecm::DescribeTickLaunch(num_sessions, compute_units), out);
+    return 0;
+}
+
+int32_t WebRtcAecm_SetDefaultDevice(int32_t device_id) {
+    if (device_id < 0) return AECM_BAD_PARAMETER_ERROR;
+    Session::SetDefaultDevice(device_id);
+    return 0;
 }
 
 // ---- streaming batch of sessions ---------------------------------------------------------------------

@@ -248,6 +248,8 @@ int RunBatch(const char *list_path, const std::vector<int> &devices) {
         // exchange between devices (the C++ form of the multi-GPU sharding of DESIGN.md section 6).
         const size_t n_dev = devices.size();
         std::vector<int32_t> shard_rc(n_dev, 0);
+        std::vector<double> shard_s(n_dev, 0.0);              // per device: seconds in the library, recordings, WebRtcAecm_ProcessBlock-equivalents
+        std::vector<size_t> shard_n(n_dev, 0);
         std::vector<std::thread> workers;
         for (size_t d = 0; d < n_dev; ++d) {
             const size_t base = ids.size() / n_dev, rem = ids.size() % n_dev;
@@ -259,12 +261,15 @@ int RunBatch(const char *list_path, const std::vector<int> &devices) {
                 AecmConfig cfg;
                 cfg.cngMode = AecmTrue;
                 cfg.echoMode = kEchoMode;
+                const auto s0 = std::chrono::steady_clock::now();
                 int32_t rc = WebRtcAecmBatch_Init(batch, (int32_t)rate);
                 if (rc == 0) rc = WebRtcAecmBatch_set_config(batch, cfg, 0, -1);
                 if (rc == 0)
                     rc = WebRtcAecmBatch_ProcessRecordingsHost(batch, &far_all[first * stride], &near_all[first * stride], /*nearendClean*/ nullptr,
                                                                &out_all[first * stride], (int64_t)stride, frame, (int32_t)max_calls,
                                                                kMsInSndCardBuf);
+                shard_s[d] = std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
+                shard_n[d] = count;
                 WebRtcAecmBatch_Free(batch);
                 shard_rc[d] = rc;
             });
@@ -274,6 +279,11 @@ int RunBatch(const char *list_path, const std::vector<int> &devices) {
             if (shard_rc[d] == -1) { fprintf(stderr, "WebRtcAecmBatch_Create failed on device %d (no usable GPU?)\n", devices[d]); return 1; }
             if (shard_rc[d] != 0) { fprintf(stderr, "batch at %u Hz failed on device %d: %d\n", rate, devices[d], shard_rc[d]); return 1; }
         }
+        // the counters of the shards, gathered where the threads join (no collective needed inside one process)
+        for (size_t d = 0; d < n_dev; ++d)
+            if (shard_n[d] != 0)
+                printf("device %d: %zu recordings at %u Hz, %zu frames of 64 samples each, %.3f s in the library (%.2f M frames/s)\n", devices[d], shard_n[d], rate,
+                       stride / 64, shard_s[d], shard_s[d] > 0 ? (double)shard_n[d] * (double)(stride / 64) / shard_s[d] / 1e6 : 0.0);
         for (size_t k = 0; k < ids.size(); ++k) {
             Job &j = jobs[ids[k]];
             const size_t n = (j.near_w.samples.size() / frame) * frame;      // tail stays untouched (main.cc:111)
@@ -291,7 +301,12 @@ int RunBatch(const char *list_path, const std::vector<int> &devices) {
 
 int main(int argc, char **argv) {
     printf("WebRTC Acoustic Echo Canceller for Mobile -- MI355X engine\n");
-    printf("usage : aecm_run far_file.wav near_file.wav | aecm_run --batch pairs.txt [--devices 0,1,...] | aecm_run --decode in.wav out.wav\n");
+    printf("usage : aecm_run [--device N] far_file.wav near_file.wav | aecm_run --batch pairs.txt [--devices 0,1,...] | aecm_run --decode in.wav out.wav\n");
+    if (argc >= 3 && strcmp(argv[1], "--device") == 0) {     // the HIP device of the single-pair form (WebRtcAecm_Create has no device argument)
+        WebRtcAecm_SetDefaultDevice(atoi(argv[2]));
+        argv += 2;
+        argc -= 2;
+    }
     if (argc < 3) return -1;
     if (strcmp(argv[1], "--decode") == 0) {                  // the reader on its own (no engine, no GPU)
         Wav w;
@@ -300,7 +315,7 @@ int main(int argc, char **argv) {
         return WriteWav(argv[3], w.rate, w.samples) ? 0 : 1;
     }
     if (strcmp(argv[1], "--batch") == 0) {
-        // --devices: HIP device ids to shard the recordings over (one host thread + one batch each); default $AECM_DEVICE or 0
+        // --devices: HIP device ids to shard the recordings over (one host thread + one batch each); default: device 0
         std::vector<int> devices;
         if (argc >= 5 && strcmp(argv[3], "--devices") == 0) {
             for (const char *p = argv[4]; *p;) {
@@ -309,7 +324,7 @@ int main(int argc, char **argv) {
                 if (*p == ',') ++p;
             }
         }
-        if (devices.empty()) devices.push_back(getenv("AECM_DEVICE") ? atoi(getenv("AECM_DEVICE")) : 0);
+        if (devices.empty()) devices.push_back(0);
         return RunBatch(argv[2], devices);
     }
     Wav far_w, near_w;

@@ -16,9 +16,54 @@ namespace aecm {
 
 #define AECM_HIP_OK(expr) ((expr) == hipSuccess)
 
-// Launches of more streams than the chip holds waves are cut into chunks of this many blocks and scheduled from a queue
-// (aecm_block_kernels.hip: aecm_process_queue_kernel).  Measured: profiles/r04_experiments.md section 1.
-constexpr int kDefaultQueueChunk = 128;
+// (kDefaultQueueChunk: launches of more streams than the chip holds waves are cut into chunks of that many blocks and scheduled from
+// a queue -- aecm_block_kernels.hip: aecm_process_queue_kernel; measured: profiles/r04_experiments.md section 1.)
+
+#if defined(AECM_EXPERIMENTS)
+// Experiments build only (tools/ab_build.py adds -DAECM_EXPERIMENTS): the environment's wishes on top of the default policy, so that
+// tools/sweep_streams.py and the A/B scripts can try launch forms without a caller that sets a policy.  The shipped library reads no
+// environment variable anywhere.
+static void ApplyEnvironmentWishes(LaunchPolicy *p) {
+    auto num = [](const char *name, int *dst) { if (const char *env = getenv(name)) *dst = atoi(env); };
+    if (const char *env = getenv("AECM_QUEUE_CHUNK")) p->queue_chunk_blocks = std::min(std::max(0, atoi(env)), BatchEngine::kMaxQueueChunk);
+    num("AECM_QUEUE_MIN_STREAMS", &p->queue_min_streams);
+    num("AECM_PIPE_FRONT", &p->pipe.front_waves);
+    num("AECM_PIPE_TAIL", &p->pipe.tail_waves);
+    num("AECM_PIPE_RAW", &p->pipe.raw);
+    num("AECM_PIPE_DELAY", &p->pipe.delay_waves);
+    num("AECM_PIPE_GAIN", &p->pipe.gain_waves);
+    num("AECM_PIPE_SPREAD", &p->pipe.spread);
+    num("AECM_PIPE_WGS", &p->pipe.wgs_per_cu);
+    num("AECM_PIPE_ROT", &p->pipe.rot);
+    num("AECM_PIPE_MAX_STREAMS", &p->pipelined_max_streams);
+    if (const char *env = getenv("AECM_PIPELINED")) p->pipelined_min_streams = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
+    if (const char *env = getenv("AECM_PIPE_MIN_BLOCKS")) p->pipelined_min_blocks = atoi(env) > 1 ? atoi(env) : 1;
+}
+#endif
+
+// The launch-form limits of a device with `compute_units` CUs: everything follows from the CU count and from what the kernels are
+// built for (waves per SIMD, LDS per workgroup: aecm_block_kernels.hip; tests/test_capi.py checks those against the code object).
+LaunchPolicy DefaultLaunchPolicy(int compute_units) {
+    LaunchPolicy p;
+    p.compute_units = compute_units;
+    p.rotation_stream_limit = RotationStreamLimit(compute_units);
+    p.resident_waves = ResidentWaves(compute_units);
+    p.pipelined_max_streams = PipelinedStreamLimit(compute_units, 0);      // the six-wave shape, four workgroups per CU
+#if defined(AECM_EXPERIMENTS)
+    ApplyEnvironmentWishes(&p);
+#endif
+    return p;
+}
+
+bool LaunchPolicyValid(const LaunchPolicy &p) {
+    const PipeWishes &w = p.pipe;
+    auto in = [](int v, std::initializer_list<int> ok) { return std::find(ok.begin(), ok.end(), v) != ok.end(); };
+    return p.compute_units >= 0 && p.queue_chunk_blocks >= 0 && p.queue_chunk_blocks <= BatchEngine::kMaxQueueChunk && p.pipelined_min_blocks >= 1 &&
+           p.pipelined_max_streams >= 0 && p.pipelined_max_streams <= PipelinedStreamLimit(p.compute_units, 0) && p.resident_waves > 0 &&
+           p.resident_waves <= ResidentWaves(p.compute_units) && p.rotation_stream_limit >= 0 && in(w.tail_waves, {-1, 0, 2}) &&
+           in(w.front_waves, {-1, 2, 4}) && in(w.raw, {-1, 0, 1}) && in(w.delay_waves, {-1, 0, 2, 4}) && in(w.gain_waves, {-1, 0, 4}) &&
+           in(w.spread, {0, 1}) && w.wgs_per_cu >= 0 && w.wgs_per_cu <= 8 && w.rot >= -1 && w.rot < 1024;
+}
 
 BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     if (num_streams <= 0) return nullptr;
@@ -27,11 +72,10 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     if (!AECM_HIP_OK(hipSetDevice(device_id))) return nullptr;
     BatchEngine *e = new BatchEngine();
     e->device_ = device_id;
-    e->owns_device_resources_ = true;
     e->num_streams_ = num_streams;
     int cus = 0;
     if (!AECM_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id))) cus = 0;
-    e->ConfigureLaunchForms(cus);
+    e->policy_ = DefaultLaunchPolicy(cus);
     const size_t S = (size_t)num_streams;
     bool ok = AECM_HIP_OK(hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking)) &&
               AECM_HIP_OK(hipMalloc((void **)&e->st_.vec, S * kVecWordsPerStream * sizeof(uint32_t))) &&
@@ -54,37 +98,13 @@ BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
     return e;
 }
 
-// The launch-form limits of a device with `cus` compute units, and the environment's wishes.
-void BatchEngine::ConfigureLaunchForms(int cus) {
-    BatchEngine *e = this;
-    e->compute_units_ = cus;
-    e->rotation_limit_ = RotationStreamLimit(cus);
-    e->resident_waves_ = ResidentWaves(cus);
-    e->queue_chunk_ = kDefaultQueueChunk;
-    if (const char *env = getenv("AECM_QUEUE_CHUNK")) e->queue_chunk_ = std::min(std::max(0, atoi(env)), kMaxQueueChunk);   // the C API's bound
-    if (const char *env = getenv("AECM_QUEUE_MIN_STREAMS")) e->queue_min_streams_ = atoi(env);      // experiments: the queue form above this many streams
-    e->pipe_max_streams_ = PipelinedStreamLimit(cus, 0);            // = that of one tail wave (seven waves per workgroup fill the SIMDs' 28 slots)
-    // experiments: the shape of pipelined launches (aecm_kernels.h: PipelinedShapeFor); default: by the launch's size
-    if (const char *env = getenv("AECM_PIPE_FRONT")) e->pipe_front_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_TAIL")) e->pipe_tail_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_RAW")) e->pipe_raw_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_DELAY")) e->pipe_delay_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPE_GAIN")) e->pipe_gain_ = atoi(env);
-    if (const char *env = getenv("AECM_PIPELINED")) e->pipe_min_streams_ = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
-    if (const char *env = getenv("AECM_PIPE_MIN_BLOCKS")) e->pipe_min_blocks_ = atoi(env) > 1 ? atoi(env) : 1;
-}
-
-// What an engine of num_streams streams on a device of compute_units CUs would answer DescribeLaunch with (no device needed: the
-// launch-form rules are host logic; the CPU-only tests walk them).
-int BatchEngine::DescribeLaunchFor(int num_streams, int compute_units, int num_blocks, bool has_clean, int *chunk_blocks) {
-    BatchEngine e;                       // (owns no device resources: its destructor touches nothing)
-    e.num_streams_ = num_streams;
-    e.ConfigureLaunchForms(compute_units);
-    return e.DescribeLaunch(num_blocks, has_clean, chunk_blocks);
+bool BatchEngine::set_launch_policy(const LaunchPolicy &p) {
+    if (!LaunchPolicyValid(p) || p.compute_units != policy_.compute_units) return false;
+    policy_ = p;
+    return true;
 }
 
 BatchEngine::~BatchEngine() {
-    if (!owns_device_resources_) return;             // (DescribeLaunchFor's shell)
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int i = 0; i < kTimerSlots; ++i) {
@@ -219,64 +239,102 @@ bool BatchEngine::EnsureLaunchControl(size_t need) {
     return true;
 }
 
+// Which form a launch of `count` streams x num_blocks blocks takes under a policy (host logic, no device): the rules of
+// INTEGRATION.md's table.
+//   chunk queue   every launch of more streams than the pipelined form takes (or than queue_min_streams, when set) that is at least
+//                 two chunks long: above the chip's resident waves because the launch would otherwise end in a long drain, and between
+//                 4 096 streams and that too -- every wave is resident there, but the SIMD's arbiter favours its oldest wave, the waves
+//                 dispatched first pull ahead, and with items claimed in order those waves simply take more of the work (4 608 streams
+//                 728 -> 830 M frames/s, 6 144: 844 -> 930 M; profiles/r04_experiments.md section 4).  Shorter chunks there: a quarter.
+//   pipelined     launches the chip holds at once: fast variant, no clean input, every stream the same number of blocks
+namespace {
+int QueueMinStreams(const LaunchPolicy &p) { return p.queue_min_streams >= 0 ? p.queue_min_streams : p.pipelined_max_streams; }
+// (The quarter rule is for the default chunk; a length set by the caller is taken as it is.)
+int QueueChunkFor(const LaunchPolicy &p, int count) {
+    if (p.queue_chunk_blocks <= 0 || count > p.resident_waves || p.queue_chunk_explicit) return p.queue_chunk_blocks;
+    return std::max(8, p.queue_chunk_blocks / 4);
+}
+bool PipelinedLaunchApplies(const LaunchPolicy &p, int variant, int count, int num_blocks, bool clean, bool ragged) {
+    return variant == kVariantFast && !clean && !ragged && count >= p.pipelined_min_streams && count <= p.pipelined_max_streams &&
+           num_blocks >= p.pipelined_min_blocks;
+}
+int PipeShapeBits(const PipeShape &sh) {
+    return sh.tail_waves | (sh.balance ? 0x100 : 0) | (sh.front_waves == 4 ? 0x200 : 0) | (sh.raw ? 0x400 : 0) | (sh.delay_waves ? 0x800 : 0) |
+           (sh.gain_waves ? 0x1000 : 0);
+}
+}  // namespace
+
+LaunchDescription DescribeLaunchWith(const LaunchPolicy &p, int variant, int count, int num_blocks, bool has_clean) {
+    LaunchDescription d;
+    const int cus = p.compute_units > 0 ? p.compute_units : 256;
+    auto rounds = [&](LaunchDescription &x) { x.rounds_x1000 = (int)((int64_t)1000 * x.workgroups / ((int64_t)cus * std::max(1, x.workgroups_per_cu))); };
+    const int chunk = QueueChunkFor(p, count);
+    if (QueueLaunchApplies(count, num_blocks, variant, chunk, QueueMinStreams(p), false)) {
+        d.form = 2;
+        d.chunk_blocks = chunk;
+        d.waves_per_workgroup = kWavesPerWorkgroup;
+        d.workgroups_per_cu = p.resident_waves / (cus * kWavesPerWorkgroup);
+        d.workgroups = std::min((count + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup, p.resident_waves / kWavesPerWorkgroup);
+        rounds(d);
+        return d;
+    }
+    if (PipelinedLaunchApplies(p, variant, count, num_blocks, has_clean, false)) {
+        const PipeShape sh = PipelinedShapeFor(count, num_blocks, p.compute_units, p.pipe);
+        d.form = 3;
+        d.shape = PipeShapeBits(sh);
+        d.workgroups = sh.workgroups;
+        d.waves_per_workgroup = PipelinedWorkgroupWaves(sh);
+        d.workgroups_per_cu = p.pipe.wgs_per_cu > 0 ? p.pipe.wgs_per_cu : PipelinedWorkgroupsPerCu(sh);
+        rounds(d);
+        return d;
+    }
+    d.form = variant == kVariantFast && count > p.rotation_stream_limit ? 1 : 0;
+    d.waves_per_workgroup = kWavesPerWorkgroup;
+    d.workgroups = (count + kWavesPerWorkgroup - 1) / kWavesPerWorkgroup;
+    d.workgroups_per_cu = (d.form == 1 ? p.resident_waves : std::max(p.rotation_stream_limit, 1)) / (cus * kWavesPerWorkgroup);
+    rounds(d);
+    return d;
+}
+
+// A tick of a session batch (aecm_kernels.hip: aecm_tick_flow_kernel): one wavefront per session, four per workgroup, seven such
+// workgroups per CU -- 65 536 sessions on 256 CUs are 16 384 workgroups on 1 792 places: 9.14 rounds, the last one 14 % full.
+LaunchDescription DescribeTickLaunch(int num_sessions, int compute_units) {
+    LaunchDescription d;
+    const int cus = compute_units > 0 ? compute_units : 256;
+    d.form = 0;
+    d.waves_per_workgroup = TickWorkgroupWaves();
+    d.workgroups = (num_sessions + d.waves_per_workgroup - 1) / d.waves_per_workgroup;
+    d.workgroups_per_cu = TickWorkgroupsPerCu();
+    d.rounds_x1000 = (int)((int64_t)1000 * d.workgroups / ((int64_t)cus * d.workgroups_per_cu));
+    return d;
+}
+
 bool BatchEngine::LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev) {
     if (launch_failed_) return false;                 // streams half processed by an abandoned launch: nothing runs until Init
-    const int chunk = QueueChunkFor(count);
-    if (QueueLaunchApplies(count, num_blocks, variant_, chunk, QueueMinStreams(), blocks_per_stream_dev != nullptr)) {
+    const int chunk = QueueChunkFor(policy_, count);
+    if (QueueLaunchApplies(count, num_blocks, variant_, chunk, QueueMinStreams(policy_), blocks_per_stream_dev != nullptr)) {
         if (!EnsureLaunchControl(QueueControlBytes(count))) return false;
         if (!EnsureLaunchErrorWord()) return false;
         queue_unchecked_ = true;
-        return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, chunk, resident_waves_, queue_ctl_, queue_err_, stream_));
+        return AECM_HIP_OK(LaunchProcessBlocksQueued(st, io, count, num_blocks, chunk, policy_.resident_waves, queue_ctl_, queue_err_, stream_));
     }
-    if (PipelinedLaunchApplies(count, num_blocks, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
-#if defined(AECM_PIPE_TRACE)
-        trace_streams_ = count;
-    if (PipelinedLaunchApplies(count, num_blocks, io.near_clean != nullptr, blocks_per_stream_dev != nullptr))
-#endif
-    {
-        const PipeShape shape = PipelinedShapeFor(count, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_, pipe_delay_, pipe_gain_);
+    if (PipelinedLaunchApplies(policy_, variant_, count, num_blocks, io.near_clean != nullptr, blocks_per_stream_dev != nullptr)) {
+        const PipeShape shape = PipelinedShapeFor(count, num_blocks, policy_.compute_units, policy_.pipe);
         bool need_ctl = shape.balance;
 #if defined(AECM_PIPE_TRACE)
         need_ctl = true;                      // (the diagnostics build keeps the buffer: its per-wave records live behind the progress words)
+        trace_streams_ = shape.workgroups;
 #endif
-        if (need_ctl && !EnsureLaunchControl(PipelinedControlBytes(count))) return false;
+        if (need_ctl && !EnsureLaunchControl(PipelinedControlBytes(shape.workgroups))) return false;
         return AECM_HIP_OK(LaunchProcessBlocksPipelined(st, io, count, num_blocks, shape, need_ctl ? queue_ctl_ : nullptr, stream_));
     }
-    return AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, rotation_limit_, stream_, blocks_per_stream_dev));
-}
-
-// Launches the chip holds at once take the pipelined kernel (aecm_block_kernels.hip): fast variant, no clean input, every
-// stream the same number of blocks.
-bool BatchEngine::PipelinedLaunchApplies(int count, int num_blocks, bool clean, bool ragged) const {
-    return variant_ == kVariantFast && !clean && !ragged && count >= pipe_min_streams_ && count <= pipe_max_streams_ && num_blocks >= pipe_min_blocks_;
-}
-
-// The chunk queue takes every launch of more streams than the pipelined form does (or than min_streams, when set): above the
-// chip's resident waves because the launch would otherwise end in a long drain, and between 4 096 streams and that too --
-// every wave is resident there, but the SIMD's arbiter favours its oldest wave, the waves dispatched first pull ahead, and
-// with items claimed in order those waves simply take more of the work (4 608 streams 728 -> 830 M frames/s, 6 144
-// 844 -> 930 M, 7 168 917 -> 961 M; profiles/r04_experiments.md section 4).  Shorter chunks there: 32 instead of 128 blocks.
-int BatchEngine::QueueMinStreams() const { return queue_min_streams_ >= 0 ? queue_min_streams_ : pipe_max_streams_; }
-// (The quarter rule is for the default and the environment's chunk; a length set through SetLaunchChunking is taken as it is.)
-int BatchEngine::QueueChunkFor(int count) const {
-    if (queue_chunk_ <= 0 || count > resident_waves_ || queue_chunk_explicit_) return queue_chunk_;
-    return std::max(8, queue_chunk_ / 4);
+    return AECM_HIP_OK(LaunchProcessBlocks(st, io, count, num_blocks, variant_, policy_.rotation_stream_limit, stream_, blocks_per_stream_dev));
 }
 
 int BatchEngine::DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const {
-    if (QueueLaunchApplies(num_streams_, num_blocks, variant_, QueueChunkFor(num_streams_), QueueMinStreams(), false)) {
-        if (chunk_blocks) *chunk_blocks = QueueChunkFor(num_streams_);
-        return 2;
-    }
-    if (chunk_blocks) *chunk_blocks = 0;
-    if (PipelinedLaunchApplies(num_streams_, num_blocks, has_clean, false)) {
-        // (for this form: the tail waves per workgroup, + 0x100 when the launch balances its workgroups' progress, + 0x200 with
-        // four front waves, + 0x400 with the raw hand-over, + 0x800 with delay waves, + 0x1000 with gain waves: the kernel's template arguments)
-        const PipeShape sh = PipelinedShapeFor(num_streams_, num_blocks, compute_units_, pipe_tail_, pipe_front_, pipe_raw_, pipe_delay_, pipe_gain_);
-        if (chunk_blocks) *chunk_blocks = sh.tail_waves | (sh.balance ? 0x100 : 0) | (sh.front_waves == 4 ? 0x200 : 0) | (sh.raw ? 0x400 : 0) | (sh.delay_waves ? 0x800 : 0) | (sh.gain_waves ? 0x1000 : 0);
-        return 3;
-    }
-    return variant_ == kVariantFast && num_streams_ > rotation_limit_ ? 1 : 0;
+    const LaunchDescription d = DescribeLaunchWith(policy_, variant_, num_streams_, num_blocks, has_clean);
+    if (chunk_blocks) *chunk_blocks = d.form == 2 ? d.chunk_blocks : d.form == 3 ? d.shape : 0;
+    return d.form;
 }
 
 // Wait for everything enqueued on stream_; false if a HIP call failed or a wave of a chunk-queue launch gave up waiting.
@@ -341,7 +399,11 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
     const size_t per = (size_t)num_streams_ * num_blocks * kBlock;
     const int n_in = io.near_clean ? 3 : 2;
     const size_t need = per * (n_in + 1);
+#if defined(AECM_EXPERIMENTS)
     static const bool mapped = [] { const char *e = getenv("AECM_HOST_MAPPED"); return !(e && e[0] == '0'); }();
+#else
+    constexpr bool mapped = true;
+#endif
     if (mapped && need * sizeof(int16_t) <= kMappedBytes) return ProcessBlocksHostMapped(io, num_blocks);
     if (need > stage_elems_) {
         (void)hipFree(stage_dev_);
@@ -351,7 +413,11 @@ bool BatchEngine::ProcessBlocksHost(const IoView &io, int num_blocks) {
         stage_elems_ = need;
     }
     const bool dense = io.block_stride == kBlock && io.stream_stride == (int64_t)num_blocks * kBlock;
+#if defined(AECM_EXPERIMENTS)
     static const bool pipeline = [] { const char *e = getenv("AECM_HOST_PIPELINE"); return !(e && e[0] == '0'); }();
+#else
+    constexpr bool pipeline = true;
+#endif
     if (pipeline && dense && num_streams_ >= 2 * kHostChunkStreams) return ProcessBlocksHostPipelined(io, num_blocks);
     std::vector<int16_t> tmp;
     auto upload = [&](const int16_t *src, int16_t *dst) -> bool {

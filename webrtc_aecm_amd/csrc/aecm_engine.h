@@ -11,11 +11,39 @@
 
 namespace aecm {
 
-constexpr int kDefaultPipelinedMinStreams = 2;    // a single stream (the drop-in ABI's 10 ms calls) keeps its one-wave launch
-// ... and so do launches of one or two blocks: the pipelined kernel's fill and drain steps (up to five with the sixteen-wave shape)
-// cost more than they save there -- 1 024 streams x 1 / 2 / 3 / 4 blocks: 10.8 / 12.4 / 14.3 / 15.9 us against 8.7 / 11.7 / 15.1 / 18.2 us
-// with one wave per stream (4 096 streams: 13.5 / 19.0 / 23.2 / 27.4 against 12.6 / 18.3 / 23.7 / 28.7)
-constexpr int kDefaultPipelinedMinBlocks = 3;
+constexpr int kDefaultQueueChunk = 128;
+
+// How ProcessBlocks launches are scheduled on a device (results never depend on it): the thresholds between the launch forms and
+// the wishes for the pipelined form's shape.  One value type, set through the C ABI (include/aecm_batch.h: AecmLaunchPolicy mirrors
+// it field by field); DefaultLaunchPolicy derives it from the device's compute units alone.  The environment is consulted only by
+// an -DAECM_EXPERIMENTS build (ApplyEnvironmentWishes).
+struct LaunchPolicy {
+    int compute_units = 0;
+    int queue_chunk_blocks = kDefaultQueueChunk;   // chunk queue: blocks per item; 0 = every launch keeps one wavefront per stream
+    bool queue_chunk_explicit = false;             // set by the caller: taken as it is (else quartered while every stream's wave is resident)
+    int queue_min_streams = -1;                    // the queue above this many streams; < 0: above pipelined_max_streams
+    int pipelined_min_streams = 2;                 // a single stream (the drop-in ABI's 10 ms calls) keeps its one-wave launch; > num_streams: never
+    // launches of one or two blocks keep one wave per stream: the pipelined kernel's fill and drain steps (up to five with the sixteen-wave
+    // shape) cost more than they save there -- 1 024 streams x 1 / 2 / 3 / 4 blocks: 10.8 / 12.4 / 14.3 / 15.9 us against 8.7 / 11.7 / 15.1 / 18.2 us
+    int pipelined_min_blocks = 3;
+    int pipelined_max_streams = 0;                 // what the chip holds of the pipelined form's widest shape (16 streams per CU)
+    int resident_waves = 0;                        // waves of the one-wave-per-stream kernels the chip holds (28 per CU)
+    int rotation_stream_limit = 0;                 // launches of at most this many streams take the kernel variants built for full residency
+    PipeWishes pipe;
+};
+LaunchPolicy DefaultLaunchPolicy(int compute_units);
+bool LaunchPolicyValid(const LaunchPolicy &p);
+// What a ProcessBlocks launch looks like on the device (WebRtcAecmBatch_DescribeLaunchDetail; capacity planning).
+struct LaunchDescription {
+    int form = 0;                   // AECM_LAUNCH_*
+    int chunk_blocks = 0;           // chunk queue: blocks per item
+    int shape = 0;                  // pipelined: the shape bits of WebRtcAecmBatch_DescribeLaunch
+    int workgroups = 0, waves_per_workgroup = 0;
+    int workgroups_per_cu = 0;      // of this kernel a CU holds at once
+    int rounds_x1000 = 0;           // 1000 x workgroups / (CUs x workgroups_per_cu): 1000 = the chip exactly full once; 9140 = nine full rounds and one 14 % full
+};
+LaunchDescription DescribeLaunchWith(const LaunchPolicy &policy, int variant, int num_streams, int num_blocks, bool has_clean);
+LaunchDescription DescribeTickLaunch(int num_sessions, int compute_units);
 
 class BatchEngine {
 public:
@@ -69,16 +97,16 @@ public:
     // blocks = 0: every launch in the one-stream-per-wave form.  min_streams < 0: launches of more streams than the chip
     // holds waves take the queue form (the default); otherwise launches of more than min_streams streams do (tests).
     void set_queue_chunk(int blocks, int min_streams) {
-        queue_chunk_ = blocks < 0 ? 0 : blocks > kMaxQueueChunk ? kMaxQueueChunk : blocks;
-        queue_chunk_explicit_ = true;
-        queue_min_streams_ = min_streams;
+        policy_.queue_chunk_blocks = blocks < 0 ? 0 : blocks > kMaxQueueChunk ? kMaxQueueChunk : blocks;
+        policy_.queue_chunk_explicit = true;
+        policy_.queue_min_streams = min_streams;
     }
     static constexpr int kMaxQueueChunk = 1 << 20;
     int DescribeLaunch(int num_blocks, bool has_clean, int *chunk_blocks) const;
-    // The same for an engine of num_streams streams on a device of compute_units CUs, without one (the launch-form rules are host logic)
-    static int DescribeLaunchFor(int num_streams, int compute_units, int num_blocks, bool has_clean, int *chunk_blocks);
     // n <= 0: never.  A threshold set through the ABI is taken as it is: launches of any length from n streams
-    void set_pipelined_min_streams(int n) { pipe_min_streams_ = n > 0 ? n : 0x7fffffff; pipe_min_blocks_ = 1; }
+    void set_pipelined_min_streams(int n) { policy_.pipelined_min_streams = n > 0 ? n : 0x7fffffff; policy_.pipelined_min_blocks = 1; }
+    const LaunchPolicy &launch_policy() const { return policy_; }
+    bool set_launch_policy(const LaunchPolicy &p);       // false (nothing changed): not a valid policy, or one for another CU count than the device's
     int variant() const { return variant_; }
     const StatePtrs &state_ptrs() const { return st_; }      // for kernels launched by the session batch on stream()
 
@@ -88,27 +116,13 @@ private:
     bool FlushTimers() { return HarvestTimers(true); }
 
     int device_ = 0;
-    int compute_units_ = 0;
-    bool owns_device_resources_ = false;     // set by Create; the destructor of a shell (DescribeLaunchFor) touches no HIP call
-    void ConfigureLaunchForms(int cus);
-    int rotation_limit_ = 0;             // RotationStreamLimit of device_'s CU count (launch-size switch of the block kernels)
-    // The chunk-queue form of large launches (aecm_block_kernels.hip): chunk length in blocks (0 = off; AECM_QUEUE_CHUNK),
-    // the chip's resident waves, the queue's control words (grown on first use) and its error word.
-    int queue_chunk_ = 0, resident_waves_ = 0, queue_min_streams_ = -1;
+    LaunchPolicy policy_;                // DefaultLaunchPolicy of device_'s CU count until the caller sets another
+    // The chunk-queue form's control words (grown on first use) and the error word a wave raises when it gives up waiting.
     uint32_t *queue_ctl_ = nullptr, *queue_err_ = nullptr;
     size_t queue_ctl_bytes_ = 0;
     bool queue_unchecked_ = false;       // a queue launch has been enqueued since the error word was last read
-    bool queue_chunk_explicit_ = false;  // queue_chunk_ was set through set_queue_chunk: taken as it is (QueueChunkFor)
     bool launch_failed_ = false;         // a wave of a queue launch gave up: sticky until Init (CheckQueueError)
-    // The pipelined form of launches the chip holds at once: from pipe_min_streams_ (AECM_PIPELINED; SetLaunchPipelining)
-    // up to PipelinedStreamLimit of the device.
-    int pipe_min_streams_ = kDefaultPipelinedMinStreams, pipe_max_streams_ = 0;
-    int pipe_min_blocks_ = kDefaultPipelinedMinBlocks;        // (AECM_PIPE_MIN_BLOCKS)
-    int pipe_tail_ = -1, pipe_front_ = -1, pipe_raw_ = -1, pipe_delay_ = -1, pipe_gain_ = -1;      // shape overrides (AECM_PIPE_TAIL / _FRONT / _RAW / _DELAY / _GAIN); < 0: by size
-    bool PipelinedLaunchApplies(int count, int num_blocks, bool clean, bool ragged) const;
     bool LaunchBlocks(const StatePtrs &st, const IoView &io, int count, int num_blocks, const int32_t *blocks_per_stream_dev);
-    int QueueMinStreams() const;
-    int QueueChunkFor(int count) const;
     bool CheckQueueError();
     bool Drain();
     bool EnsureLaunchErrorWord();

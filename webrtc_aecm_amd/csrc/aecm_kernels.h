@@ -49,15 +49,28 @@ struct PipeShape {
     bool balance;        // progress feedback on the front waves' issue priority (needs `progress`)
     int delay_waves;     // 0, 4 or (with gain waves) 2 per workgroup: the delay estimator in waves of its own, one block ahead of the back waves (with tail waves, not raw)
     int gain_waves;      // 0 or 4 per workgroup: the gain half of the back waves' work in waves of its own, one block behind the channel half (with delay waves)
+    int wgs_per_round;   // the device's CUs: workgroups i, i + wgs_per_round, ... are taken to share a CU (the dispatcher deals them out in turn) and start their slots on different SIMDs
+    int rot;             // slot rotations: front | gain << 2 | delay << 4 | per workgroup of a CU << 6 | tail << 8 (the kernel's slot_of)
+    int workgroups;      // of the launch: ceil(n_streams / 4) .. n_streams; the streams are dealt out evenly (the first n_streams % workgroups serve one more)
 };
-// The shape a launch of this size takes; tail_waves / front_waves / raw < 0 = by size, else the caller's wish where it exists and fits.
-PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, int tail_waves = -1, int front_waves = -1, int raw = -1, int delay_waves = -1,
-                            int gain_waves = -1);
-int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves = 2, int delay_waves = 0, int gain_waves = 0);
-// progress: PipelinedControlBytes(n_streams) of device memory owned by the engine (cleared by the launch): 16 bits per
+// What a caller may wish for the shape instead of leaving it to the launch's size (experiments, tests: AecmLaunchPolicy in
+// include/aecm_batch.h carries the same fields); < 0 = by size.  A wish is taken where the shape exists and fits.
+struct PipeWishes {
+    int tail_waves = -1, front_waves = -1, raw = -1, delay_waves = -1, gain_waves = -1;
+    int spread = 1;          // != 0: every CU gets the shape's full count of workgroups, of fewer than four streams each where the launch is short of streams
+    int wgs_per_cu = 0;      // > 0: workgroups of the shape a CU takes (0: what the shape is built for)
+    int rot = -1;            // >= 0: PipeShape::rot
+};
+// The shape a launch of this size takes on a device of compute_units CUs.
+PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, const PipeWishes &wishes = PipeWishes());
+int PipelinedStreamLimit(int compute_units, int tail_waves, int front_waves = 2, int delay_waves = 0, int gain_waves = 0, int wgs_per_cu = 0);
+// Waves of a workgroup of this shape, and how many such workgroups a CU holds at once (by the wave slots the kernel is built for and the LDS it declares).
+int PipelinedWorkgroupWaves(const PipeShape &shape);
+int PipelinedWorkgroupsPerCu(const PipeShape &shape);
+// progress: PipelinedControlBytes(shape.workgroups) of device memory owned by the engine (cleared by the launch): 16 bits per
 // workgroup, by which the workgroups of a balanced launch keep in step.
-size_t PipelinedControlBytes(int n_streams);
-size_t PipelinedTraceOffsetBytes(int n_streams);     // diagnostics builds (-DAECM_PIPE_TRACE): where the per-wave records follow the progress words
+size_t PipelinedControlBytes(int n_workgroups);
+size_t PipelinedTraceOffsetBytes(int n_workgroups);     // diagnostics builds (-DAECM_PIPE_TRACE): where the per-wave records follow the progress words
 hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, int n_streams, int n_blocks, const PipeShape &shape, uint32_t *progress,
                                         hipStream_t stream);
 
@@ -122,6 +135,8 @@ struct TickFlowIo {
     int32_t ms, flags, fs;
 };
 hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowIo &fio, int n_streams, hipStream_t stream);
+int TickWorkgroupWaves();        // sessions per workgroup of the tick kernel
+int TickWorkgroupsPerCu();       // workgroups of it a CU holds at once
 // Far-end bursts: WebRtcAecm_BufferFarend calls WITHOUT a Process (reference echo_control_mobile.cc:215-234), one wavefront
 // per session.  Session s makes clamp(calls_per_session[s] - call_base, 0, max_calls) calls of io.n samples (max_calls each
 // when calls_per_session is null) on io.far_in[s][c * io.n .. + io.n): delay compensation when past the start-up phase, then

@@ -401,6 +401,12 @@ void aecm_tick_flow_kernel(StatePtrs st, TickIo io, TickFlowIo fio, int n_stream
     }
 }
 
+int TickWorkgroupWaves() { return kTickFlowWaves; }
+int TickWorkgroupsPerCu() {       // by the wave slots the kernel is built for, and by the LDS its tables take
+    const int by_waves = 4 * AECM_TICK_FLOW_WAVES_PER_EU / kTickFlowWaves, by_lds = (int)((160 * 1024) / sizeof(LdsTables));
+    return by_waves < by_lds ? by_waves : by_lds;
+}
+
 hipError_t LaunchTickFlow(const StatePtrs &st, const TickIo &io, const TickFlowIo &fio, int n_streams, hipStream_t stream) {
     if (n_streams <= 0) return hipSuccess;
     hipLaunchKernelGGL(aecm_flow_plan_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, fio, io.n, (unsigned)io.near_pos, n_streams);

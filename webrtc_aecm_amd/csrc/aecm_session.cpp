@@ -3,14 +3,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/echo_control_mobile.h"
 
 namespace aecm {
 
+// The HIP device single sessions are created on (WebRtcAecm_Create has no device argument): process-wide, set through
+// WebRtcAecm_SetDefaultDevice (include/aecm_batch.h).
+static std::atomic<int> g_default_device{0};
+void Session::SetDefaultDevice(int device) { g_default_device.store(device, std::memory_order_relaxed); }
+int Session::DefaultDevice() { return g_default_device.load(std::memory_order_relaxed); }
+
 Session *Session::Create() {
-    const char *dev_env = getenv("AECM_DEVICE");
-    const int device = dev_env ? atoi(dev_env) : 0;
-    BatchEngine *engine = BatchEngine::Create(1, device);
+    BatchEngine *engine = BatchEngine::Create(1, DefaultDevice());
     if (!engine) return nullptr;                 // no usable GPU: there is no CPU path to fall back to
     Session *s = new Session();
     s->engine_.reset(engine);

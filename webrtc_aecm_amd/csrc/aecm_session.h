@@ -17,6 +17,8 @@ namespace aecm {
 class Session {
 public:
     static Session *Create();
+    static void SetDefaultDevice(int device);     // the HIP device of sessions created from now on (process-wide; default 0)
+    static int DefaultDevice();
     int32_t Init(int32_t samp_freq);
     int32_t BufferFarendError(const int16_t *farend, size_t n) const { return flow_.BufferFarendError(farend, n); }
     int32_t BufferFarend(const int16_t *farend, size_t n) { return flow_.BufferFarend(farend, n); }

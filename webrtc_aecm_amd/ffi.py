@@ -43,6 +43,8 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_ImportStatesDevice", "WebRtcAecmBatch_GetDigest", "WebRtcAecmBatch_SetKernelVariant", "WebRtcAecmBatch_SetLaunchChunking", "WebRtcAecmBatch_SetLaunchPipelining", "WebRtcAecmBatch_DescribeLaunch", "WebRtcAecmBatch_DescribeLaunchFor",
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
     "WebRtcAecmBatch_RegisterHostBuffer", "WebRtcAecmBatch_UnregisterHostBuffer",
+    "WebRtcAecmBatch_DefaultLaunchPolicy", "WebRtcAecmBatch_GetLaunchPolicy", "WebRtcAecmBatch_SetLaunchPolicy", "WebRtcAecmBatch_DescribeLaunchDetail",
+    "WebRtcAecm_SetDefaultDevice",
 ]
 SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_Create", "WebRtcAecmSessions_Free", "WebRtcAecmSessions_Init", "WebRtcAecmSessions_set_config",
@@ -52,7 +54,7 @@ SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_GetEchoPath", "WebRtcAecmSessions_TickAsync", "WebRtcAecmSessions_Synchronize",
     "WebRtcAecmSessions_SetKernelVariant", "WebRtcAecmSessions_session_size_bytes", "WebRtcAecmSessions_ExportSession",
     "WebRtcAecmSessions_ImportSession", "WebRtcAecmSessions_BufferFarend", "WebRtcAecmSessions_BufferFarendHost",
-    "WebRtcAecmSessions_BufferFarendAsync", "WebRtcAecmSessions_Process", "WebRtcAecmSessions_ProcessHost",
+    "WebRtcAecmSessions_BufferFarendAsync", "WebRtcAecmSessions_Process", "WebRtcAecmSessions_ProcessHost", "WebRtcAecmSessions_DescribeTick",
 ]
 SESSION_NO_FAREND = 1
 SESSION_SPLIT_CALLS = 2
@@ -63,6 +65,24 @@ class AecmConfig(C.Structure):
 
 
 _lib = None
+
+
+class AecmLaunchPolicy(C.Structure):
+    """include/aecm_batch.h: AecmLaunchPolicy (every threshold and wish that decides how a ProcessBlocks launch is scheduled)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "compute_units", "queue_chunk_blocks", "queue_chunk_explicit", "queue_min_streams", "pipelined_min_streams",
+        "pipelined_min_blocks", "pipelined_max_streams", "resident_waves", "rotation_stream_limit", "pipe_tail_waves", "pipe_front_waves",
+        "pipe_raw", "pipe_delay_waves", "pipe_gain_waves", "pipe_spread", "pipe_wgs_per_cu", "pipe_rot")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class AecmLaunchDescription(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("form", "chunk_blocks", "shape", "workgroups", "waves_per_workgroup", "workgroups_per_cu", "rounds_x1000")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 def library_path() -> Path:
@@ -130,6 +150,13 @@ def load():
     lib.WebRtcAecmBatch_DescribeLaunch.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.WebRtcAecmBatch_SetLaunchPipelining.argtypes = [vp, C.c_int32]
     lib.WebRtcAecmBatch_DescribeLaunchFor.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    lib.WebRtcAecmBatch_DefaultLaunchPolicy.argtypes = [C.c_int32, C.POINTER(AecmLaunchPolicy)]
+    lib.WebRtcAecmBatch_GetLaunchPolicy.argtypes = [vp, C.POINTER(AecmLaunchPolicy)]
+    lib.WebRtcAecmBatch_SetLaunchPolicy.argtypes = [vp, C.POINTER(AecmLaunchPolicy)]
+    lib.WebRtcAecmBatch_DescribeLaunchDetail.argtypes = [C.POINTER(AecmLaunchPolicy), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                         C.POINTER(AecmLaunchDescription)]
+    lib.WebRtcAecmSessions_DescribeTick.argtypes = [C.c_int32, C.c_int32, C.POINTER(AecmLaunchDescription)]
+    lib.WebRtcAecm_SetDefaultDevice.argtypes = [C.c_int32]
     lib.WebRtcAecmSessions_Create.restype = vp
     lib.WebRtcAecmSessions_Create.argtypes = [C.c_int32, C.c_int32]
     lib.WebRtcAecmSessions_Free.argtypes = [vp]
@@ -269,6 +296,21 @@ class AecmBatch:
         <= 0: never.  By default launches of one or two blocks keep one wavefront per stream; after this call launches of
         any length do what min_streams says."""
         self._check(self.lib.WebRtcAecmBatch_SetLaunchPipelining(self.h, min_streams), "SetLaunchPipelining")
+
+    def launch_policy(self) -> AecmLaunchPolicy:
+        p = AecmLaunchPolicy()
+        self._check(self.lib.WebRtcAecmBatch_GetLaunchPolicy(self.h, C.byref(p)), "WebRtcAecmBatch_GetLaunchPolicy")
+        return p
+
+    def set_launch_policy(self, policy=None, **fields):
+        """Set the batch's launch policy: a whole AecmLaunchPolicy, or the current one with `fields` changed
+        (e.g. pipe_tail_waves=0, queue_min_streams=0)."""
+        p = policy if policy is not None else self.launch_policy()
+        for k, v in fields.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        self._check(self.lib.WebRtcAecmBatch_SetLaunchPolicy(self.h, C.byref(p)), "WebRtcAecmBatch_SetLaunchPolicy")
 
     def describe_launch(self, num_blocks, clean=False):
         """(form, chunk_blocks) of a ProcessBlocks launch of num_blocks blocks: form 0 / 1 = one wavefront per stream
@@ -637,6 +679,37 @@ def describe_launch_for(num_streams: int, compute_units: int, num_blocks: int, c
     if form < 0:
         raise AecmError(form, "WebRtcAecmBatch_DescribeLaunchFor")
     return form, chunk.value
+
+
+def default_launch_policy(compute_units: int) -> AecmLaunchPolicy:
+    p = AecmLaunchPolicy()
+    rc = load().WebRtcAecmBatch_DefaultLaunchPolicy(compute_units, C.byref(p))
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_DefaultLaunchPolicy")
+    return p
+
+
+def describe_launch_detail(num_streams: int, num_blocks: int, compute_units: int = 0, clean: bool = False, policy=None) -> dict:
+    """Form, shape, grid and chip quantisation of a launch (include/aecm_batch.h: AecmLaunchDescription), without a device:
+    under `policy` (an AecmLaunchPolicy) or the default policy of compute_units."""
+    d = AecmLaunchDescription()
+    rc = load().WebRtcAecmBatch_DescribeLaunchDetail(C.byref(policy) if policy is not None else None, compute_units, num_streams, num_blocks,
+                                                     1 if clean else 0, C.byref(d))
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_DescribeLaunchDetail")
+    return d.as_dict()
+
+
+def describe_tick(num_sessions: int, compute_units: int) -> dict:
+    d = AecmLaunchDescription()
+    rc = load().WebRtcAecmSessions_DescribeTick(num_sessions, compute_units, C.byref(d))
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmSessions_DescribeTick")
+    return d.as_dict()
+
+
+def set_default_device(device: int) -> int:
+    return load().WebRtcAecm_SetDefaultDevice(device)
 
 
 def device_info(device: int = 0):
