@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--profile", choices=sorted(PROFILES), default="recipe",
                     help="content of the synthetic signals (the frame rate depends on which data-dependent paths the blocks take): "
                          + "; ".join(f"{k} = {v[3]}" for k, v in PROFILES.items()))
+    ap.add_argument("--policy", default="",
+                    help="launch-policy fields to change, 'field=value field=value' of AecmLaunchPolicy (include/aecm_batch.h), e.g. "
+                         "'queue_chunk_blocks=0' (one wavefront per stream always) or 'pipelined_min_streams=0'; A/B runs -- the default is the shipped policy")
     ap.add_argument("--fixed-delay", type=int, default=-1,
                     help="WebRtcAecm_Control fixed delay (>= 0 disables the estimator's choice; 0 = no far-history reads; "
                          "used to calibrate the FETCH_SIZE counter on a known byte count)")
@@ -338,6 +341,8 @@ def main():
     clean = (near.to(torch.int32) * 3 // 4).to(torch.int16) if args.clean else None
     batch = aecm.AecmBatch(S, args.fs, cng_mode=1, echo_mode=1, device=local_rank,
                            variant=aecm.KERNEL_FAST if args.variant == "fast" else aecm.KERNEL_SAFE)
+    if args.policy:
+        batch.set_launch_policy(**{kv.split("=", 1)[0]: int(kv.split("=", 1)[1], 0) for kv in args.policy.split()})
     if args.fixed_delay >= 0:
         batch.control(args.fixed_delay, 1)
     stride = far.shape[1]
@@ -373,7 +378,9 @@ def main():
     launches = K                            # per step from here on (a step is len(chunks) launches only under --launch-blocks)
 
     cdev = device if args.dist_backend == "nccl" else torch.device("cpu")
-    dev_name = "%s (%d CUs, hip device %d)" % (aecm.device_info(local_rank)[0], aecm.device_info(local_rank)[1], local_rank)
+    _form, _detail = batch.describe_launch(C, bool(args.clean))
+    dev_name = "%s %d CUs hip%d pci %s form %d/%#x" % (aecm.device_info(local_rank)[0].split(":")[0], aecm.device_info(local_rank)[1], local_rank,
+                                                       aecm.device_pci_bus_id(local_rank), _form, _detail)      # (64 bytes travel per rank)
     c = adist.gather_counters(S * T * K, wall, kernel_ms_total, cdev, dev_name)
     parity = None
     if not args.no_parity:                  # every rank checks streams of its own shard; rank 0 reports, all must agree
@@ -407,7 +414,7 @@ def main():
                        "streams_per_gpu": S, "blocks_per_step": T, "launches_per_step": len(chunks), "launch_form": form,
                        "launch_chunk_blocks": chunk if form == 2 else 0, "pipelined_tail_waves": (chunk & 0xff) if form == 3 else None, "fs": args.fs, "kernel_variant": args.variant,
                        "sharding": f"static, {world} x {S} independent streams, no data-path collective",
-                       "timed_region_s": c["seconds"], "commit": commit},
+                       "timed_region_s": c["seconds"], "commit": commit, **({"launch_policy_changes": args.policy} if args.policy else {})},
             "device": dict(zip(("name", "compute_units", "clock_khz"), aecm.device_info(local_rank))),
             "ranks": {"world_size": world, "ranks_seen": c["ranks_seen"], "collective_backend": c["backend"],
                       "devices_visible_to_rank0": n_dev, "share_devices": bool(args.share_devices),

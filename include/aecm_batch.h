@@ -117,6 +117,8 @@ int32_t WebRtcAecmBatch_ImportState(AecmBatch *b, int32_t stream, const void *st
  * the *Device form) before any stream is touched; AECM_BAD_PARAMETER_ERROR if one of them may not be run on. */
 int32_t WebRtcAecmBatch_ExportStates(AecmBatch *b, int32_t first, int32_t count, void *states_host, size_t size_bytes);
 int32_t WebRtcAecmBatch_ImportStates(AecmBatch *b, int32_t first, int32_t count, const void *states_host, size_t size_bytes);
+/* (The *Device forms: states_dev must be 4-byte aligned -- AECM_BAD_PARAMETER_ERROR otherwise -- and, for ImportStatesDevice, must not
+ * change while the call runs: the blobs are validated by one launch and written into the streams by a second one.) */
 int32_t WebRtcAecmBatch_ExportStatesDevice(AecmBatch *b, int32_t first, int32_t count, void *states_dev, size_t size_bytes);
 int32_t WebRtcAecmBatch_ImportStatesDevice(AecmBatch *b, int32_t first, int32_t count, const void *states_dev, size_t size_bytes);
 
@@ -367,6 +369,8 @@ int32_t WebRtcAecmBatch_DebugFft128(int32_t device_id, int16_t *data_host, int32
 /* Name, CU count and clock of the device the library would use (diagnostics). */
 int32_t WebRtcAecmBatch_DeviceInfo(int32_t device_id, char *name, size_t name_len, int32_t *compute_units,
                                    int32_t *clock_khz);
+/* Its PCI bus id ("0000:05:00.0"; bus_id_len >= 13): which physical GPU a rank of a multi-GPU run really had. */
+int32_t WebRtcAecmBatch_DevicePciBusId(int32_t device_id, char *bus_id, size_t bus_id_len);
 
 #ifdef __cplusplus
 }

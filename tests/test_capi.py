@@ -95,6 +95,23 @@ def test_launch_policy_is_one_value_and_the_library_reads_no_environment(monkeyp
     assert shape(pipe_gain_waves=0)["shape"] == 0x802
     assert shape(pipe_delay_waves=0)["shape"] == 0x2 and shape(pipe_delay_waves=0, pipe_raw=1, pipe_front_waves=4)["shape"] == 0x602
     assert shape(pipe_tail_waves=0)["shape"] == 0x0
+    # wishes that name a kernel the library does not carry land on the nearest one it does (never on a launch error):
+    # four front waves without the raw hand-over -> with it, for every size and CU count
+    for cus, S in ((256, 1024), (256, 2048), (64, 300), (304, 2000)):
+        q = aecm.default_launch_policy(cus)
+        q.pipe_raw, q.pipe_delay_waves, q.pipe_front_waves = 0, 0, 4
+        assert aecm.describe_launch_detail(S, 300, policy=q)["shape"] == 0x602, (cus, S)
+    built = {0x0, 0x500, 0x2, 0x402, 0x602, 0x802, 0x1a02}
+    for tail in (-1, 0, 2):
+        for front in (-1, 2, 4):
+            for raw in (-1, 0, 1):
+                for delay in (-1, 0, 2, 4):
+                    for gain in (-1, 0, 4):
+                        for S in (7, 1024, 1500, 2048, 2500, 3072, 3500, 4096):
+                            q = aecm.default_launch_policy(256)
+                            q.pipe_tail_waves, q.pipe_front_waves, q.pipe_raw, q.pipe_delay_waves, q.pipe_gain_waves = tail, front, raw, delay, gain
+                            d = aecm.describe_launch_detail(S, 300, policy=q)
+                            assert d["form"] == 3 and d["shape"] in built, (tail, front, raw, delay, gain, S, hex(d["shape"]))
     assert shape(pipelined_min_streams=0)["form"] == 0
     assert shape(queue_min_streams=0, pipelined_min_streams=5000) == dict(form=2, chunk_blocks=32, shape=0, workgroups=256, waves_per_workgroup=4,
                                                                            workgroups_per_cu=7, rounds_x1000=142)
@@ -124,6 +141,33 @@ def test_launch_policy_is_one_value_and_the_library_reads_no_environment(monkeyp
                 stack.pop()
             elif "getenv" in t and not t.startswith("//"):
                 assert any(stack), f"{src.name}:{n}: getenv in the default build"
+
+
+def test_cmake_build_equals_the_python_recipe(tmp_path):
+    """The C/C++-native recipe (top-level CMakeLists.txt: `cmake -S . -B build && cmake --build build`, no Python) and
+    webrtc_aecm_amd/build.py must produce the same product: every kernel of both libraries with the same instruction stream
+    (isa_census fingerprints -- the per-source -mllvm flags are worth 9 % of the frame rate), the same exported C ABI, and the
+    command-line tool."""
+    import shutil
+    import subprocess
+    if not shutil.which("cmake"):
+        pytest.skip("no cmake on this machine")
+    from webrtc_aecm_amd import build, ffi, isa_census
+    build.build()
+    out = tmp_path / "build"
+    subprocess.run(["cmake", "-S", str(ROOT), "-B", str(out)], check=True, capture_output=True)
+    subprocess.run(["cmake", "--build", str(out), "-j", "8"], check=True, capture_output=True)
+    for ours, theirs in ((build.LIB, out / "libaecm_mi355x.so"), (build.LIB_CHECKED, out / "libaecm_mi355x_checked.so")):
+        a = isa_census.census_of_text(isa_census.disassemble(ours))
+        b = isa_census.census_of_text(isa_census.disassemble(theirs))
+        assert len(a) >= 25 and set(a) == set(b)
+        assert {k: v["fingerprint"] for k, v in a.items()} == {k: v["fingerprint"] for k, v in b.items()}, theirs.name
+    lib = ctypes.CDLL(str(out / "libaecm_mi355x.so"))
+    for name in ffi.SESSION_SYMBOLS + ffi.BATCH_SYMBOLS + ffi.SESSIONS_SYMBOLS:
+        assert hasattr(lib, name), name
+    assert (out / "aecm_run").exists()
+    r = subprocess.run([str(out / "aecm_run")], capture_output=True, text=True)
+    assert "usage : aecm_run" in r.stdout
 
 
 def test_product_does_not_use_the_oracle():

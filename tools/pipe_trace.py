@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--blocks", type=int, default=2048)
     ap.add_argument("--fs", type=int, default=16000)
+    ap.add_argument("--policy", default="", help="launch-policy fields to change: 'field=value ...' of AecmLaunchPolicy")
     a = ap.parse_args()
     trace = tempfile.NamedTemporaryFile(suffix=".bin", delete=False).name
     os.environ["AECM_PIPE_TRACE_FILE"] = trace
@@ -35,6 +36,8 @@ def main():
     far, near = bench.synth_on_device(torch, S, T * 64, 1234, dev)
     out = torch.empty_like(near)
     b = aecm.AecmBatch(S, a.fs, cng_mode=1, echo_mode=1)
+    if a.policy:
+        b.set_launch_policy(**{kv.split("=", 1)[0]: int(kv.split("=", 1)[1], 0) for kv in a.policy.split()})
     assert b.describe_launch(T)[0] == 3, "not a pipelined launch"
     shape = b.describe_launch(T)[1]
     gain_waves = 4 if shape & 0x1000 else 0

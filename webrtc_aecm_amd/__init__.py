@@ -5,9 +5,9 @@ The hot path -- WebRtcAecm_ProcessBlock of cpuimage/WebRTC_AECM -- is hand-writt
 batch extension (include/*.h).  This package only builds and binds that shared library.
 """
 from .ffi import (check_counters, Aecm, AecmBatch, AecmSessions, AecmConfig, AecmError, AecmLaunchPolicy, KERNEL_FAST, KERNEL_SAFE, debug_fft128,  # noqa: F401
-                  default_launch_policy, describe_launch_detail, describe_launch_for, describe_tick, device_info, library_path, load,
+                  default_launch_policy, describe_launch_detail, describe_launch_for, describe_tick, device_info, device_pci_bus_id, library_path, load,
                   register_host_buffer, self_test, set_default_device, unregister_host_buffer)
 
 __all__ = ["check_counters", "Aecm", "AecmBatch", "AecmSessions", "AecmConfig", "AecmError", "AecmLaunchPolicy", "KERNEL_FAST", "KERNEL_SAFE", "debug_fft128",
-           "default_launch_policy", "describe_launch_detail", "describe_launch_for", "describe_tick", "device_info", "library_path", "load",
+           "default_launch_policy", "describe_launch_detail", "describe_launch_for", "describe_tick", "device_info", "device_pci_bus_id", "library_path", "load",
            "register_host_buffer", "self_test", "set_default_device", "unregister_host_buffer"]

@@ -922,6 +922,9 @@ PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, cons
             sh.delay_waves = 2;
         }
     }
+    // Onto the set of kernels the library carries (LaunchProcessBlocksPipelined): four front waves exist with the raw hand-over (or with
+    // delay and gain waves) only -- a wish for them without it gets the raw form rather than a launch error.
+    if (sh.front_waves == 4 && sh.delay_waves == 0 && !sh.raw) sh.raw = true;
     // Even load (round 6).  The shape holds per_cu workgroups on a CU; with fewer workgroups of four streams than that on some CUs
     // the launch ends when the fullest CU does (1 536 streams = 384 workgroups: half the CUs carried two, the launch ran slower than
     // 1 024 streams).  Every CU gets its full count of workgroups instead, of three or four (two, one) streams each: the

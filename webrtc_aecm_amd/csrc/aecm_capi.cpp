@@ -259,6 +259,7 @@ int32_t WebRtcAecmBatch_ImportStates(AecmBatch *b, int32_t first, int32_t count,
 
 int32_t WebRtcAecmBatch_ExportStatesDevice(AecmBatch *b, int32_t first, int32_t count, void *states_dev, size_t size_bytes) {
     if (int32_t rc = CheckStates(b, first, count, states_dev, size_bytes)) return rc;
+    if (reinterpret_cast<uintptr_t>(states_dev) & 3) return AECM_BAD_PARAMETER_ERROR;        // the kernels move 32-bit words
     return b->engine->ExportStates(first, count, states_dev, true) ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
@@ -641,6 +642,12 @@ int32_t WebRtcAecmBatch_DeviceInfo(int32_t device_id, char *name, size_t name_le
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (clock_khz) *clock_khz = prop.clockRate;
     return 0;
+}
+
+int32_t WebRtcAecmBatch_DevicePciBusId(int32_t device_id, char *bus_id, size_t bus_id_len) {
+    if (!bus_id) return AECM_NULL_POINTER_ERROR;
+    if (bus_id_len < 13) return AECM_BAD_PARAMETER_ERROR;                     // "0000:00:00.0" + NUL
+    return hipDeviceGetPCIBusId(bus_id, (int)bus_id_len, device_id) == hipSuccess ? 0 : AECM_UNSPECIFIED_ERROR;
 }
 
 }  // extern "C"

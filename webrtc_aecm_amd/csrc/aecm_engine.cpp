@@ -779,6 +779,8 @@ int32_t BatchEngine::ImportStates(int first, int count, const void *states, bool
     if (count == 0) return 0;
     bool other_rate = false;
     if (device) {
+        // the kernels read the blobs as 32-bit words: a pointer that is not a multiple of 4 would fault on the GPU
+        if (reinterpret_cast<uintptr_t>(states) & 3) return kErrBadParameter;
         if (!EnsureStateStage(1)) return kErrUnspecified;
         const uint32_t preset[2] = {0xffffffffu, 0u};
         uint32_t verdict[2] = {0, 0};

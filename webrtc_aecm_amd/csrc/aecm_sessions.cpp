@@ -255,8 +255,12 @@ int32_t SessionBatch::Enqueue(const int16_t *far, const int16_t *near, const int
     }
     if (clean && !clean_ring_) {
         const size_t bytes = (size_t)S * kRing * 2;
-        if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st)))
-            return AECM_UNSPECIFIED_ERROR;
+        if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes))) { clean_ring_ = nullptr; return AECM_UNSPECIFIED_ERROR; }
+        if (!AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st))) {
+            (void)hipFree(clean_ring_);
+            clean_ring_ = nullptr;
+            return Fail();
+        }
     }
     auto fail = [&]() -> int32_t { return Fail(); };
     // this tick's argument slot
@@ -413,14 +417,26 @@ int32_t SessionBatch::ImportSession(int session, const void *buf) {
     SnapshotHeader core;                                     // the core state must be of the session's rate
     memcpy(&core, p + at.state, sizeof core);
     if (!SnapshotHeaderOk(core) || core.fs != h.fs) return AECM_BAD_PARAMETER_ERROR;
+    {   // the block-stream blob: the same rules ImportState applies, BEFORE anything is allocated or written (a refused snapshot changes nothing)
+        std::vector<uint32_t> vec(kVecWordsPerStream);
+        int32_t scal[kNumScal];
+        memcpy(vec.data(), p + at.state + BatchEngine::kStateHeaderBytes, kVecWordsPerStream * 4);
+        memcpy(scal, p + at.state + BatchEngine::kStateHeaderBytes + kVecWordsPerStream * 4, sizeof scal);
+        if (ValidateStateImage(vec.data(), scal, (int)core.fs) != nullptr) return AECM_BAD_PARAMETER_ERROR;
+    }
     if (!AECM_HIP_OK(hipSetDevice(device_))) return AECM_UNSPECIFIED_ERROR;
     const int S = engine_->num_streams();
     hipStream_t st = engine_->stream();
     if (h.has_clean && !clean_ring_) {                      // as the first tick that carries a clean near end would
         const size_t bytes = (size_t)S * kRing * 2;
-        if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes)) || !AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st))) return AECM_UNSPECIFIED_ERROR;
+        if (!AECM_HIP_OK(hipMalloc((void **)&clean_ring_, bytes))) { clean_ring_ = nullptr; return AECM_UNSPECIFIED_ERROR; }
+        if (!AECM_HIP_OK(hipMemsetAsync(clean_ring_, 0, bytes, st))) {      // a ring that may hold anything is no ring
+            (void)hipFree(clean_ring_);
+            clean_ring_ = nullptr;
+            return Fail();
+        }
     }
-    // the block-stream blob last among the checks (ImportState validates it and is the first thing that writes), first among the writes
+    // (ImportState validates the blob once more and is the first thing that writes)
     if (const int32_t rc = engine_->ImportState(session, p + at.state)) return rc;
     std::vector<int16_t> row(kRing, 0);
     auto place_tail = [&](int16_t *ring_row, uint32_t end_pos, int n, const uint8_t *src, bool zero_rest) -> bool {

@@ -84,7 +84,7 @@ def gather_counters(frames: int, seconds: float, kernel_ms: float, device, name:
     rows = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(rows, mine)
     per_rank = [(int(round(r[0].item())), float(r[1].item()), float(r[2].item())) for r in rows]
-    nb = name.encode()[:64].ljust(64, b"\0")                           # device names as fixed-size byte rows
+    nb = name.encode()[:96].ljust(96, b"\0")                           # device names as fixed-size byte rows
     mine_n = torch.tensor(list(nb), dtype=torch.uint8, device=device)
     rows_n = [torch.zeros_like(mine_n) for _ in range(world)]
     dist.all_gather(rows_n, mine_n)

@@ -44,7 +44,7 @@ BATCH_SYMBOLS = [
     "WebRtcAecmBatch_SelfTest", "WebRtcAecmBatch_DebugFft128", "WebRtcAecmBatch_DeviceInfo", "WebRtcAecmBatch_GetCheckCounters",
     "WebRtcAecmBatch_RegisterHostBuffer", "WebRtcAecmBatch_UnregisterHostBuffer",
     "WebRtcAecmBatch_DefaultLaunchPolicy", "WebRtcAecmBatch_GetLaunchPolicy", "WebRtcAecmBatch_SetLaunchPolicy", "WebRtcAecmBatch_DescribeLaunchDetail",
-    "WebRtcAecm_SetDefaultDevice",
+    "WebRtcAecm_SetDefaultDevice", "WebRtcAecmBatch_DevicePciBusId",
 ]
 SESSIONS_SYMBOLS = [
     "WebRtcAecmSessions_Create", "WebRtcAecmSessions_Free", "WebRtcAecmSessions_Init", "WebRtcAecmSessions_set_config",
@@ -187,6 +187,7 @@ def load():
     lib.WebRtcAecmBatch_SelfTest.argtypes = [C.c_int32, C.c_int32, vp]
     lib.WebRtcAecmBatch_DebugFft128.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32]
     lib.WebRtcAecmBatch_DeviceInfo.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.WebRtcAecmBatch_DevicePciBusId.argtypes = [C.c_int32, C.c_char_p, C.c_size_t]
     _lib = lib
     return lib
 
@@ -710,6 +711,14 @@ def describe_tick(num_sessions: int, compute_units: int) -> dict:
 
 def set_default_device(device: int) -> int:
     return load().WebRtcAecm_SetDefaultDevice(device)
+
+
+def device_pci_bus_id(device: int = 0) -> str:
+    buf = C.create_string_buffer(32)
+    rc = load().WebRtcAecmBatch_DevicePciBusId(device, buf, 32)
+    if rc != 0:
+        raise AecmError(rc, "WebRtcAecmBatch_DevicePciBusId")
+    return buf.value.decode()
 
 
 def device_info(device: int = 0):
