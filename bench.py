@@ -34,11 +34,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_FRAME = 384            # 128 far in + 128 near in + 128 out
 HBM_PEAK_GBPS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# rocprofv3 records of this round's kernels (tools/gpu_round5_final.sh): the headline (chunk-queue kernel), the configs[1] kernel (pipelined,
-# balanced) and the small launches' kernel (pipelined, sixteen waves per four streams)
-PROFILE_SUMMARIES = [ROOT / "profiles" / "r05_rocprof_summary.json", ROOT / "profiles" / "r05_pipelined_rocprof_summary.json",
-                     ROOT / "profiles" / "r05_small_rocprof_summary.json", ROOT / "profiles" / "r05_mid2048_rocprof_summary.json",
-                     ROOT / "profiles" / "r05_mid3072_rocprof_summary.json"]
+# rocprofv3 records of this round's kernels (tools/gpu_round_final.sh): the headline (chunk-queue kernel), the configs[1] kernel (pipelined,
+# balanced) and the small launches' kernel (pipelined, sixteen waves per workgroup)
+PROFILE_SUMMARIES = [ROOT / "profiles" / "r06_rocprof_summary.json", ROOT / "profiles" / "r06_pipelined_rocprof_summary.json",
+                     ROOT / "profiles" / "r06_small_rocprof_summary.json"]
 
 
 PROFILES = {
@@ -229,7 +228,7 @@ def workload_name(S, T, fs, world, clean):
 
 def load_profile_record(lib_path, workload_key, kernel_substr):
     """Issue-port figures and HBM traffic of the dominant kernel come from separate rocprofv3 PMC passes
-    (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/r05_*rocprof_summary.json), which cannot run
+    (tools/profile_gpu.sh -> tools/summarize_profile.py -> profiles/r06_*rocprof_summary.json), which cannot run
     inside this process.  They are only valid for the binary they were measured on: the summary stores the
     instruction-stream fingerprint of the profiled kernel (webrtc_aecm_amd/isa_census.py) and is quoted only
     when the library timed here has the same fingerprint and the same workload; otherwise it is reported as stale."""
@@ -250,7 +249,7 @@ def load_profile_record(lib_path, workload_key, kernel_substr):
         return None, dict(static, available=False, stale=bool(same_kernel),
                           reason=(f"profiles/{p.name} was measured on kernel fingerprint {r.get('kernel_fingerprint')} (commit {r.get('measured_at_commit')}), "
                                   f"this library is {now['fingerprint']}: re-profile") if same_kernel else
-                                 f"no rocprofv3 record of {now['kernel'][:60]} under profiles/ (recorded: the headline and the four pipelined shapes' kernels)")
+                                 f"no rocprofv3 record of {now['kernel'][:60]} under profiles/ (recorded: the headline, the configs[1] and the sixteen-wave kernels)")
     PROFILE_SUMMARY, rec = match[0]
     d = rec.get("derived", {})
     note = dict(static, available=True, measured_at_commit=rec.get("measured_at_commit"),
@@ -441,7 +440,7 @@ def main():
         }
         shares = parity.pop("content_shares", None) if parity is not None else None
         # what the frame rate was measured ON: the signal profile and, from the checker's streams over the timed passes, how many
-        # blocks took the data-dependent paths that cost or save work (profiles/r05_content_sweep.txt has all profiles side by side)
+        # blocks took the data-dependent paths that cost or save work (profiles/r06_content_sweep.txt has all profiles side by side)
         res["content"] = {"profile": args.profile, "what": PROFILES[args.profile][3],
                           "nlms_share": shares and shares.get("nlms_share"), "passthrough_share": shares and shares.get("gain_zero_share"),
                           "q_steady_share": shares and shares.get("q_steady_share"), "ifft_unscaled_share": shares and shares.get("ifft_unscaled_share"),

@@ -1259,6 +1259,52 @@ def test_65536_live_sessions_property(fs, frame):
 
 
 @_needs_ref
+@pytest.mark.parametrize("fs,frame", [(16000, 160), (8000, 80)])
+def test_65536_live_sessions_with_far_end_bursts_property(fs, frame):
+    """Far-end bursts at the full serving size: 65 536 sessions replicate 32 distinct (audio, burst pattern, msInSndCardBuf) triples
+    -- k = 0, 1, 1, 1, 2, 3 far calls per near call and 30-frame bursts that overflow the jitter buffer, through
+    WebRtcAecmSessions_BufferFarend + _Process on device pointers -- and every session must equal the reference session of the
+    triple it replicates, call by call."""
+    import torch
+    S, U, n_calls = 65536, 32, 110
+    pats = [call_pattern(50 + k, n_calls, bursts=True) for k in range(U)]
+    k_u = np.stack([p[1] for p in pats], axis=1).astype(np.int64)                # [n_calls, U]
+    ms_u = np.stack([p[0] for p in pats], axis=1)
+    fars = [synth_pair(7100 + k, int(k_u[:, k].sum()) * frame // 64 + 1, fs, "mixed")[0] for k in range(U)]
+    near_u = np.stack([synth_pair(7100 + k, n_calls * frame // 64 + 1, fs, "mixed")[1][:n_calls * frame] for k in range(U)])
+    refs = [pyoracle.RefSession(fs, 1, 3) for _ in range(U)]
+    idx = torch.arange(S) % U
+    idx_np = idx.numpy()
+    dnear_all = torch.from_numpy(near_u)[idx].contiguous().cuda()
+    dout = torch.empty((S, frame), dtype=torch.int16, device="cuda")
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    cursor = np.zeros(U, dtype=np.int64)
+    for i in range(n_calls):
+        sl = slice(i * frame, (i + 1) * frame)
+        k = k_u[i]
+        kmax = int(k.max())
+        rows = np.zeros((U, max(kmax, 1) * frame), dtype=np.int16)
+        want = np.empty((U, frame), dtype=np.int16)
+        codes = np.empty(U, dtype=np.int32)
+        for q in range(U):
+            rows[q, :k[q] * frame] = fars[q][cursor[q]:cursor[q] + k[q] * frame]
+            for j in range(k[q]):
+                assert refs[q].buffer_farend(rows[q, j * frame:(j + 1) * frame]) == 0
+            codes[q], want[q] = refs[q].process(near_u[q, sl], None, int(ms_u[i, q]))
+            cursor[q] += k[q] * frame
+        if kmax:
+            drows = torch.from_numpy(rows)[idx].contiguous().cuda()
+            torch.cuda.synchronize()
+            assert sb.buffer_farend_device(drows.data_ptr(), rows.shape[1], frame, kmax, k[idx_np].astype(np.uint8)) == 0
+        dn = dnear_all[:, sl].contiguous()
+        torch.cuda.synchronize()
+        rc = sb.process_device(dn.data_ptr(), dout.data_ptr(), frame, frame, ms_per_session=ms_u[i][idx_np])
+        assert rc == next((int(c) for c in codes if c), 0), i
+        assert torch.equal(dout.view(S // U, U, frame), torch.from_numpy(want).cuda().unsqueeze(0).expand(S // U, U, frame)), i
+    sb.close()
+
+
+@_needs_ref
 def test_sixteen_thousand_sessions_each_with_its_own_history():
     """The serving shape at scale: 16 384 live sessions, EVERY one with its own msInSndCardBuf walk, its own far-end
     underruns, its own call shape (one 160-sample call or two of 80) and its own age (slots re-initialised at random
