@@ -245,6 +245,47 @@ def test_block_kernel_register_budget(tmp_path):
         assert wide_loads <= 6 and scalar_loads >= 14, (has_clean, wide_loads, scalar_loads)
 
 
+def test_kernels_fit_the_residency_the_launch_policy_counts_on(tmp_path):
+    """The launch policy counts on a residency per kernel -- 28 waves of the one-wave-per-stream and tick kernels per CU, 2 x 16 of
+    the sixteen-wave pipelined kernel, 3 x 8 and 4 x 6 of the eight- and six-wave ones (WebRtcAecmBatch_DescribeLaunchDetail:
+    workgroups_per_cu x waves_per_workgroup).  What the hardware admits follows from the code object (MI355X_MICROARCH.md,
+    "Residency": waves per SIMD = min(8, 512 / VGPRs rounded up to 8, 800 / (SGPRs rounded up to 16 + 16)) -- the compiler's own
+    occupancy line is one too high at 82-96 SGPRs, which is how two sixteen-wave workgroups never shared a CU in round 5): the
+    kernel metadata of the built library must admit what the policy assumes."""
+    import subprocess
+    import webrtc_aecm_amd as aecm
+    from webrtc_aecm_amd import build, isa_census
+    build.build()
+    lib = tmp_path / build.LIB.name
+    lib.write_bytes(build.LIB.read_bytes())
+    subprocess.run([isa_census._tool("llvm-objdump"), "--offloading", str(lib)], check=True, capture_output=True)
+    meta = ""
+    for obj in sorted(tmp_path.glob(lib.name + ".*amdgcn*gfx950*")):
+        meta += subprocess.run([isa_census._tool("llvm-readelf"), "--notes", str(obj)], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    for block in re.split(r"\n\s*- \.agpr_count:", meta)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = (int(re.search(r"\.sgpr_count:\s+(\d+)", block).group(1)), int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)),
+                         int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)))
+    assert len(kernels) >= 25
+
+    def admitted(sym_regex):
+        hits = [(k, v) for k, v in kernels.items() if re.search(sym_regex, k)]
+        assert len(hits) == 1, (sym_regex, [k for k, _ in hits])
+        (sgpr, vgpr, scratch) = hits[0][1]
+        return min(8, 512 // (-(-vgpr // 8) * 8), 800 // (-(-sgpr // 16) * 16 + 16)), scratch
+
+    cus = 256
+    for S, T in ((1000, 300), (2048, 300), (3000, 300), (4096, 300), (5000, 300), (65536, 1280), (6000, 40)):
+        d = aecm.describe_launch_detail(S, T, cus)
+        need = -(-d["workgroups_per_cu"] * d["waves_per_workgroup"] // 4)                  # waves per SIMD the policy counts on
+        waves, scratch = admitted(isa_census.block_kernel(d["form"], False, d["chunk_blocks"] if d["form"] == 2 else d["shape"])[0])
+        assert waves >= need and scratch == 0, (S, T, d, waves, scratch)
+    d = aecm.describe_tick(65536, cus)
+    waves, _ = admitted(r"aecm_tick_flow_kernelILb0E")
+    assert waves >= -(-d["workgroups_per_cu"] * d["waves_per_workgroup"] // 4), (d, waves)
+
+
 def test_forwarder_header_and_unmodified_reference_caller_links():
     """include/aecm/echo_control_mobile.h makes `#include "aecm/echo_control_mobile.h"` (reference main.cc:18) find the
     drop-in declarations; where the reference tree is present its main.cc, unmodified, compiles against include/
