@@ -267,6 +267,57 @@ def load_profile_record(lib_path, workload_key, kernel_substr):
     return traffic, note
 
 
+def live_counters(child_args, kernel_regex, frames_per_launch, kernel_avg_s, compute_units):
+    """HBM traffic and issued instructions of the dominant kernel measured IN THIS RUN (not quoted from profiles/): three short
+    rocprofv3 --pmc passes over child runs of this script with the same workload (counters in their own passes with --kernel-trace
+    only; FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, rocprofv3 section), averaged per launch of the kernel
+    this run timed.  Corrections as that guide prescribes for gfx950: the counters are in KiB; FETCH_SIZE tallies the kernel's wide
+    coalesced reads at half their bytes (x 2: profiles/r06_rocprof_summary.json calibrates 1.998 on a known byte count of this very
+    access pattern); WRITE_SIZE as it is.  None (with the reason) where rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if exe is None:
+        return {"available": False, "reason": "rocprofv3 not found"}
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"]):
+        d = tempfile.mkdtemp(prefix="aecm_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "b", "--",
+                   sys.executable, str(Path(__file__).resolve()), *child_args, "--no-cpu-baseline", "--no-parity", "--no-live-counters", "--steps", "2", "--warmup", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            vals = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if re.search(kernel_regex, row["Kernel_Name"]) or kernel_regex.split("IL")[0].replace("aecm_", "aecm::aecm_") in row["Kernel_Name"]:
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return {"available": False, "reason": f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"}
+            out.update({k: sum(v) / len(v) for k, v in vals.items()})
+        except (OSError, subprocess.SubprocessError) as e:
+            return {"available": False, "reason": f"rocprofv3 pass failed: {e}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = out["FETCH_SIZE"] * 1024 * 2.0, out["WRITE_SIZE"] * 1024
+    # issue: shader cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs) x SIMDs / wave64 VALU instructions
+    cycles = out.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    per_valu = cycles * compute_units * 4 / out["SQ_INSTS_VALU"] if cycles and out.get("SQ_INSTS_VALU") else None
+    return {"available": True, "how": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE) over child runs of this "
+                                      "command, 3 launches each, averaged per launch of the timed kernel; FETCH_SIZE x 1024 x 2 (gfx950), WRITE_SIZE x 1024",
+            "shader_cycles_per_launch": cycles or None, "cycles_per_valu_inst": per_valu,
+            "valu_port_busy_frac_at_4_cycles_per_inst": 4.0 / per_valu if per_valu else None,
+            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+            "hbm_GBps_at_this_runs_kernel_time": (rd + wr) / kernel_avg_s / 1e9,
+            "valu_insts_per_frame": out["SQ_INSTS_VALU"] / frames_per_launch, "salu_insts_per_frame": out["SQ_INSTS_SALU"] / frames_per_launch,
+            "waves_per_launch": out.get("SQ_WAVES"), "seconds": time.perf_counter() - t0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +334,8 @@ def main():
     ap.add_argument("--variant", choices=["fast", "safe"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the CPU re-run of the timed workload (A/B timing loops only)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="skip the rocprofv3 counter passes that measure roofline.traffic in this very run (N = 1 only; ~40 s)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the counter gather (nccl = RCCL)")
     ap.add_argument("--share-devices", action="store_true",
                     help="map rank r to HIP device r %% device_count (exercises the N-rank path on a box with fewer GPUs; "
@@ -438,6 +491,24 @@ def main():
                                  "see issue_bound for the binding resource",
                          "issue_bound": issue},
         }
+        # roofline.traffic measured in THIS run (N = 1): counter passes over child runs of the same command; the quoted profile record
+        # stays beside it (issue_bound: the port-busy fractions need the SQ cycle counters of the full profile)
+        if world == 1 and not args.no_live_counters and not args.no_cpu_baseline and args.variant == "fast":
+            child = ["--streams", str(S), "--blocks", str(T), "--fs", str(args.fs), "--profile", args.profile]
+            if args.clean:
+                child.append("--clean")
+            if args.launch_blocks:
+                child += ["--launch-blocks", str(args.launch_blocks)]
+            if args.policy:
+                child += ["--policy", args.policy]
+            if args.fixed_delay >= 0:
+                child += ["--fixed-delay", str(args.fixed_delay)]
+            live = live_counters(child, kernel_substr, S * C, kern_avg_s / len(chunks), aecm.device_info(local_rank)[1])
+            res["roofline"]["live_counters"] = live
+            if live.get("available"):
+                res["roofline"]["traffic_quoted_from_profile"] = res["roofline"]["traffic"]
+                res["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = "measured in this run (live_counters)"
         shares = parity.pop("content_shares", None) if parity is not None else None
         # what the frame rate was measured ON: the signal profile and, from the checker's streams over the timed passes, how many
         # blocks took the data-dependent paths that cost or save work (profiles/r06_content_sweep.txt has all profiles side by side)
