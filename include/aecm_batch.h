@@ -320,25 +320,33 @@ int32_t WebRtcAecmBatch_DescribeLaunchFor(int32_t num_streams, int32_t compute_u
  *                          2 / 4, raw hand-over 0 / 1, delay wavefronts 0 / 2 / 4, gain wavefronts 0 / 4; pipe_spread 1 = every compute
  *                          unit gets the shape's full count of workgroups, of fewer than four streams each where the launch is short of
  *                          streams (0: workgroups of four); pipe_wgs_per_cu > 0 = workgroups of the shape a compute unit takes;
- *                          pipe_rot >= 0 = the slot rotations (csrc/aecm_kernels.h: PipeShape::rot) */
+ *                          pipe_rot >= 0 = the slot rotations, pipe_prio >= 0 = the role wavefronts' issue priorities (csrc/aecm_kernels.h:
+ *                          PipeShape::rot / prio) */
 typedef struct AecmLaunchPolicy {
     int32_t struct_size;
     int32_t compute_units;
     int32_t queue_chunk_blocks, queue_chunk_explicit, queue_min_streams;
     int32_t pipelined_min_streams, pipelined_min_blocks, pipelined_max_streams;
     int32_t resident_waves, rotation_stream_limit;
-    int32_t pipe_tail_waves, pipe_front_waves, pipe_raw, pipe_delay_waves, pipe_gain_waves, pipe_spread, pipe_wgs_per_cu, pipe_rot;
+    int32_t pipe_tail_waves, pipe_front_waves, pipe_raw, pipe_delay_waves, pipe_gain_waves, pipe_spread, pipe_wgs_per_cu, pipe_rot, pipe_prio;
 } AecmLaunchPolicy;
 int32_t WebRtcAecmBatch_DefaultLaunchPolicy(int32_t compute_units, AecmLaunchPolicy *policy);
 int32_t WebRtcAecmBatch_GetLaunchPolicy(const AecmBatch *b, AecmLaunchPolicy *policy);
 int32_t WebRtcAecmBatch_SetLaunchPolicy(AecmBatch *b, const AecmLaunchPolicy *policy);
 /* What a launch looks like on the device, for capacity planning (no device needed): the form and its detail as DescribeLaunch gives
  * them, the grid, and how the grid quantises on the chip -- rounds_x1000 = 1000 x workgroups / (compute units x workgroups a compute
- * unit holds at once): 1000 = the chip exactly full once; 9140 = nine full rounds and a last one 14 % full (65 536 sessions' tick).
+ * unit holds at once): 1000 = the chip exactly full once; 9140 = nine full rounds and a last one 14 % full (65 536 sessions' tick);
+ * and how evenly a pipelined launch loads the compute units (cu_load_evenness_x1000: batches that are multiples of the unit count
+ * lose nothing, one stream more loses up to 1 / (streams per unit + 1) of the frame rate).
  * policy == NULL: the default policy of compute_units.  WebRtcAecmSessions_DescribeTick: the same for one tick of num_sessions sessions. */
 typedef struct AecmLaunchDescription {
     int32_t form, chunk_blocks, shape;
     int32_t workgroups, waves_per_workgroup, workgroups_per_cu, rounds_x1000;
+    /* pipelined launches keep every stream on one compute unit for the whole launch, so the launch ends when the fullest unit does:
+     * 1000 x (streams / compute units) / (streams on the fullest unit) -- 1000 when the batch is a multiple of the unit count,
+     * 800 for 1 025 streams on 256 units (one unit carries five streams, the average four).  1000 for the other forms (the chunk queue
+     * balances dynamically; one wavefront per stream runs in rounds: rounds_x1000). */
+    int32_t cu_load_evenness_x1000;
 } AecmLaunchDescription;
 int32_t WebRtcAecmBatch_DescribeLaunchDetail(const AecmLaunchPolicy *policy, int32_t compute_units, int32_t num_streams, int32_t num_blocks,
                                              int32_t has_clean_input, AecmLaunchDescription *out);

@@ -88,7 +88,7 @@ def test_launch_policy_is_one_value_and_the_library_reads_no_environment(monkeyp
     assert p.as_dict() == dict(struct_size=C.sizeof(ffi.AecmLaunchPolicy), compute_units=256, queue_chunk_blocks=128, queue_chunk_explicit=0,
                                queue_min_streams=-1, pipelined_min_streams=2, pipelined_min_blocks=3, pipelined_max_streams=4096,
                                resident_waves=7168, rotation_stream_limit=6144, pipe_tail_waves=-1, pipe_front_waves=-1, pipe_raw=-1,
-                               pipe_delay_waves=-1, pipe_gain_waves=-1, pipe_spread=1, pipe_wgs_per_cu=0, pipe_rot=-1)
+                               pipe_delay_waves=-1, pipe_gain_waves=-1, pipe_spread=1, pipe_wgs_per_cu=0, pipe_rot=-1, pipe_prio=-1)
     assert aecm.describe_launch_for(1024, 256, 300) == (3, 0x1a02)                      # the environment above changed nothing
     # wishes on a policy
     shape = lambda **kw: (lambda q: [setattr(q, k, v) for k, v in kw.items()] and aecm.describe_launch_detail(1024, 300, policy=q))(aecm.default_launch_policy(256))
@@ -114,17 +114,20 @@ def test_launch_policy_is_one_value_and_the_library_reads_no_environment(monkeyp
                             assert d["form"] == 3 and d["shape"] in built, (tail, front, raw, delay, gain, S, hex(d["shape"]))
     assert shape(pipelined_min_streams=0)["form"] == 0
     assert shape(queue_min_streams=0, pipelined_min_streams=5000) == dict(form=2, chunk_blocks=32, shape=0, workgroups=256, waves_per_workgroup=4,
-                                                                           workgroups_per_cu=7, rounds_x1000=142)
+                                                                           workgroups_per_cu=7, rounds_x1000=142, cu_load_evenness_x1000=1000)
     # every CU its full count of workgroups: 1 536 streams = two sixteen-wave workgroups of three streams per CU; without the spread, 384 of four
     d = aecm.describe_launch_detail(1536, 300, 256)
     assert (d["workgroups"], d["waves_per_workgroup"], d["workgroups_per_cu"], d["rounds_x1000"]) == (512, 16, 2, 1000)
     assert shape(pipe_spread=0)["workgroups"] == 256 and aecm.describe_launch_detail(2560, 300, 256)["workgroups"] == 768
     # a tick of 65 536 sessions: 16 384 workgroups on 1 792 places (the last round 14 % full)
     assert aecm.describe_tick(65536, 256) == dict(form=0, chunk_blocks=0, shape=0, workgroups=16384, waves_per_workgroup=4, workgroups_per_cu=7,
-                                                  rounds_x1000=9142)
+                                                  rounds_x1000=9142, cu_load_evenness_x1000=1000)
+    # a pipelined launch keeps a stream on one CU: batches that are multiples of the CU count load every CU alike, one stream more does not
+    assert [aecm.describe_launch_detail(S, 300, 256)["cu_load_evenness_x1000"] for S in (256, 1024, 1025, 1280, 2049, 3072, 4095, 100)] == \
+        [1000, 1000, 800, 1000, 889, 1000, 999, 1000]
     # refused: another struct size, values outside what the kernels exist for
     for bad in (dict(struct_size=8), dict(pipe_front_waves=3), dict(pipe_gain_waves=2), dict(queue_chunk_blocks=-1), dict(pipelined_max_streams=5000),
-                dict(pipe_rot=4096)):
+                dict(pipe_rot=4096), dict(pipe_prio=256)):
         q = aecm.default_launch_policy(256)
         for k, v in bad.items():
             setattr(q, k, v)

@@ -27,6 +27,8 @@ PREFIX=psmall PARTS="stats hbm sq cal" BENCH_ARGS="--streams 1024 --blocks 2048"
 bash tools/content_sweep.sh > $O/${T}_content_sweep.txt 2>&1
 {
 python tools/sweep_streams.py --sizes 256:8192:256 --blocks 2048 --tolerance 0.01 2>&1 | grep -v amdgpu.ids
+echo "# between the multiples of the CU count (the static placement's sawtooth) and right behind each shape's largest launch:"
+python tools/sweep_streams.py --sizes 1025,1100,1152,2049,2100,2176,3073,3150,3200,4097,4200 --blocks 2048 --tolerance 1.0 2>&1 | grep -v "amdgpu.ids\|monotone"
 for a in "--streams 4 --blocks 2048" "--streams 64 --blocks 2048" "--streams 1024 --blocks 2048" "--streams 1536 --blocks 2048" "--streams 2560 --blocks 2048" \
          "--streams 4096 --blocks 2048" "--streams 16384" "--fs 8000 --streams 32768" "--streams 131072 --blocks 512" "--clean" "--variant safe"; do
   python bench.py --no-cpu-baseline $a | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a', round(d['value']/1e6,1), 'M frames/s; parity', d['parity']['ok'], ';', d['roofline']['kernel'], ';', d['config']['workload'][:70])"

@@ -396,7 +396,7 @@ template <int kTail, bool kBalance, bool kRaw = false, int kFront = 2, int kDela
 __global__ __launch_bounds__(64 * PipeWaves(kTail, kFront, kDelay, kGain))
 __attribute__((amdgpu_waves_per_eu(PipeWavesPerEu(kTail, kFront, kDelay, kGain), AECM_MAX_WAVES_PER_EU)))
 void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int streams_base, int streams_rem, int n_blocks, uint32_t *progress, int n_workgroups,
-                                    int wgs_per_round, int rot) {
+                                    int wgs_per_round, int rot, int prio) {
     constexpr int kMode = kBalance ? AECM_PIPE_BALANCE : 0;               // AECM_PIPE_BALANCE's meaning, per instantiation
     constexpr int kFrontBehind = kBalance ? AECM_PIPE_FRONT_PRIO_BEHIND : AECM_PIPE_FRONT_PRIO;
     // the second-stream boost is for the launches without balance: on top of it, it costs (4 096 streams: 862 M frames/s without, 844 with)
@@ -540,7 +540,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int streams_base, in
         // ---- front wave: two streams, the transforms of the block after the one their back waves are at ----
         typename EF::Regs r;
         EF::init_lane_constants(r, st.consts);
-        int level = kFrontBehind;                                         // this group's base priority (constant without balance)
+        int level = kBalance ? kFrontBehind : (prio & 3);                 // this group's base priority (without balance: the launch's, PipeShape::prio)
         SetPrioDynamic(level);
         k0 = slot_of((wave - kPipeStreams) * kPipeStreamsPerFront, rot_front);        // (a wave of two slots: k0 and the one after it, round the ring)
         int x_old[kPipeStreamsPerFront], d_old[kPipeStreamsPerFront], far_next[kPipeStreamsPerFront], near_next[kPipeStreamsPerFront];
@@ -670,7 +670,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int streams_base, in
         typename EF::Regs r;
         EF::init_lane_constants(r, st.consts);
         r.u.prio_drop = 0;
-        __builtin_amdgcn_s_setprio(AECM_PIPE_TAIL_PRIO);
+        SetPrioDynamic((prio >> 2) & 3);
         k0 = slot_of((wave - kPipeStreams - kPipeFrontWaves) * kPer, rot_tail);
         int ovl[kPer], c_old[kPer];
         bool live[kPer];
@@ -711,7 +711,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int streams_base, in
             typename EF::Regs r;
             EF::init_lane_constants(r, st.consts);
             r.u.prio_drop = 0;
-            __builtin_amdgcn_s_setprio(AECM_PIPE_DELAY_PRIO);
+            SetPrioDynamic((prio >> 4) & 3);
             k0 = slot_of((wave - (kPipeStreams + kPipeFrontWaves + kTail)) * kPer, rot_delay);
             // the estimator's state per stream (BlockEngine::load_delay_state's fields), moved into r around each call
             int mean[kPer], bh0[kPer], bh1[kPer], m01[kPer], far_init[kPer], near_init[kPer], min_prob[kPer], last_prob[kPer], last_delay[kPer];
@@ -799,7 +799,7 @@ void aecm_process_pipelined_kernel(StatePtrs st, IoView io, int streams_base, in
             typename EF::Regs r;
             EF::init_lane_constants(r, st.consts);
             r.u.prio_drop = 0;
-            __builtin_amdgcn_s_setprio(AECM_PIPE_GAIN_PRIO);
+            SetPrioDynamic((prio >> 6) & 3);
             const int k = slot_of(wave - (kPipeStreams + kPipeFrontWaves + kTail + kDelay), rot_gain);
             const int64_t stream = slot_stream(k);
             const bool live = slot_live(k);
@@ -895,7 +895,7 @@ PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, cons
     const int spread = wishes.spread, wgs = wishes.wgs_per_cu;
     const int cus = compute_units > 0 ? compute_units : 256;
     const int n_wg = (n_streams + kPipeStreams - 1) / kPipeStreams;
-    PipeShape sh{0, 2, false, false, 0, 0, cus, 0, n_wg};
+    PipeShape sh{0, 2, false, false, 0, 0, cus, 0, 0, n_wg};
     const int want_tail = tail_waves < 0 ? 2 : tail_waves;
     if (want_tail >= 2 && n_streams <= PipelinedStreamLimit(cus, 2, 2, 0, 0, wgs)) sh.tail_waves = 2;
     const int want_front = front_waves < 0 ? (n_wg > cus ? 4 : 2) : front_waves;
@@ -945,6 +945,16 @@ PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, cons
     else if (sh.tail_waves == 2 && sh.front_waves == 2 && sh.delay_waves == 0) sh.rot = 3 | (2 << 8);
     else sh.rot = 0;
     if (wishes.rot >= 0) sh.rot = wishes.rot;
+    // The roles' issue priorities (the channel / middle / back waves': by phase of the block, 1..3): front | tail << 2 | delay << 4 | gain << 6.
+    // Swept like the rotations (profiles/r06_experiments.md section 1.5; M frames/s):
+    //   sixteen waves, two to four streams per workgroup: the delay waves at 0 instead of 1    1 280 streams 648 -> 682, 1 536: 682 -> 684, 1 792: 700 -> 708, 2 048: 727 -> 721
+    //     (workgroups of one stream keep 1: 512 streams 443 vs 432)
+    //   eight waves, workgroups not all full: the tail waves at 0 instead of 1                 2 304 streams 676 -> 685, 2 560: 705 -> 732, 2 816: 751 -> 783 (3 072, all full: 787 at 1, 760 at 0)
+    int tail_prio = AECM_PIPE_TAIL_PRIO, delay_prio = AECM_PIPE_DELAY_PRIO;
+    if (sh.gain_waves != 0 && n_streams >= 2 * sh.workgroups) delay_prio = 0;
+    if (sh.tail_waves == 2 && sh.front_waves == 2 && sh.delay_waves == 0 && n_streams < kPipeStreams * sh.workgroups) tail_prio = 0;
+    sh.prio = AECM_PIPE_FRONT_PRIO | (tail_prio << 2) | (delay_prio << 4) | (AECM_PIPE_GAIN_PRIO << 6);
+    if (wishes.prio >= 0) sh.prio = wishes.prio;
     return sh;
 }
 
@@ -969,7 +979,7 @@ hipError_t LaunchProcessBlocksPipelined(const StatePtrs &st, const IoView &io, i
     if (!shape.balance) progress = nullptr;
 #endif
 #define AECM_LAUNCH_PIPE(T, B, R, F, D, G) hipLaunchKernelGGL((aecm_process_pipelined_kernel<T, B, R, F, D, G>), grid, block, sizeof(LdsTables) + sizeof(PipeShared<T, R, D, G>), \
-                                                              stream, st, io, streams_base, streams_rem, n_blocks, progress, (int)grid.x, shape.wgs_per_round, shape.rot)
+                                                              stream, st, io, streams_base, streams_rem, n_blocks, progress, (int)grid.x, shape.wgs_per_round, shape.rot, shape.prio)
     // The instantiations the library carries (PipelinedShapeFor only ever asks for these).  One tail wave for four streams (kTail = 1,
     // seven-wave workgroups) measured slower than its neighbours at every size and is not built.
     const int key = shape.gain_waves * 10000 + shape.delay_waves * 1000 + shape.tail_waves * 100 + shape.front_waves * 10 + (shape.raw ? 1 : 0);

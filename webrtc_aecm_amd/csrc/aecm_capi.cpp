@@ -314,7 +314,7 @@ int32_t WebRtcAecmBatch_DescribeLaunchFor(int32_t num_streams, int32_t compute_u
 static void PolicyToAbi(const aecm::LaunchPolicy &p, AecmLaunchPolicy *o) {
     *o = AecmLaunchPolicy{(int32_t)sizeof(AecmLaunchPolicy), p.compute_units, p.queue_chunk_blocks, p.queue_chunk_explicit ? 1 : 0, p.queue_min_streams,
                           p.pipelined_min_streams, p.pipelined_min_blocks, p.pipelined_max_streams, p.resident_waves, p.rotation_stream_limit,
-                          p.pipe.tail_waves, p.pipe.front_waves, p.pipe.raw, p.pipe.delay_waves, p.pipe.gain_waves, p.pipe.spread, p.pipe.wgs_per_cu, p.pipe.rot};
+                          p.pipe.tail_waves, p.pipe.front_waves, p.pipe.raw, p.pipe.delay_waves, p.pipe.gain_waves, p.pipe.spread, p.pipe.wgs_per_cu, p.pipe.rot, p.pipe.prio};
 }
 static aecm::LaunchPolicy PolicyFromAbi(const AecmLaunchPolicy &a) {
     aecm::LaunchPolicy p;
@@ -335,6 +335,7 @@ static aecm::LaunchPolicy PolicyFromAbi(const AecmLaunchPolicy &a) {
     p.pipe.spread = a.pipe_spread;
     p.pipe.wgs_per_cu = a.pipe_wgs_per_cu;
     p.pipe.rot = a.pipe_rot;
+    p.pipe.prio = a.pipe_prio;
     return p;
 }
 
@@ -360,7 +361,7 @@ int32_t WebRtcAecmBatch_SetLaunchPolicy(AecmBatch *b, const AecmLaunchPolicy *po
 }
 
 static void DescriptionToAbi(const aecm::LaunchDescription &d, AecmLaunchDescription *o) {
-    *o = AecmLaunchDescription{d.form, d.chunk_blocks, d.shape, d.workgroups, d.waves_per_workgroup, d.workgroups_per_cu, d.rounds_x1000};
+    *o = AecmLaunchDescription{d.form, d.chunk_blocks, d.shape, d.workgroups, d.waves_per_workgroup, d.workgroups_per_cu, d.rounds_x1000, d.cu_load_evenness_x1000};
 }
 
 int32_t WebRtcAecmBatch_DescribeLaunchDetail(const AecmLaunchPolicy *policy, int32_t compute_units, int32_t num_streams, int32_t num_blocks,

@@ -35,6 +35,7 @@ static void ApplyEnvironmentWishes(LaunchPolicy *p) {
     num("AECM_PIPE_SPREAD", &p->pipe.spread);
     num("AECM_PIPE_WGS", &p->pipe.wgs_per_cu);
     num("AECM_PIPE_ROT", &p->pipe.rot);
+    num("AECM_PIPE_PRIO", &p->pipe.prio);
     num("AECM_PIPE_MAX_STREAMS", &p->pipelined_max_streams);
     if (const char *env = getenv("AECM_PIPELINED")) p->pipelined_min_streams = atoi(env) > 0 ? atoi(env) : 0x7fffffff;   // 0: off; n: from n streams
     if (const char *env = getenv("AECM_PIPE_MIN_BLOCKS")) p->pipelined_min_blocks = atoi(env) > 1 ? atoi(env) : 1;
@@ -62,7 +63,7 @@ bool LaunchPolicyValid(const LaunchPolicy &p) {
            p.pipelined_max_streams >= 0 && p.pipelined_max_streams <= PipelinedStreamLimit(p.compute_units, 0) && p.resident_waves > 0 &&
            p.resident_waves <= ResidentWaves(p.compute_units) && p.rotation_stream_limit >= 0 && in(w.tail_waves, {-1, 0, 2}) &&
            in(w.front_waves, {-1, 2, 4}) && in(w.raw, {-1, 0, 1}) && in(w.delay_waves, {-1, 0, 2, 4}) && in(w.gain_waves, {-1, 0, 4}) &&
-           in(w.spread, {0, 1}) && w.wgs_per_cu >= 0 && w.wgs_per_cu <= 8 && w.rot >= -1 && w.rot < 1024;
+           in(w.spread, {0, 1}) && w.wgs_per_cu >= 0 && w.wgs_per_cu <= 8 && w.rot >= -1 && w.rot < 1024 && w.prio >= -1 && w.prio < 256;
 }
 
 BatchEngine *BatchEngine::Create(int num_streams, int device_id) {
@@ -286,6 +287,17 @@ LaunchDescription DescribeLaunchWith(const LaunchPolicy &p, int variant, int cou
         d.waves_per_workgroup = PipelinedWorkgroupWaves(sh);
         d.workgroups_per_cu = p.pipe.wgs_per_cu > 0 ? p.pipe.wgs_per_cu : PipelinedWorkgroupsPerCu(sh);
         rounds(d);
+        // workgroups i, i + CUs, ... share a CU (the dispatcher deals them out in turn); the first count % workgroups serve one stream more
+        {
+            const int base = count / sh.workgroups, rem = count % sh.workgroups;
+            int fullest = 0;
+            for (int c = 0; c < std::min(cus, sh.workgroups); ++c) {
+                int load = 0;
+                for (int w = c; w < sh.workgroups; w += cus) load += base + (w < rem ? 1 : 0);
+                fullest = std::max(fullest, load);
+            }
+            d.cu_load_evenness_x1000 = (int)((int64_t)1000 * count / ((int64_t)std::max(fullest, 1) * std::min(cus, sh.workgroups)));
+        }
         return d;
     }
     d.form = variant == kVariantFast && count > p.rotation_stream_limit ? 1 : 0;

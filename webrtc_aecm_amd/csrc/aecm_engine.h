@@ -41,6 +41,7 @@ struct LaunchDescription {
     int workgroups = 0, waves_per_workgroup = 0;
     int workgroups_per_cu = 0;      // of this kernel a CU holds at once
     int rounds_x1000 = 0;           // 1000 x workgroups / (CUs x workgroups_per_cu): 1000 = the chip exactly full once; 9140 = nine full rounds and one 14 % full
+    int cu_load_evenness_x1000 = 1000;   // pipelined: 1000 x (streams / CUs) / streams on the fullest CU
 };
 LaunchDescription DescribeLaunchWith(const LaunchPolicy &policy, int variant, int num_streams, int num_blocks, bool has_clean);
 LaunchDescription DescribeTickLaunch(int num_sessions, int compute_units);

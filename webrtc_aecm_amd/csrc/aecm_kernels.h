@@ -51,6 +51,7 @@ struct PipeShape {
     int gain_waves;      // 0 or 4 per workgroup: the gain half of the back waves' work in waves of its own, one block behind the channel half (with delay waves)
     int wgs_per_round;   // the device's CUs: workgroups i, i + wgs_per_round, ... are taken to share a CU (the dispatcher deals them out in turn) and start their slots on different SIMDs
     int rot;             // slot rotations: front | gain << 2 | delay << 4 | per workgroup of a CU << 6 | tail << 8 (the kernel's slot_of)
+    int prio;            // the roles' issue priorities: front | tail << 2 | delay << 4 | gain << 6 (the channel / middle / back waves': by phase, 1..3)
     int workgroups;      // of the launch: ceil(n_streams / 4) .. n_streams; the streams are dealt out evenly (the first n_streams % workgroups serve one more)
 };
 // What a caller may wish for the shape instead of leaving it to the launch's size (experiments, tests: AecmLaunchPolicy in
@@ -60,6 +61,7 @@ struct PipeWishes {
     int spread = 1;          // != 0: every CU gets the shape's full count of workgroups, of fewer than four streams each where the launch is short of streams
     int wgs_per_cu = 0;      // > 0: workgroups of the shape a CU takes (0: what the shape is built for)
     int rot = -1;            // >= 0: PipeShape::rot
+    int prio = -1;           // >= 0: PipeShape::prio
 };
 // The shape a launch of this size takes on a device of compute_units CUs.
 PipeShape PipelinedShapeFor(int n_streams, int n_blocks, int compute_units, const PipeWishes &wishes = PipeWishes());

@@ -72,14 +72,14 @@ class AecmLaunchPolicy(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "compute_units", "queue_chunk_blocks", "queue_chunk_explicit", "queue_min_streams", "pipelined_min_streams",
         "pipelined_min_blocks", "pipelined_max_streams", "resident_waves", "rotation_stream_limit", "pipe_tail_waves", "pipe_front_waves",
-        "pipe_raw", "pipe_delay_waves", "pipe_gain_waves", "pipe_spread", "pipe_wgs_per_cu", "pipe_rot")]
+        "pipe_raw", "pipe_delay_waves", "pipe_gain_waves", "pipe_spread", "pipe_wgs_per_cu", "pipe_rot", "pipe_prio")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class AecmLaunchDescription(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("form", "chunk_blocks", "shape", "workgroups", "waves_per_workgroup", "workgroups_per_cu", "rounds_x1000")]
+    _fields_ = [(n, C.c_int32) for n in ("form", "chunk_blocks", "shape", "workgroups", "waves_per_workgroup", "workgroups_per_cu", "rounds_x1000", "cu_load_evenness_x1000")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
