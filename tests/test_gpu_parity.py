@@ -1143,6 +1143,44 @@ def test_far_end_bursts_in_session_batches_vs_reference_sessions(fs, frame, with
 
 
 @_needs_ref
+@pytest.mark.parametrize("fs,frame", [(16000, 160), (8000, 80)])
+def test_far_end_burst_of_255_calls_overflows_the_jitter_buffer(fs, frame):
+    """The largest burst the ABI takes (255 WebRtcAecm_BufferFarend calls per session in one launch; host pointers: staged in
+    rounds) into a jitter buffer that holds 4 000 samples: the reference truncates the call that no longer fits and drops
+    the rest (ring_buffer.c:142-170).  Before and after: ordinary ticks, which must go on from the overflowed buffer exactly
+    as the reference's sessions do (delay compensation, read-pointer moves)."""
+    S, n_ticks = 3, 90
+    pairs = [synth_pair(8100 + k, (n_ticks + 260) * frame // 64 + 1, fs, "mixed") for k in range(S)]
+    refs = [pyoracle.RefSession(fs, 1, 3) for _ in range(S)]
+    sb = aecm.AecmSessions(S, fs, 1, 3)
+    cursor = np.zeros(S, dtype=np.int64)
+
+    def tick(i):
+        n = frame
+        far = np.stack([pairs[k][0][cursor[k]:cursor[k] + n] for k in range(S)])
+        near = np.stack([pairs[k][1][i * frame:(i + 1) * frame] for k in range(S)])
+        rc, out = sb.tick_host(far, near, 40)
+        for k in range(S):
+            assert refs[k].buffer_farend(far[k]) == 0
+            rc1, o1 = refs[k].process(near[k], None, 40)
+            assert rc == rc1 and np.array_equal(out[k], o1), (fs, i, k)
+        cursor[:] += n
+    for i in range(30):
+        tick(i)
+    # 255 calls each (session 1: 254, session 2: none): far more than the buffer holds
+    calls = np.array([255, 254, 0], dtype=np.uint8)
+    rows = np.stack([pairs[k][0][cursor[k]:cursor[k] + 255 * frame] for k in range(S)])
+    assert sb.buffer_farend_host(rows, frame, 255, calls) == 0
+    for k in range(S):
+        for j in range(int(calls[k])):
+            assert refs[k].buffer_farend(rows[k, j * frame:(j + 1) * frame]) == 0
+    cursor += calls.astype(np.int64) * frame
+    for i in range(30, 60):
+        tick(i)
+    sb.close()
+
+
+@_needs_ref
 def test_session_churn_slots_recycled_mid_run():
     """A media server recycling slots: sessions are re-initialised, re-configured and re-seeded (echo path) by index
     while the others keep running, with per-session delays and underruns; every slot must equal a reference
