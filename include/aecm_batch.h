@@ -266,23 +266,23 @@ int32_t WebRtcAecmBatch_SetKernelVariant(AecmBatch *b, int32_t variant);
 /* How a ProcessBlocks launch is scheduled on the device; results do not depend on it.  A launch of more streams than
  * the pipelined form takes (4 096 on an MI355X) is cut into chunks of chunk_blocks blocks that resident wavefronts
  * claim in order from a queue, so that all streams advance together and the launch does not end at low occupancy
- * (default: 128 blocks, environment AECM_QUEUE_CHUNK; the default / environment value is quartered, to at least 8, while
- * every stream's wavefront is resident at once -- a chunk_blocks set through this call is taken as it is).
+ * (default: 128 blocks; the default is quartered, to at least 8, while every stream's wavefront is resident at once -- a
+ * chunk_blocks set through this call is taken as it is).  (Shorthand for the queue_* fields of AecmLaunchPolicy, below.)
  * chunk_blocks = 0: one wavefront keeps one stream for the whole launch, always.  min_streams < 0 (default): the
  * threshold above; >= 0: the queue form above that many streams (diagnostics / tests). */
 int32_t WebRtcAecmBatch_SetLaunchChunking(AecmBatch *b, int32_t chunk_blocks, int32_t min_streams);
-/* Launches the chip holds at once (<= 4 streams x 4 workgroups per compute unit = 4 096 streams on an MI355X; fast
- * variant, no clean near-end input) run pipelined: six wavefronts serve four streams, the state-independent transforms
- * of a block in wavefronts of their own, one block ahead of the rest; up to 3 072 streams two more wavefronts per
- * workgroup run the inverse transforms and the synthesis one block behind (1 025 .. 2 048 streams: four front wavefronts;
- * up to 1 024 streams -- one workgroup per compute unit -- sixteen wavefronts per four streams: the delay estimator one block
- * ahead and the gain half of the block one block behind its channel half in wavefronts of their own as well),
- * above that the workgroups keep in step through progress feedback on their front wavefronts' issue priority.
+/* Launches the chip holds at once (<= 16 streams per compute unit = 4 096 streams on an MI355X; fast variant, no clean
+ * near-end input) run pipelined: a workgroup serves up to four streams with the state-independent transforms of a block in
+ * "front" wavefronts of their own, one block ahead of the rest.  Shape by streams per compute unit: up to 8 (2 048 streams)
+ * sixteen wavefronts per workgroup, two workgroups per unit -- the delay estimator one block ahead, the gain half of the block and
+ * the inverse transforms one block behind, each in wavefronts of their own; up to 12 (3 072) eight wavefronts (front and "tail"
+ * wavefronts of two streams each), three workgroups per unit; above that six (no tail wavefronts), four per unit, the workgroups kept
+ * in step through progress feedback on their front wavefronts' issue priority.  Every compute unit gets the shape's full count of
+ * workgroups, of one to four streams each, so that unit loads differ by at most one stream.
  * min_streams: the smallest batch that takes this form (default 2; <= 0: never).  Results do not depend on it.
  * By default launches of one or two blocks keep one wavefront per stream (the pipeline's fill and drain steps cost more than
- * they save there; environment AECM_PIPE_MIN_BLOCKS); after this call launches of any length from min_streams streams are pipelined.
- * Environment: AECM_PIPELINED (0 = never, n = from n); AECM_PIPE_TAIL / AECM_PIPE_FRONT / AECM_PIPE_RAW / AECM_PIPE_DELAY /
- * AECM_PIPE_GAIN override the shape (experiments). */
+ * they save there); after this call launches of any length from min_streams streams are pipelined.  (Shorthand for
+ * pipelined_min_streams / pipelined_min_blocks of AecmLaunchPolicy, below; its pipe_* fields override the shape.) */
 int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
 /* Which form a ProcessBlocks launch of num_blocks blocks over the whole batch takes, with (has_clean_input != 0) or
  * without a clean near-end input (for measurement tools that must name
@@ -296,7 +296,7 @@ int32_t WebRtcAecmBatch_SetLaunchPipelining(AecmBatch *b, int32_t min_streams);
 #define AECM_LAUNCH_CHUNK_QUEUE 2
 #define AECM_LAUNCH_PIPELINED 3
 int32_t WebRtcAecmBatch_DescribeLaunch(const AecmBatch *b, int32_t num_blocks, int32_t has_clean_input, int32_t *chunk_blocks);
-/* The same answer for a batch of num_streams streams (fast variant, default thresholds, the environment's wishes) on a device with
+/* The same answer for a batch of num_streams streams (fast variant, the default launch policy) on a device with
  * compute_units compute units -- no device and no batch needed (capacity planning; -1 for a non-positive argument). */
 int32_t WebRtcAecmBatch_DescribeLaunchFor(int32_t num_streams, int32_t compute_units, int32_t num_blocks, int32_t has_clean_input,
                                           int32_t *chunk_blocks);
