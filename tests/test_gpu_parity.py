@@ -1180,6 +1180,140 @@ def test_far_end_burst_of_255_calls_overflows_the_jitter_buffer(fs, frame):
     sb.close()
 
 
+class _LoggedRef:
+    """A reference session that remembers every call it received, so that a second reference session in the same state can be
+    made by replaying them (the reference has no way to copy an instance; migration tests need the copy)."""
+
+    def __init__(self, fs):
+        self.fs = fs
+        self.ref = pyoracle.RefSession(fs, 1, 3)
+        self.log = []
+
+    def call(self, name, *args):
+        self.log.append((name, args))
+        return getattr(self.ref, name)(*args)
+
+    def clone(self):
+        c = _LoggedRef(self.fs)
+        for name, args in self.log:
+            c.call(name, *args)
+        return c
+
+
+@_needs_ref
+@pytest.mark.parametrize("seed,fs", [(1, 16000), (2, 8000), (3, 16000)])
+def test_session_api_fuzz_vs_reference_sessions(seed, fs):
+    """Everything the session-batch ABI offers, interleaved at random for 1 500 steps on two AecmSessions objects of 6 sessions:
+    ticks in their three forms (uniform, per-session delay + flags incl. two 80-sample calls in a 160-sample tick, far-end
+    bursts + near-end only) with the frame size changing from tick to tick, bursts of 0 .. 6 (sometimes 40) far frames,
+    slots re-initialised, re-configured and re-seeded, and live sessions migrated between the two objects.  After every call
+    every session must equal a reference session that received exactly the same reference calls."""
+    rs = np.random.RandomState(seed)
+    S, steps = 6, 1500
+    objs = [aecm.AecmSessions(S, fs, 1, 3) for _ in range(2)]
+    refs = [[_LoggedRef(fs) for _ in range(S)] for _ in range(2)]
+    L = 900 * 160
+    audio = [[synth_pair(9000 + 10 * o + k, L // 64 + 1, fs, "mixed") for k in range(S)] for o in range(2)]
+    fpos = np.zeros((2, S), dtype=np.int64)                     # far / near read positions per session (wrap inside the recordings)
+    npos = np.zeros((2, S), dtype=np.int64)
+
+    def take(o, k, which, n):
+        pos = fpos if which == 0 else npos
+        a = audio[o][k][which]
+        start = int(pos[o, k]) % (a.size - 200 * 160)
+        pos[o, k] += n
+        return a[start:start + n]
+
+    n_migrations = n_bursts = n_cancelling = 0
+    for step in range(steps):
+        o = int(rs.randint(0, 2))
+        sb, rf = objs[o], refs[o]
+        op = rs.rand()
+        if op < 0.62:                                             # ---- a tick, in one of its forms
+            n = int(rs.choice([80, 160]))
+            ms = (40 + rs.randint(-15, 16, size=S)).astype(np.int16)
+            if rs.rand() < 0.05:
+                ms[rs.randint(0, S)] = rs.choice([-5, 700])
+            form = int(rs.randint(0, 3))
+            far = np.stack([take(o, k, 0, n) for k in range(S)])
+            near = np.stack([take(o, k, 1, n) for k in range(S)])
+            want, want_codes = np.empty((S, n), np.int16), np.empty(S, np.int32)
+            if form == 0:                                         # uniform: one far + one near call each
+                ms[:] = ms[0]
+                rc, out = sb.tick_host(far, near, int(ms[0]))
+                codes = np.full(S, rc)
+                flags = np.zeros(S, np.uint8)
+            elif form == 1:                                       # per-session delays and flags
+                flags = rs.choice([0, 0, 0, aecm.ffi.SESSION_NO_FAREND, aecm.ffi.SESSION_SPLIT_CALLS if n == 160 else 0], size=S).astype(np.uint8)
+                rc, out, codes = sb.tick_host_per_session(far, near, ms, flags=flags)
+            else:                                                 # far-end burst of 0 .. 3 frames of this size, then the near-end calls alone
+                k_s = rs.randint(0, 4, size=S)
+                rows = np.zeros((S, 3 * n), np.int16)
+                rows[:, :n] = far
+                for k in range(S):
+                    for j in range(1, int(k_s[k])):
+                        rows[k, j * n:(j + 1) * n] = take(o, k, 0, n)
+                assert sb.buffer_farend_host(rows, n, 3, k_s.astype(np.uint8)) == 0
+                rc, out, codes = sb.process_host(near, ms_per_session=ms)
+                flags = None
+            for k in range(S):
+                if form == 2:
+                    for j in range(int(k_s[k])):
+                        assert rf[k].call("buffer_farend", rows[k, j * n:(j + 1) * n].copy()) == 0
+                    want_codes[k], want[k] = rf[k].call("process", near[k].copy(), None, int(ms[k]))
+                elif flags[k] & aecm.ffi.SESSION_SPLIT_CALLS:
+                    c = 0
+                    for h in range(2):
+                        assert rf[k].call("buffer_farend", far[k, h * 80:(h + 1) * 80].copy()) == 0
+                        c1, want[k, h * 80:(h + 1) * 80] = rf[k].call("process", near[k, h * 80:(h + 1) * 80].copy(), None, int(ms[k]))
+                        c = c or c1
+                    want_codes[k] = c
+                else:
+                    if not flags[k] & aecm.ffi.SESSION_NO_FAREND:
+                        assert rf[k].call("buffer_farend", far[k].copy()) == 0
+                    want_codes[k], want[k] = rf[k].call("process", near[k].copy(), None, int(ms[k]))
+            assert np.array_equal(codes, want_codes), (seed, step, form)
+            bad = np.nonzero((out != want).any(axis=1))[0]
+            assert bad.size == 0, (seed, step, form, n, bad.tolist())
+            n_cancelling += int((out != near).any(axis=1).sum())                # calls past the start-up copy
+        elif op < 0.74:                                           # ---- a far-end burst on its own
+            n = int(rs.choice([80, 160]))
+            kmax = 40 if rs.rand() < 0.1 else 6
+            k_s = rs.randint(0, kmax + 1, size=S)
+            rows = np.stack([take(o, k, 0, kmax * n) for k in range(S)])
+            assert sb.buffer_farend_host(rows, n, kmax, k_s.astype(np.uint8)) == 0
+            for k in range(S):
+                for j in range(int(k_s[k])):
+                    assert rf[k].call("buffer_farend", rows[k, j * n:(j + 1) * n].copy()) == 0
+            n_bursts += 1
+        elif op < 0.80:                                           # ---- a slot is recycled
+            k = int(rs.randint(0, S))
+            assert sb.init_session(k) == 0 and rf[k].call("init", fs) == 0
+        elif op < 0.87:
+            k, cfg = int(rs.randint(0, S)), (int(rs.randint(0, 2)), int(rs.randint(0, 5)))
+            assert sb.set_config_session(k, *cfg) == 0 and rf[k].call("set_config", *cfg) == 0
+        elif op < 0.91:
+            k, path = int(rs.randint(0, S)), rs.randint(0, 6000, size=65).astype(np.int16)
+            assert sb.init_echo_path(k, path) == 0 and rf[k].call("init_echo_path", path.copy()) == 0
+        elif op < 0.95:
+            k = int(rs.randint(0, S))
+            rc, p = sb.get_echo_path(k)
+            rc1, p1 = rf[k].call("get_echo_path")
+            assert rc == rc1 == 0 and np.array_equal(p, p1), (seed, step)
+        else:                                                     # ---- a live session moves to the other object (the source goes on as well)
+            k, j = int(rs.randint(0, S)), int(rs.randint(0, S))
+            rc, snap = sb.export_session(k)
+            assert rc == 0 and objs[1 - o].import_session(j, snap) == 0
+            refs[1 - o][j] = rf[k].clone()
+            fpos[1 - o, j], npos[1 - o, j] = fpos[o, k], npos[o, k]
+            audio[1 - o][j] = audio[1 - o][j]                     # (the imported session continues on ITS slot's audio: any audio is a valid continuation)
+            n_migrations += 1
+    print(f"fuzz seed {seed}: {n_migrations} migrations, {n_bursts} bursts, {n_cancelling} session-calls past start-up")
+    assert n_migrations >= 40 and n_bursts >= 100 and n_cancelling >= 2000
+    for sb in objs:
+        sb.close()
+
+
 @_needs_ref
 def test_session_churn_slots_recycled_mid_run():
     """A media server recycling slots: sessions are re-initialised, re-configured and re-seeded (echo path) by index
