@@ -778,6 +778,53 @@ def test_pipelined_shapes_by_wish(wish, shape):
     b.close()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_launch_policies_never_change_results(seed):
+    """Results never depend on how a launch is scheduled: one batch advanced by a dozen launches of random lengths, each under a
+    random valid launch policy -- any pipelined shape, workgroups of four or spread, any slot rotation and role priority, the chunk
+    queue forced onto small batches, one wavefront per stream -- must produce the oracle's outputs and states for every stream."""
+    rs = np.random.RandomState(seed)
+    cus = aecm.device_info(0)[1]
+    fs = int(rs.choice([16000, 8000]))
+    S = int(rs.choice([rs.randint(2, 40), rs.randint(40, 700), cus + rs.randint(-3, 4), 2 * cus + rs.randint(1, 90)]))
+    U = min(S, 20)
+    parts = [int(rs.choice([1, 2, 3, 5, 17, 40, 64])) for _ in range(12)]
+    T = sum(parts)
+    seeds = list(range(8800 + seed * 50, 8800 + seed * 50 + U))
+    far_u, near_u = synth_streams(seeds, T, fs)
+    exp = []
+    for k in range(U):
+        o = pyoracle.OracleStream(fs, *stream_config(k))
+        exp.append((o.process(far_u[k], near_u[k]), o.digest()))
+    idx = np.arange(S) % U
+    far, near = far_u[idx], near_u[idx]
+    b = aecm.AecmBatch(S, fs)
+    for s_ in range(S):
+        b.set_config(*stream_config(int(idx[s_])), s_, 1)
+    outs, pos, forms = [], 0, set()
+    for t in parts:
+        wishes = dict(pipe_tail_waves=int(rs.choice([-1, 0, 2])), pipe_front_waves=int(rs.choice([-1, 2, 4])), pipe_raw=int(rs.choice([-1, 0, 1])),
+                      pipe_delay_waves=int(rs.choice([-1, 0, 2, 4])), pipe_gain_waves=int(rs.choice([-1, 0, 4])), pipe_spread=int(rs.randint(0, 2)),
+                      pipe_rot=int(rs.choice([-1, rs.randint(0, 1024)])), pipe_prio=int(rs.choice([-1, rs.randint(0, 256)])),
+                      pipelined_min_streams=int(rs.choice([2, 2, 2, 0])), pipelined_min_blocks=int(rs.choice([1, 3])))
+        if rs.rand() < 0.25:                                  # the chunk queue on a batch this small: chunks of 8, at least two of them
+            wishes.update(queue_min_streams=0, queue_chunk_blocks=8, queue_chunk_explicit=1, pipelined_min_streams=0)
+        else:
+            wishes.update(queue_min_streams=-1, queue_chunk_blocks=128, queue_chunk_explicit=0)
+        b.set_launch_policy(**wishes)
+        forms.add(b.describe_launch(t)[0])
+        outs.append(b.process_host(far[:, pos * 64:(pos + t) * 64], near[:, pos * 64:(pos + t) * 64]))
+        pos += t
+    out = np.concatenate(outs, axis=1)
+    want = np.stack([e[0] for e in exp])[idx]
+    bad = np.nonzero((out != want).any(axis=1))[0]
+    assert bad.size == 0, (seed, S, fs, parts, bad[:8].tolist())
+    for s_ in (range(S) if S < 100 else list(range(0, S, S // 37)) + [S - 1]):
+        assert np.array_equal(b.digest(s_), exp[idx[s_]][1]), (seed, S, s_, describe_digest_diff(b.digest(s_), exp[idx[s_]][1]))
+    assert 3 in forms
+    b.close()
+
+
 def test_chunk_queue_launch_the_chip_holds_at_once():
     """5 003 streams (between the pipelined form's 4 096 and the chip's 7 168 resident waves): every wave is resident from the
     start and the launch still takes the chunk queue (items of 32 blocks), because the waves dispatched first pull ahead and
